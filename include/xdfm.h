@@ -1,0 +1,284 @@
+/*
+ * xdfm.h -- C ABI of libxdfm.so: the MI355X (gfx950) implementation of the
+ * xDeepFM CTR training path of recommenders.models.deeprec.
+ *
+ * The reference has no FFI for this path: its compute boundary is
+ * `sess.run(fetches, feed_dict)` (reference base_model.py:379-388, :402, :416)
+ * into TensorFlow 2.7.  Each entry point below replaces the TensorFlow ops one
+ * reference call site builds; the comment on it names that call site
+ * (paths are relative to /root/reference/recommenders/models/deeprec/).
+ *
+ * Conventions
+ *  - every function returns an int status: 0 = ok, <0 = error (see XDFM_E_*);
+ *    xdfm_last_error() returns the message of the calling thread's last error.
+ *  - device pointers are plain `void*`-compatible pointers into HBM owned by the
+ *    caller (PyTorch-ROCm allocations in the Python host); nothing is retained
+ *    after a call returns, nothing is allocated or freed by the library on the
+ *    device (the sort workspaces are sized by *_workspace_bytes and passed in).
+ *  - `stream` is a hipStream_t passed as void*; all device entry points only
+ *    enqueue work on it and return without synchronising.
+ *  - all floating point tensors are IEEE fp32, row-major, densely packed.
+ *  - `err_flag` is a device int32 the kernels OR error bits into
+ *    (XDFM_DEVERR_*); the host reads it at its next natural sync point.
+ */
+#ifndef XDFM_H_
+#define XDFM_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define XDFM_ABI_VERSION 1
+
+#define XDFM_OK 0
+#define XDFM_E_INVALID (-1)   /* bad argument (null pointer, size, enum) */
+#define XDFM_E_HIP (-2)       /* a HIP runtime call failed */
+#define XDFM_E_WORKSPACE (-3) /* workspace too small */
+#define XDFM_E_PARSE (-4)     /* malformed libffm text (host parser) */
+#define XDFM_E_IO (-5)        /* file could not be opened / mapped */
+#define XDFM_E_EOF (-6)       /* reader exhausted */
+
+/* bits OR-ed into the device error flag */
+#define XDFM_DEVERR_ID_RANGE 1  /* feature id outside [0, FEATURE_COUNT) */
+#define XDFM_DEVERR_ROW_RANGE 2 /* row (sample*FIELD_COUNT+field) outside [0, B*F) */
+#define XDFM_DEVERR_ROW_ORDER 4 /* dnn_feat_indices rows not ascending */
+
+/* optimizer enum: base_model.py:283-302 (TF1 optimizers, defaults of TF 2.7) */
+#define XDFM_OPT_SGD 0
+#define XDFM_OPT_ADAM 1
+#define XDFM_OPT_ADAGRAD 2
+
+/* loss enum: base_model.py:215-262 */
+#define XDFM_LOSS_LOG 0           /* tf.compat.v1.losses.log_loss, eps 1e-7 */
+#define XDFM_LOSS_CROSS_ENTROPY 1 /* sigmoid_cross_entropy_with_logits, mean */
+#define XDFM_LOSS_SQUARE 2        /* sqrt(mean((pred-y)^2)) */
+
+/* activation enum: base_model.py:339-353 */
+#define XDFM_ACT_IDENTITY 0
+#define XDFM_ACT_RELU 1
+#define XDFM_ACT_SIGMOID 2
+#define XDFM_ACT_TANH 3
+#define XDFM_ACT_ELU 4
+
+int xdfm_abi_version(void);
+const char* xdfm_last_error(void);
+
+/* ------------------------------------------------------------------------
+ * libffm text ingest (host).  Replaces FFMTextIterator.parser_one_line /
+ * load_data_from_file / _convert_data  (io/iterator.py:90-219).
+ * ---------------------------------------------------------------------- */
+typedef struct xdfm_ffm_reader xdfm_ffm_reader;
+
+typedef struct xdfm_ffm_batch_info {
+  int64_t n_rows;      /* samples in this batch (== batch_size except the last) */
+  int64_t nnz;         /* field:feature:value tokens in this batch */
+  int64_t dnn_width;   /* dnn_feat_shape[1] = max per-(sample,field) count (0 if nnz==0) */
+  int64_t imp_bytes;   /* total bytes of the impression-id strings */
+  int64_t first_line;  /* 1-based line number of the first sample (for messages) */
+} xdfm_ffm_batch_info;
+
+/* Opens (mmaps) `path`.  col_sep / id_sep are the reference's col_spliter / ID_spliter
+ * (single characters here).  iterator.py:50-63, :132. */
+int xdfm_ffm_open(const char* path, int64_t field_count, int64_t feature_count,
+                  char col_sep, char id_sep, xdfm_ffm_reader** out);
+/* Parses the next `batch_size` lines (fewer at end of file) into the reader's
+ * staging area and reports the sizes.  Returns XDFM_E_EOF when no line is left,
+ * XDFM_E_PARSE on a malformed line.  iterator.py:118-150, :90-116. */
+int xdfm_ffm_next(xdfm_ffm_reader* r, int64_t batch_size, xdfm_ffm_batch_info* info);
+/* Copies the staged batch into caller buffers, in the reference's layout
+ * (iterator.py:152-219).  Any pointer may be NULL to skip that array.
+ *   labels[n_rows]                      float32   (labels[:,0])
+ *   fm_feat_indices[nnz*2]              int64     [sample, feature] in file order
+ *   fm_feat_values[nnz]                 float32
+ *   dnn_feat_indices[nnz*2]             int64     [sample*F+field, k-th of that field], sorted
+ *   dnn_feat_values[nnz]                int64     feature id, same order
+ *   dnn_feat_weights[nnz]               float32   value, same order
+ *   row_ptr[n_rows*F+1]                 int32     CSR offsets of the dnn view (build extra;
+ *                                                 only valid when every row is in range)
+ *   imp_offsets[n_rows+1], imp_chars[imp_bytes]   impression ids; offset pair equal and
+ *   imp_present[n_rows]                           present==0 means "no id" (reference: int 0)
+ */
+int xdfm_ffm_fill(xdfm_ffm_reader* r, float* labels, int64_t* fm_feat_indices,
+                  float* fm_feat_values, int64_t* dnn_feat_indices, int64_t* dnn_feat_values,
+                  float* dnn_feat_weights, int32_t* row_ptr, int64_t* imp_offsets,
+                  char* imp_chars, uint8_t* imp_present);
+int xdfm_ffm_close(xdfm_ffm_reader* r);
+
+/* ------------------------------------------------------------------------
+ * Device batch preparation.
+ * ---------------------------------------------------------------------- */
+/* CSR offsets + per-token row from the (sorted) dnn_feat_indices[:,0] column that
+ * `tf.SparseTensor(dnn_feat_indices, ...)` carries (xDeepFM.py:82-91).
+ *   dnn_feat_indices : int64 [nnz,2] (device)      row_ptr : int32 [n_rows+1]
+ *   tok_row          : int32 [nnz]  */
+int xdfm_build_row_ptr(const int64_t* dnn_feat_indices, int64_t nnz, int64_t n_rows,
+                       int32_t* row_ptr, int32_t* tok_row, int32_t* err_flag, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Field-embedding lookup + linear part + FM part (forward).
+ *   tf.nn.embedding_lookup_sparse(..., combiner="sum")   xDeepFM.py:92-100
+ *   sparse_dense_matmul(x, w)                            xDeepFM.py:128   (bias added by the caller)
+ *   0.5*sum((xE)^2 - (x^2)(E^2))                         xDeepFM.py:153-158
+ *   table[N,D], lin_w[N] (NULL: no linear part)
+ *   row_ptr[B*F+1] int32, ids[nnz] int64, weights[nnz] float32 : the dnn view
+ *   emb_out[B,F,D]           out[r,:] = sum_j w_j*table[id_j,:] in column order; rows
+ *                            without a token are zero (also trailing ones)
+ *   lin_out[B]  (NULL ok)    sum_j w_j*lin_w[id_j]
+ *   fm_out[B]   (NULL ok)    FM second-order term
+ *   fm_sum[B,D] (NULL ok)    s[b,d] = sum_j w_j*table[id_j,d]   (kept for the backward)
+ * ---------------------------------------------------------------------- */
+int xdfm_embed_fwd(const float* table, const float* lin_w, int64_t N, int32_t D, int32_t F,
+                   int64_t B, const int32_t* row_ptr, const int64_t* ids, const float* weights,
+                   int64_t nnz, float* emb_out, float* lin_out, float* fm_out, float* fm_sum,
+                   int32_t* err_flag, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Embedding backward: deterministic sorted-key segment sum (+ row update).
+ * Replaces TF's gradient of embedding_lookup_sparse / sparse_dense_matmul and
+ * AdamOptimizer/AdagradOptimizer.apply_gradients on the table
+ * (base_model.py:290, :286, :314-322).
+ * ---------------------------------------------------------------------- */
+/* bytes of `plan_ws` needed by xdfm_embed_plan for nnz tokens and ids < N */
+int xdfm_embed_plan_workspace_bytes(int64_t nnz, int64_t N, size_t* bytes);
+/* Sorts the tokens of one batch by feature id (stable: equal ids keep token order).
+ *   sorted_ids[nnz] int32, sorted_tok[nnz] int32 (token index into ids/weights) */
+int xdfm_embed_plan(const int64_t* ids, int64_t nnz, int64_t N, int32_t* sorted_ids,
+                    int32_t* sorted_tok, void* plan_ws, size_t plan_ws_bytes, void* stream);
+
+typedef struct xdfm_opt_args {
+  int32_t kind;       /* XDFM_OPT_* */
+  float lr;           /* learning_rate */
+  float beta1, beta2; /* Adam */
+  float eps;          /* Adam epsilon (outside the sqrt, TF1 placement) */
+  float beta1_power;  /* beta1^t, t = 1-based step being applied */
+  float beta2_power;  /* beta2^t */
+  float l2;           /* coefficient of sum(p^2)/2, gradient l2*p */
+  float l1;           /* coefficient of sum|p|, gradient l1*sign(p) */
+  float clip_norm;    /* >0: per-tensor tf.clip_by_norm(g, clip_norm); 0: off */
+} xdfm_opt_args;
+
+/* Segment sum of the per-token gradient contributions
+ *     c_j = w_j*d_emb[row_j,:] + g[b_j]*w_j*(fm_sum[b_j,:] - w_j*table[id_j,:])   (FM term optional)
+ *     l_j = g[b_j]*w_j                                                            (linear, optional)
+ * over equal ids in sorted order, then
+ *   mode 0 (sparse_rows): apply `opt` to the touched rows of table (+slots) and lin_w in place;
+ *   mode 1 (scatter)    : store the sums into grad_table[N,D] / grad_lin[N] (rows of untouched
+ *                         ids are left as they are: the caller keeps them zero).
+ *   pieces[nnz*D (+nnz)] float scratch, long_list[nnz+1] int32 scratch (count in [0]).
+ *   d_emb[B,F,D]; g_logit[B] and fm_sum[B,D] only when the FM / linear parts are on. */
+int xdfm_embed_bwd(int32_t mode, float* table, float* slot_m, float* slot_v, float* lin_w,
+                   float* lin_m, float* lin_v, float* grad_table, float* grad_lin, int64_t N,
+                   int32_t D, int32_t F, int64_t B, const int32_t* sorted_ids,
+                   const int32_t* sorted_tok, const int32_t* tok_row, const float* weights,
+                   int64_t nnz, const float* d_emb, const float* g_logit, const float* fm_sum,
+                   int32_t use_fm, const xdfm_opt_args* opt, float* pieces, int32_t* long_list,
+                   void* stream);
+/* zero the rows of grad_table / grad_lin named by sorted_ids (restores the all-zero invariant) */
+int xdfm_embed_clear_rows(float* grad_table, float* grad_lin, int32_t D,
+                          const int32_t* sorted_ids, int64_t nnz, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Dense optimizer step over a flat fp32 buffer made of `n_seg` tensors
+ * (apply_gradients, base_model.py:305-322; regulariser gradients of
+ * base_model.py:121-167 folded in).
+ *   seg_off[n_seg+1] int64 (host), per segment: l2, l1 coefficients, norm_l2 coefficient
+ *   (gradient norm_l2 * p/||p||_F, the `tf.norm(ord=2)` term of cross_params) -- host arrays.
+ *   grad may be NULL (regulariser-only step, used for untouched state in tests).
+ *   stats: device float scratch of at least n_seg*260 floats (per-segment sums of p^2, |p|,
+ *   g^2 and their per-block partials); n_seg <= 32 per call
+ *   reg_loss (device float, may be NULL): receives the regularisation loss of these
+ *   segments (value BEFORE the update), base_model.py:264-272.
+ * ---------------------------------------------------------------------- */
+int xdfm_dense_update(float* param, const float* grad, float* slot_m, float* slot_v,
+                      int32_t n_seg, const int64_t* seg_off, const float* seg_l2,
+                      const float* seg_l1, const float* seg_norm_l2, const xdfm_opt_args* opt,
+                      float* stats, float* reg_loss, int32_t accumulate_reg_loss, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Compressed Interaction Network, one layer.   xDeepFM.py:191-267
+ *   x0[B,F,D], xk[B,H,D] (layer 0: xk == x0), w[F*H, L] (filter f_k, index f*H+h)
+ *   masked != 0: layer-0 strictly-upper mask times 2 (xDeepFM.py:208-217)
+ *   curr[b,n,d] = sum_{f,h} s*M[f,h]*x0[b,f,d]*xk[b,h,d]*w[f*H+h,n]
+ *   n <  n_hidden : xnext[b,n,d]            = curr   ([B,n_hidden,D], the next layer's input)
+ *   n >= n_hidden : pooled[b,pool_off+n-n_hidden] = sum_d curr   (pooled is [B,pool_stride])
+ * ---------------------------------------------------------------------- */
+int xdfm_cin_fwd(const float* x0, const float* xk, const float* w, int64_t B, int32_t F,
+                 int32_t H, int32_t D, int32_t L, int32_t n_hidden, int32_t masked,
+                 float* xnext, float* pooled, int32_t pool_stride, int32_t pool_off,
+                 void* stream);
+/* Backward of one layer.  Upstream gradient of curr[b,n,d]:
+ *   n <  n_hidden : d_xnext[b,n,d]
+ *   n >= n_hidden : d_pooled[b,pool_off+n-n_hidden]        (same for every d)
+ * Outputs: d_xk[B,H,D] (written; NULL for layer 0 where both roles are x0),
+ *          d_x0[B,F,D] (accumulated into: +=), d_w partial sums in dw_part, reduced
+ *          into d_w[F*H,L] (written).  dw_part: float scratch of
+ *          xdfm_cin_bwd_workspace_floats(...) elements. */
+int xdfm_cin_bwd_workspace_floats(int64_t B, int32_t F, int32_t H, int32_t D, int32_t L,
+                                  size_t* floats);
+int xdfm_cin_bwd(const float* x0, const float* xk, const float* w, int64_t B, int32_t F,
+                 int32_t H, int32_t D, int32_t L, int32_t n_hidden, int32_t masked,
+                 const float* d_xnext, const float* d_pooled, int32_t pool_stride,
+                 int32_t pool_off, float* d_xk, float* d_x0, float* d_w, float* dw_part,
+                 void* stream);
+
+/* ------------------------------------------------------------------------
+ * Dense layer  y = act(x*W + b)     xDeepFM.py:491-507 (xw_plus_b + activation),
+ * also the two output heads (xDeepFM.py:290-292, :531-533) with act = identity.
+ *   x[B,K], w[K,Nout], b[Nout], y[B,Nout]
+ * Backward: dy is the gradient w.r.t. y (post-activation); y is the saved output.
+ *   dx[B,K] written or accumulated (accumulate_dx != 0), dw[K,Nout], db[Nout] written.
+ *   part: float scratch of xdfm_dense_bwd_workspace_floats(...) elements.
+ * ---------------------------------------------------------------------- */
+int xdfm_dense_fwd(const float* x, const float* w, const float* b, int64_t B, int32_t K,
+                   int32_t Nout, int32_t act, float* y, void* stream);
+int xdfm_dense_bwd_workspace_floats(int64_t B, int32_t K, int32_t Nout, size_t* floats);
+int xdfm_dense_bwd(const float* x, const float* w, const float* y, const float* dy, int64_t B,
+                   int32_t K, int32_t Nout, int32_t act, float* dx, int32_t accumulate_dx,
+                   float* dw, float* db, float* part, void* stream);
+
+/* ------------------------------------------------------------------------
+ * CIN output head with the residual connection (res=True):
+ *   exFM_out[b] = sum_n r[b,n] + (sum_n r[b,n]*w[n] + bias)        xDeepFM.py:269-293
+ *   pooled r[B,n], w[n], bias[1], out[B].
+ * Backward (g = d loss / d exFM_out [B]): d_pooled[b,n] = g[b] + g[b]*w[n] (written),
+ *   dw[n] = sum_b g[b]*r[b,n], db = sum_b g[b].  part: scratch of
+ *   xdfm_dense_bwd_workspace_floats(B, n, 1) floats.
+ * ---------------------------------------------------------------------- */
+int xdfm_cin_head_fwd(const float* pooled, const float* w, const float* bias, int64_t B,
+                      int32_t n, float* out, void* stream);
+int xdfm_cin_head_bwd(const float* pooled, const float* w, const float* g, int64_t B, int32_t n,
+                      float* d_pooled, float* dw, float* db, float* part, void* stream);
+
+/* ------------------------------------------------------------------------
+ * logit sum + prediction + data loss + d(loss)/d(logit).
+ *   _build_graph sum xDeepFM.py:46-71, _get_pred base_model.py:91-112,
+ *   _compute_data_loss base_model.py:215-262.
+ *   parts: up to 4 device arrays [B] (NULL entries skipped) summed in the given order,
+ *   plus `bias` (device float scalar or NULL; the linear part's b).
+ *   classification != 0: pred = sigmoid(logit) else pred = logit.
+ *   labels[B]; outputs logit[B], pred[B], g_logit[B] (NULL: forward only),
+ *   loss: device float (mean data loss; NULL: skip), scratch[1024] floats.
+ * ---------------------------------------------------------------------- */
+int xdfm_logit_loss(const float* part0, const float* part1, const float* part2,
+                    const float* part3, const float* bias, const float* labels, int64_t B,
+                    int32_t classification, int32_t loss_kind, float* logit, float* pred,
+                    float* g_logit, float* loss, float* scratch, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Fused evaluation: AUC (ties grouped, == sklearn.roc_auc_score) and logloss
+ * (float64, preds clipped to [1e-11, 1-1e-11]) of a whole file's predictions.
+ *   cal_metric deeprec_utils.py:535-545 as called from run_eval base_model.py:588.
+ *   preds[n], labels[n] float32 (device); out[4] double (device):
+ *   out[0]=auc (NaN when only one class), out[1]=logloss, out[2]=#positives, out[3]=n
+ * ---------------------------------------------------------------------- */
+int xdfm_eval_workspace_bytes(int64_t n, size_t* bytes);
+int xdfm_eval_auc_logloss(const float* preds, const float* labels, int64_t n, double* out,
+                          void* ws, size_t ws_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* XDFM_H_ */

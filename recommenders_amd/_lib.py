@@ -1,0 +1,125 @@
+"""ctypes binding of libxdfm.so (the C ABI declared in include/xdfm.h).
+
+The library is built in-tree by ``__graft_entry__.build()`` /
+``make -C recommenders_amd/csrc``.  There is no fallback: if the shared object is
+missing or a symbol cannot be bound, importing a caller fails with
+``XdfmLibraryError``.
+"""
+
+import ctypes
+import os
+
+__all__ = ["lib", "check", "XdfmLibraryError", "XdfmError", "OptArgs", "BatchInfo", "LIB_PATH"]
+
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libxdfm.so")
+
+
+class XdfmLibraryError(ImportError):
+    pass
+
+
+class XdfmError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__("libxdfm error {0}: {1}".format(code, message))
+        self.code = code
+        self.message = message
+
+
+class OptArgs(ctypes.Structure):
+    """struct xdfm_opt_args"""
+
+    _fields_ = [
+        ("kind", ctypes.c_int32),
+        ("lr", ctypes.c_float),
+        ("beta1", ctypes.c_float),
+        ("beta2", ctypes.c_float),
+        ("eps", ctypes.c_float),
+        ("beta1_power", ctypes.c_float),
+        ("beta2_power", ctypes.c_float),
+        ("l2", ctypes.c_float),
+        ("l1", ctypes.c_float),
+        ("clip_norm", ctypes.c_float),
+    ]
+
+
+class BatchInfo(ctypes.Structure):
+    """struct xdfm_ffm_batch_info"""
+
+    _fields_ = [
+        ("n_rows", ctypes.c_int64),
+        ("nnz", ctypes.c_int64),
+        ("dnn_width", ctypes.c_int64),
+        ("imp_bytes", ctypes.c_int64),
+        ("first_line", ctypes.c_int64),
+    ]
+
+
+_P = ctypes.c_void_p
+_I32 = ctypes.c_int32
+_I64 = ctypes.c_int64
+_SZ = ctypes.c_size_t
+_PSZ = ctypes.POINTER(ctypes.c_size_t)
+
+# name -> argument types, in the order of include/xdfm.h.  tests/test_abi.py checks this
+# table against the header text, so a declaration cannot drift from its binding.
+SIGNATURES = {
+    "xdfm_abi_version": [],
+    "xdfm_ffm_open": [ctypes.c_char_p, _I64, _I64, ctypes.c_char, ctypes.c_char, ctypes.POINTER(_P)],
+    "xdfm_ffm_next": [_P, _I64, ctypes.POINTER(BatchInfo)],
+    "xdfm_ffm_fill": [_P] * 11,
+    "xdfm_ffm_close": [_P],
+    "xdfm_build_row_ptr": [_P, _I64, _I64, _P, _P, _P, _P],
+    "xdfm_embed_fwd": [_P, _P, _I64, _I32, _I32, _I64, _P, _P, _P, _I64, _P, _P, _P, _P, _P, _P],
+    "xdfm_embed_plan_workspace_bytes": [_I64, _I64, _PSZ],
+    "xdfm_embed_plan": [_P, _I64, _I64, _P, _P, _P, _SZ, _P],
+    "xdfm_embed_bwd": [_I32, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I32, _I32, _I64, _P, _P, _P,
+                       _P, _I64, _P, _P, _P, _I32, ctypes.POINTER(OptArgs), _P, _P, _P],
+    "xdfm_embed_clear_rows": [_P, _P, _I32, _P, _I64, _P],
+    "xdfm_dense_update": [_P, _P, _P, _P, _I32, _P, _P, _P, _P, ctypes.POINTER(OptArgs), _P, _P,
+                          _I32, _P],
+    "xdfm_cin_fwd": [_P, _P, _P, _I64, _I32, _I32, _I32, _I32, _I32, _I32, _P, _P, _I32, _I32, _P],
+    "xdfm_cin_bwd_workspace_floats": [_I64, _I32, _I32, _I32, _I32, _PSZ],
+    "xdfm_cin_bwd": [_P, _P, _P, _I64, _I32, _I32, _I32, _I32, _I32, _I32, _P, _P, _I32, _I32, _P,
+                     _P, _P, _P, _P],
+    "xdfm_dense_fwd": [_P, _P, _P, _I64, _I32, _I32, _I32, _P, _P],
+    "xdfm_dense_bwd_workspace_floats": [_I64, _I32, _I32, _PSZ],
+    "xdfm_dense_bwd": [_P, _P, _P, _P, _I64, _I32, _I32, _I32, _P, _I32, _P, _P, _P, _P],
+    "xdfm_cin_head_fwd": [_P, _P, _P, _I64, _I32, _P, _P],
+    "xdfm_cin_head_bwd": [_P, _P, _P, _I64, _I32, _P, _P, _P, _P, _P],
+    "xdfm_logit_loss": [_P, _P, _P, _P, _P, _P, _I64, _I32, _I32, _P, _P, _P, _P, _P, _P],
+    "xdfm_eval_workspace_bytes": [_I64, _PSZ],
+    "xdfm_eval_auc_logloss": [_P, _P, _I64, _P, _P, _SZ, _P],
+}
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise XdfmLibraryError(
+            "{0} not found: build it first (python -c 'import __graft_entry__ as g; g.build()' "
+            "or make -C recommenders_amd/csrc). There is no CPU fallback.".format(LIB_PATH)
+        )
+    try:
+        handle = ctypes.CDLL(LIB_PATH)
+    except OSError as exc:  # pragma: no cover - depends on the box
+        raise XdfmLibraryError("cannot load {0}: {1}".format(LIB_PATH, exc))
+    for name, argtypes in SIGNATURES.items():
+        try:
+            fn = getattr(handle, name)
+        except AttributeError:
+            raise XdfmLibraryError("{0} does not export {1}".format(LIB_PATH, name))
+        fn.argtypes = argtypes
+        fn.restype = ctypes.c_int
+    handle.xdfm_last_error.argtypes = []
+    handle.xdfm_last_error.restype = ctypes.c_char_p
+    return handle
+
+
+lib = _load()
+
+
+def check(code):
+    """Raise XdfmError for a negative status."""
+    if code < 0:
+        msg = lib.xdfm_last_error()
+        raise XdfmError(code, msg.decode("utf-8", "replace") if msg else "")
+    return code

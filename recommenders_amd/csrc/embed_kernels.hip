@@ -1,0 +1,558 @@
+// Field-embedding lookup (+ linear + FM) forward and the deterministic
+// sorted-key segment-sum backward with the fused row optimizer, for gfx950.
+//
+// Reference call sites replaced (recommenders/models/deeprec/models/):
+//   xDeepFM.py:92-100   tf.nn.embedding_lookup_sparse(..., combiner="sum")
+//   xDeepFM.py:128      sparse_dense_matmul(x, w)
+//   xDeepFM.py:153-158  FM second order term
+//   base_model.py:290/:286/:288 + :314-322  Adam / Adagrad / SGD apply_gradients on the table
+//
+// HBM layout: table[N][D] fp32 row-major (one shared table for all fields), lin_w[N],
+// optimizer slots with the same shapes.  emb_out[B][F][D].  The dnn view of a batch is
+// CSR: row_ptr[B*F+1] over tokens (ids int64, weights fp32), rows = sample*F+field.
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <rocprim/rocprim.hpp>
+
+#include "xdfm_common.h"
+
+namespace {
+
+constexpr int kWave = 64;
+constexpr int kPieceLen = 64;  // sorted positions per piece boundary in the backward
+
+template <int VEC>
+struct Vec;
+template <>
+struct Vec<4> {
+  using T = float4;
+};
+template <>
+struct Vec<2> {
+  using T = float2;
+};
+template <>
+struct Vec<1> {
+  using T = float;
+};
+
+template <int VEC>
+__device__ __forceinline__ void load_vec(const float* p, float (&v)[VEC]) {
+  using T = typename Vec<VEC>::T;
+  T t = *reinterpret_cast<const T*>(p);
+  memcpy(v, &t, sizeof(T));
+}
+template <int VEC>
+__device__ __forceinline__ void store_vec(float* p, const float (&v)[VEC]) {
+  using T = typename Vec<VEC>::T;
+  T t;
+  memcpy(&t, v, sizeof(T));
+  *reinterpret_cast<T*>(p) = t;
+}
+
+// ---------------------------------------------------------------- row_ptr
+__global__ void build_row_ptr_kernel(const int64_t* __restrict__ idx, int64_t nnz, int64_t n_rows,
+                                     int32_t* __restrict__ row_ptr, int32_t* __restrict__ tok_row,
+                                     int32_t* err_flag) {
+  const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k > nnz) return;
+  int64_t prev = (k == 0) ? -1 : idx[2 * (k - 1)];
+  int64_t row = (k == nnz) ? n_rows : idx[2 * k];
+  int err = 0;
+  if (k < nnz && (row < 0 || row >= n_rows)) err |= XDFM_DEVERR_ROW_RANGE;
+  if (row < prev) err |= XDFM_DEVERR_ROW_ORDER;
+  prev = prev < -1 ? -1 : (prev > n_rows ? n_rows : prev);
+  row = row < 0 ? 0 : (row > n_rows ? n_rows : row);
+  if (k < nnz) tok_row[k] = (int32_t)(row >= n_rows ? n_rows - 1 : row);
+  // rows in (prev, row] start at token k   (empty rows included)
+  for (int64_t r = prev + 1; r <= row; ++r) row_ptr[r] = (int32_t)k;
+  if (err) atomicOr(err_flag, err);
+}
+
+// ---------------------------------------------------------------- forward
+// One wave per sample.  LPR = D/VEC lanes cover one output row (VEC floats each), so a
+// wave gathers 64/LPR rows per pass and writes them as one contiguous span of emb_out.
+// The sample's per-dimension sums (FM) and its linear term are reduced through LDS in a
+// fixed order, so the result does not depend on scheduling.
+template <int VEC>
+__global__ __launch_bounds__(256) void embed_fwd_kernel(
+    const float* __restrict__ table, const float* __restrict__ lin_w, int64_t N, int D, int F,
+    int64_t B, const int32_t* __restrict__ row_ptr, const int64_t* __restrict__ ids,
+    const float* __restrict__ weights, float* __restrict__ emb_out, float* __restrict__ lin_out,
+    float* __restrict__ fm_out, float* __restrict__ fm_sum, int32_t* err_flag) {
+  __shared__ float red_s[4][kWave][VEC];
+  __shared__ float red_q[4][kWave][VEC];
+  __shared__ float red_l[4][kWave];
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int64_t b = (int64_t)blockIdx.x * 4 + wave;
+  const int LPR = D / VEC;
+  const int RPP = kWave / LPR;  // rows per pass
+  const int g = lane / LPR;
+  const int c = lane - g * LPR;
+  const bool lane_on = (g < RPP) && (b < B);
+  const bool want_fm = (fm_out != nullptr) || (fm_sum != nullptr);
+
+  float s_acc[VEC], q_acc[VEC];
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) s_acc[v] = q_acc[v] = 0.f;
+  float lin_acc = 0.f;
+  int err = 0;
+
+  if (lane_on) {
+    for (int f = g; f < F; f += RPP) {
+      const int64_t r = b * F + f;
+      const int beg = row_ptr[r], end = row_ptr[r + 1];
+      float acc[VEC];
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) acc[v] = 0.f;
+      for (int k = beg; k < end; ++k) {
+        const int64_t id = ids[k];
+        const float w = weights[k];
+        if ((uint64_t)id >= (uint64_t)N) {
+          err |= XDFM_DEVERR_ID_RANGE;
+          continue;
+        }
+        float e[VEC];
+        load_vec<VEC>(table + id * D + c * VEC, e);
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+          const float t = w * e[v];               // one rounding (TF: embeddings *= weights)
+          acc[v] = (k == beg) ? t : acc[v] + t;   // segment_sum in column order
+          q_acc[v] += t * t;
+        }
+        if (c == 0 && lin_w) lin_acc += w * lin_w[id];
+      }
+      store_vec<VEC>(emb_out + r * D + c * VEC, acc);
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) s_acc[v] += acc[v];
+    }
+  }
+  if (err) atomicOr(err_flag, err);
+  if (!want_fm && !lin_out) return;  // uniform over the block
+
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) {
+    red_s[wave][lane][v] = lane_on ? s_acc[v] : 0.f;
+    red_q[wave][lane][v] = lane_on ? q_acc[v] : 0.f;
+  }
+  red_l[wave][lane] = (lane_on && c == 0) ? lin_acc : 0.f;
+  __syncthreads();
+  const bool valid = b < B;  // no early exit: every wave takes part in the barriers below
+  // lanes 0..LPR-1: sum their column chunk over the row groups, in group order
+  float part = 0.f;
+  if (valid && lane < LPR) {
+    float s[VEC], q[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) s[v] = q[v] = 0.f;
+    for (int gg = 0; gg < RPP; ++gg) {
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) {
+        s[v] += red_s[wave][gg * LPR + lane][v];
+        q[v] += red_q[wave][gg * LPR + lane][v];
+      }
+    }
+    if (fm_sum) store_vec<VEC>(fm_sum + b * D + lane * VEC, s);
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) part += s[v] * s[v] - q[v];
+  }
+  __syncthreads();
+  red_s[wave][lane][0] = part;
+  __syncthreads();
+  if (valid && lane == 0) {
+    if (fm_out) {
+      float tot = 0.f;
+      for (int cc = 0; cc < LPR; ++cc) tot += red_s[wave][cc][0];
+      fm_out[b] = 0.5f * tot;
+    }
+    if (lin_out) {
+      float tot = 0.f;
+      for (int gg = 0; gg < RPP; ++gg) tot += red_l[wave][gg * LPR];
+      lin_out[b] = tot;
+    }
+  }
+}
+
+// ---------------------------------------------------------------- plan
+__global__ void plan_keys_kernel(const int64_t* __restrict__ ids, int64_t nnz, int64_t N,
+                                 uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+  const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= nnz) return;
+  int64_t id = ids[k];
+  id = id < 0 ? 0 : (id >= N ? N - 1 : id);  // out-of-range ids are flagged by the forward
+  keys[k] = (uint32_t)id;
+  vals[k] = (uint32_t)k;
+}
+
+inline unsigned key_bits(int64_t N) {
+  unsigned bits = 1;
+  while (bits < 32 && ((int64_t)1 << bits) < N) ++bits;
+  return bits;
+}
+
+inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// ---------------------------------------------------------------- backward
+struct OptDev {
+  int kind;
+  float lr, alpha, one_minus_b1, one_minus_b2, eps;
+};
+
+template <int VEC>
+__device__ __forceinline__ void apply_row(const OptDev& o, float* p, float* m, float* v,
+                                          const float (&g)[VEC]) {
+  float pv[VEC];
+  load_vec<VEC>(p, pv);
+  if (o.kind == XDFM_OPT_ADAM) {
+    float mv[VEC], vv[VEC];
+    load_vec<VEC>(m, mv);
+    load_vec<VEC>(v, vv);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      mv[i] = mv[i] + (g[i] - mv[i]) * o.one_minus_b1;
+      vv[i] = vv[i] + (g[i] * g[i] - vv[i]) * o.one_minus_b2;
+      pv[i] = pv[i] - (mv[i] * o.alpha) / (sqrtf(vv[i]) + o.eps);
+    }
+    store_vec<VEC>(m, mv);
+    store_vec<VEC>(v, vv);
+  } else if (o.kind == XDFM_OPT_ADAGRAD) {
+    float av[VEC];
+    load_vec<VEC>(m, av);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      av[i] = av[i] + g[i] * g[i];
+      pv[i] = pv[i] - (g[i] * o.lr) / sqrtf(av[i]);
+    }
+    store_vec<VEC>(m, av);
+  } else {
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) pv[i] = pv[i] - g[i] * o.lr;
+  }
+  store_vec<VEC>(p, pv);
+}
+
+struct BwdArgs {
+  float *table, *slot_m, *slot_v, *lin_w, *lin_m, *lin_v, *grad_table, *grad_lin;
+  int64_t N, B, nnz;
+  int D, F;
+  const int32_t *sorted_ids, *sorted_tok, *tok_row;
+  const float *weights, *d_emb, *g_logit, *fm_sum;
+  int use_fm;
+  OptDev opt;
+  float* pieces;      // [nnz][D]
+  float* pieces_lin;  // [nnz]
+  int32_t* long_list; // [0]=count, [1..] head positions of segments cut by a piece boundary
+};
+
+template <int VEC, int MODE>
+__device__ __forceinline__ void finish_row(const BwdArgs& a, int id, int c, const float (&acc)[VEC],
+                                           float lacc) {
+  const int64_t off = (int64_t)id * a.D + c * VEC;
+  if (MODE == 0) {
+    apply_row<VEC>(a.opt, a.table + off, a.slot_m + off, a.slot_v + off, acc);
+    if (a.lin_w && c == 0) {
+      float g1[1] = {lacc};
+      apply_row<1>(a.opt, a.lin_w + id, a.lin_m + id, a.lin_v + id, g1);
+    }
+  } else {
+    store_vec<VEC>(a.grad_table + off, acc);
+    if (a.grad_lin && c == 0) a.grad_lin[id] = lacc;
+  }
+}
+
+// One lane group (LPR lanes) per sorted position i.  Position i starts a "piece" when it
+// is the head of its id segment or a multiple of kPieceLen; the group sums the piece's
+// token contributions in sorted order.  A segment that is a single piece is finished on
+// the spot (optimizer fused); otherwise the piece sum is parked in `pieces` and the head
+// is queued for the second kernel, which adds the pieces in position order.  The sum of
+// a row therefore has one fixed association, whatever the scheduling.
+template <int VEC, int MODE>
+__global__ __launch_bounds__(256) void embed_bwd_kernel(BwdArgs a) {
+  const int LPR = a.D / VEC;
+  const int GPB = 256 / LPR;
+  const int grp = threadIdx.x / LPR;
+  const int c = threadIdx.x - grp * LPR;
+  const int64_t i = (int64_t)blockIdx.x * GPB + grp;
+  if (grp >= GPB || i >= a.nnz) return;
+  const int id = a.sorted_ids[i];
+  const bool head = (i == 0) || (a.sorted_ids[i - 1] != id);
+  if (!head && (i % kPieceLen) != 0) return;
+
+  float acc[VEC];
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) acc[v] = 0.f;
+  float lacc = 0.f;
+  float e[VEC];
+  if (a.use_fm) load_vec<VEC>(a.table + (int64_t)id * a.D + c * VEC, e);
+  const bool need_g = a.use_fm || a.lin_w != nullptr;
+  int64_t j = i;
+  do {
+    const int t = a.sorted_tok[j];
+    const int r = a.tok_row[t];
+    const float w = a.weights[t];
+    float de[VEC];
+    load_vec<VEC>(a.d_emb + (int64_t)r * a.D + c * VEC, de);
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) acc[v] = fmaf(w, de[v], acc[v]);
+    if (need_g) {
+      const int b = r / a.F;
+      const float gw = a.g_logit[b] * w;
+      if (a.use_fm) {
+        float s[VEC];
+        load_vec<VEC>(a.fm_sum + (int64_t)b * a.D + c * VEC, s);
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) acc[v] = fmaf(gw, s[v] - w * e[v], acc[v]);
+      }
+      lacc += gw;
+    }
+    ++j;
+  } while (j < a.nnz && a.sorted_ids[j] == id && (j % kPieceLen) != 0);
+
+  const bool complete = head && (j >= a.nnz || a.sorted_ids[j] != id);
+  if (complete) {
+    finish_row<VEC, MODE>(a, id, c, acc, lacc);
+  } else {
+    store_vec<VEC>(a.pieces + i * a.D + c * VEC, acc);
+    if (c == 0) {
+      a.pieces_lin[i] = lacc;
+      if (head) {
+        const int slot = atomicAdd(a.long_list, 1);
+        a.long_list[1 + slot] = (int32_t)i;
+      }
+    }
+  }
+}
+
+template <int VEC, int MODE>
+__global__ __launch_bounds__(256) void embed_bwd_long_kernel(BwdArgs a) {
+  const int LPR = a.D / VEC;
+  const int GPB = 256 / LPR;
+  const int grp = threadIdx.x / LPR;
+  const int c = threadIdx.x - grp * LPR;
+  const int64_t e = (int64_t)blockIdx.x * GPB + grp;
+  if (grp >= GPB || e >= a.long_list[0]) return;
+  const int64_t i = a.long_list[1 + e];
+  const int id = a.sorted_ids[i];
+  float acc[VEC];
+  load_vec<VEC>(a.pieces + i * a.D + c * VEC, acc);
+  float lacc = a.pieces_lin[i];
+  for (int64_t k = (i / kPieceLen + 1) * kPieceLen; k < a.nnz && a.sorted_ids[k] == id;
+       k += kPieceLen) {
+    float p[VEC];
+    load_vec<VEC>(a.pieces + k * a.D + c * VEC, p);
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) acc[v] += p[v];
+    lacc += a.pieces_lin[k];
+  }
+  finish_row<VEC, MODE>(a, id, c, acc, lacc);
+}
+
+__global__ void clear_rows_kernel(float* __restrict__ grad_table, float* __restrict__ grad_lin,
+                                  int D, const int32_t* __restrict__ sorted_ids, int64_t nnz) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t i = t / D;
+  const int d = (int)(t - i * D);
+  if (i >= nnz) return;
+  const int id = sorted_ids[i];
+  if (i > 0 && sorted_ids[i - 1] == id) return;
+  if (grad_table) grad_table[(int64_t)id * D + d] = 0.f;
+  if (grad_lin && d == 0) grad_lin[id] = 0.f;
+}
+
+int pick_vec(int D) { return (D % 4 == 0) ? 4 : (D % 2 == 0 ? 2 : 1); }
+
+int make_opt(const xdfm_opt_args* opt, OptDev* o) {
+  XDFM_REQUIRE(opt, "optimizer arguments are null");
+  XDFM_REQUIRE(opt->kind == XDFM_OPT_SGD || opt->kind == XDFM_OPT_ADAM ||
+                   opt->kind == XDFM_OPT_ADAGRAD,
+               "unknown optimizer kind %d", opt->kind);
+  o->kind = opt->kind;
+  o->lr = opt->lr;
+  o->eps = opt->eps;
+  o->one_minus_b1 = 1.f - opt->beta1;
+  o->one_minus_b2 = 1.f - opt->beta2;
+  // TF ApplyAdam: alpha = lr * sqrt(1 - beta2^t) / (1 - beta1^t), all in fp32
+  o->alpha = (opt->kind == XDFM_OPT_ADAM)
+                 ? opt->lr * sqrtf(1.f - opt->beta2_power) / (1.f - opt->beta1_power)
+                 : 0.f;
+  return XDFM_OK;
+}
+
+}  // namespace
+
+extern "C" int xdfm_build_row_ptr(const int64_t* dnn_feat_indices, int64_t nnz, int64_t n_rows,
+                                  int32_t* row_ptr, int32_t* tok_row, int32_t* err_flag,
+                                  void* stream) {
+  XDFM_REQUIRE(row_ptr && err_flag, "xdfm_build_row_ptr: null output");
+  XDFM_REQUIRE(nnz >= 0 && n_rows >= 0 && nnz < ((int64_t)1 << 31) && n_rows < ((int64_t)1 << 31) - 1,
+               "xdfm_build_row_ptr: sizes out of range (nnz=%lld rows=%lld)", (long long)nnz,
+               (long long)n_rows);
+  XDFM_REQUIRE(nnz == 0 || (dnn_feat_indices && tok_row), "xdfm_build_row_ptr: null input");
+  const int threads = 256;
+  const unsigned blocks = (unsigned)((nnz + 1 + threads - 1) / threads);
+  hipLaunchKernelGGL(build_row_ptr_kernel, dim3(blocks), dim3(threads), 0, (hipStream_t)stream,
+                     dnn_feat_indices, nnz, n_rows, row_ptr, tok_row, err_flag);
+  XDFM_LAUNCH_CHECK();
+  return XDFM_OK;
+}
+
+extern "C" int xdfm_embed_fwd(const float* table, const float* lin_w, int64_t N, int32_t D,
+                              int32_t F, int64_t B, const int32_t* row_ptr, const int64_t* ids,
+                              const float* weights, int64_t nnz, float* emb_out, float* lin_out,
+                              float* fm_out, float* fm_sum, int32_t* err_flag, void* stream) {
+  XDFM_REQUIRE(table && row_ptr && emb_out && err_flag, "xdfm_embed_fwd: null argument");
+  XDFM_REQUIRE(nnz == 0 || (ids && weights), "xdfm_embed_fwd: null token arrays");
+  XDFM_REQUIRE(N > 0 && D > 0 && F > 0 && B >= 0, "xdfm_embed_fwd: bad sizes");
+  XDFM_REQUIRE(!lin_out || lin_w, "xdfm_embed_fwd: lin_out needs lin_w");
+  const int vec = pick_vec(D);
+  XDFM_REQUIRE(D / vec <= kWave, "xdfm_embed_fwd: dim %d not supported (needs D/%d <= 64)", D, vec);
+  if (B == 0) return XDFM_OK;
+  const unsigned blocks = (unsigned)((B + 3) / 4);
+#define LAUNCH(V)                                                                               \
+  hipLaunchKernelGGL(embed_fwd_kernel<V>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, table, \
+                     lin_out ? lin_w : nullptr, N, D, F, B, row_ptr, ids, weights, emb_out,      \
+                     lin_out, fm_out, fm_sum, err_flag)
+  if (vec == 4)
+    LAUNCH(4);
+  else if (vec == 2)
+    LAUNCH(2);
+  else
+    LAUNCH(1);
+#undef LAUNCH
+  XDFM_LAUNCH_CHECK();
+  return XDFM_OK;
+}
+
+extern "C" int xdfm_embed_plan_workspace_bytes(int64_t nnz, int64_t N, size_t* bytes) {
+  XDFM_REQUIRE(bytes && nnz >= 0 && N > 0, "xdfm_embed_plan_workspace_bytes: bad argument");
+  size_t tmp = 0;
+  uint32_t* nul = nullptr;
+  hipError_t e = rocprim::radix_sort_pairs(nullptr, tmp, nul, nul, nul, nul, (size_t)nnz, 0u,
+                                           key_bits(N), (hipStream_t)0, false);
+  if (e != hipSuccess) return xdfm::fail(XDFM_E_HIP, "rocprim size query failed");
+  *bytes = 2 * align_up((size_t)nnz * sizeof(uint32_t), 256) + align_up(tmp, 256) + 256;
+  return XDFM_OK;
+}
+
+extern "C" int xdfm_embed_plan(const int64_t* ids, int64_t nnz, int64_t N, int32_t* sorted_ids,
+                               int32_t* sorted_tok, void* plan_ws, size_t plan_ws_bytes,
+                               void* stream) {
+  XDFM_REQUIRE(nnz >= 0 && N > 0 && N <= ((int64_t)1 << 31), "xdfm_embed_plan: bad sizes");
+  if (nnz == 0) return XDFM_OK;
+  XDFM_REQUIRE(ids && sorted_ids && sorted_tok && plan_ws, "xdfm_embed_plan: null argument");
+  size_t need = 0;
+  int rc = xdfm_embed_plan_workspace_bytes(nnz, N, &need);
+  if (rc) return rc;
+  if (plan_ws_bytes < need)
+    return xdfm::fail(XDFM_E_WORKSPACE, "xdfm_embed_plan: workspace %zu < %zu", plan_ws_bytes, need);
+  const size_t seg = align_up((size_t)nnz * sizeof(uint32_t), 256);
+  char* base = (char*)plan_ws;
+  uint32_t* keys = (uint32_t*)base;
+  uint32_t* vals = (uint32_t*)(base + seg);
+  void* tmp = base + 2 * seg;
+  size_t tmp_bytes = plan_ws_bytes - 2 * seg;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(plan_keys_kernel, dim3((unsigned)((nnz + 255) / 256)), dim3(256), 0, st, ids,
+                     nnz, N, keys, vals);
+  XDFM_LAUNCH_CHECK();
+  XDFM_HIP(rocprim::radix_sort_pairs(tmp, tmp_bytes, keys, (uint32_t*)sorted_ids, vals,
+                                     (uint32_t*)sorted_tok, (size_t)nnz, 0u, key_bits(N), st,
+                                     false));
+  return XDFM_OK;
+}
+
+extern "C" int xdfm_embed_bwd(int32_t mode, float* table, float* slot_m, float* slot_v,
+                              float* lin_w, float* lin_m, float* lin_v, float* grad_table,
+                              float* grad_lin, int64_t N, int32_t D, int32_t F, int64_t B,
+                              const int32_t* sorted_ids, const int32_t* sorted_tok,
+                              const int32_t* tok_row, const float* weights, int64_t nnz,
+                              const float* d_emb, const float* g_logit, const float* fm_sum,
+                              int32_t use_fm, const xdfm_opt_args* opt, float* pieces,
+                              int32_t* long_list, void* stream) {
+  XDFM_REQUIRE(mode == 0 || mode == 1, "xdfm_embed_bwd: mode must be 0 or 1");
+  XDFM_REQUIRE(N > 0 && D > 0 && F > 0 && B >= 0 && nnz >= 0, "xdfm_embed_bwd: bad sizes");
+  if (nnz == 0) return XDFM_OK;
+  XDFM_REQUIRE(sorted_ids && sorted_tok && tok_row && weights && d_emb && pieces && long_list,
+               "xdfm_embed_bwd: null argument");
+  XDFM_REQUIRE(!use_fm || (g_logit && fm_sum && table), "xdfm_embed_bwd: FM needs g_logit, fm_sum, table");
+  BwdArgs a;
+  memset(&a, 0, sizeof(a));
+  if (mode == 0) {
+    XDFM_REQUIRE(table, "xdfm_embed_bwd: sparse_rows mode needs the table");
+    int rc = make_opt(opt, &a.opt);
+    if (rc) return rc;
+    XDFM_REQUIRE(opt->l1 == 0.f && opt->l2 == 0.f && opt->clip_norm == 0.f,
+                 "xdfm_embed_bwd: sparse_rows mode cannot apply l1/l2/clip (their gradient is dense); "
+                 "use mode 1 + xdfm_dense_update");
+    XDFM_REQUIRE(opt->kind == XDFM_OPT_SGD || slot_m, "xdfm_embed_bwd: optimizer slot missing");
+    XDFM_REQUIRE(opt->kind != XDFM_OPT_ADAM || slot_v, "xdfm_embed_bwd: Adam needs slot_v");
+    if (lin_w) {
+      XDFM_REQUIRE(g_logit, "xdfm_embed_bwd: linear part needs g_logit");
+      XDFM_REQUIRE(opt->kind == XDFM_OPT_SGD || lin_m, "xdfm_embed_bwd: lin slot missing");
+      XDFM_REQUIRE(opt->kind != XDFM_OPT_ADAM || lin_v, "xdfm_embed_bwd: lin slot_v missing");
+    }
+  } else {
+    XDFM_REQUIRE(grad_table, "xdfm_embed_bwd: scatter mode needs grad_table");
+    XDFM_REQUIRE(!grad_lin || g_logit, "xdfm_embed_bwd: linear part needs g_logit");
+  }
+  a.table = table;
+  a.slot_m = slot_m;
+  a.slot_v = slot_v;
+  a.lin_w = (mode == 0) ? lin_w : grad_lin;  // "linear part on" marker in both modes
+  a.lin_m = lin_m;
+  a.lin_v = lin_v;
+  a.grad_table = grad_table;
+  a.grad_lin = grad_lin;
+  a.N = N;
+  a.B = B;
+  a.nnz = nnz;
+  a.D = D;
+  a.F = F;
+  a.sorted_ids = sorted_ids;
+  a.sorted_tok = sorted_tok;
+  a.tok_row = tok_row;
+  a.weights = weights;
+  a.d_emb = d_emb;
+  a.g_logit = g_logit;
+  a.fm_sum = fm_sum;
+  a.use_fm = use_fm;
+  a.pieces = pieces;
+  a.pieces_lin = pieces + (size_t)nnz * D;
+  a.long_list = long_list;
+
+  const int vec = pick_vec(D);
+  const int lpr = D / vec;
+  XDFM_REQUIRE(lpr <= 256, "xdfm_embed_bwd: dim %d not supported", D);
+  const int gpb = 256 / lpr;
+  hipStream_t st = (hipStream_t)stream;
+  XDFM_HIP(hipMemsetAsync(long_list, 0, sizeof(int32_t), st));
+  const unsigned blocks = (unsigned)((nnz + gpb - 1) / gpb);
+  const int64_t max_long = nnz / kPieceLen + 1;
+  const unsigned blocks_long = (unsigned)((max_long + gpb - 1) / gpb);
+#define LAUNCH(V, M)                                                                          \
+  do {                                                                                        \
+    hipLaunchKernelGGL((embed_bwd_kernel<V, M>), dim3(blocks), dim3(256), 0, st, a);          \
+    hipLaunchKernelGGL((embed_bwd_long_kernel<V, M>), dim3(blocks_long), dim3(256), 0, st, a); \
+  } while (0)
+  if (mode == 0) {
+    if (vec == 4) LAUNCH(4, 0); else if (vec == 2) LAUNCH(2, 0); else LAUNCH(1, 0);
+  } else {
+    if (vec == 4) LAUNCH(4, 1); else if (vec == 2) LAUNCH(2, 1); else LAUNCH(1, 1);
+  }
+#undef LAUNCH
+  XDFM_LAUNCH_CHECK();
+  return XDFM_OK;
+}
+
+extern "C" int xdfm_embed_clear_rows(float* grad_table, float* grad_lin, int32_t D,
+                                     const int32_t* sorted_ids, int64_t nnz, void* stream) {
+  XDFM_REQUIRE(D > 0 && nnz >= 0, "xdfm_embed_clear_rows: bad sizes");
+  if (nnz == 0) return XDFM_OK;
+  XDFM_REQUIRE(sorted_ids, "xdfm_embed_clear_rows: null sorted_ids");
+  const int64_t total = nnz * D;
+  hipLaunchKernelGGL(clear_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, grad_table, grad_lin, D, sorted_ids, nnz);
+  XDFM_LAUNCH_CHECK();
+  return XDFM_OK;
+}

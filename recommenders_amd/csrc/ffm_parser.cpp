@@ -1,0 +1,419 @@
+// libffm text ingest for FFMTextIterator (host side of libxdfm.so).
+//
+// Follows the observable behaviour of the reference's pure-Python reader
+// (recommenders/models/deeprec/io/iterator.py:90-219):
+//   line  := label SP token (SP token)* [ '%' impression_id ]
+//   token := field ':' feature ':' value         (1-based field / feature)
+// and produces the two COO views of `_convert_data` (:152-219) directly as arrays.
+// Text semantics mirrored: universal newlines, str.strip() on the line / words,
+// split on the single separator character, empty words skipped (:111-112), the
+// impression id only when the line holds exactly one '%' (:101-103), Python's
+// int()/float() literal grammar (ASCII subset), float64 -> float32 narrowing on store.
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <cerrno>
+#include <cmath>
+#include <cstdlib>
+#include <limits>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "xdfm_common.h"
+
+namespace xdfm {
+
+char* error_buffer() {
+  static thread_local char buf[512] = {0};
+  return buf;
+}
+
+int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(error_buffer(), 512, fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+namespace {
+
+// whitespace of Python's str.strip() restricted to ASCII
+inline bool py_space(unsigned char c) {
+  return c == ' ' || (c >= 0x09 && c <= 0x0d) || (c >= 0x1c && c <= 0x1f);
+}
+
+struct Span {
+  const char* b;
+  const char* e;
+  bool empty() const { return b >= e; }
+};
+
+inline Span strip(Span s) {
+  while (s.b < s.e && py_space((unsigned char)*s.b)) ++s.b;
+  while (s.e > s.b && py_space((unsigned char)s.e[-1])) --s.e;
+  return s;
+}
+
+inline bool is_digit(char c) { return c >= '0' && c <= '9'; }
+
+// Python int(str): [ws] [+-] digit ('_'? digit)* [ws]
+bool parse_py_int(Span s, int64_t* out) {
+  s = strip(s);
+  if (s.empty()) return false;
+  bool neg = false;
+  if (*s.b == '+' || *s.b == '-') {
+    neg = (*s.b == '-');
+    ++s.b;
+  }
+  if (s.empty() || !is_digit(*s.b)) return false;
+  unsigned long long acc = 0;
+  const unsigned long long lim = neg ? 9223372036854775808ull : 9223372036854775807ull;
+  bool prev_us = false;
+  for (const char* p = s.b; p < s.e; ++p) {
+    if (*p == '_') {
+      if (prev_us || p + 1 == s.e) return false;
+      prev_us = true;
+      continue;
+    }
+    if (!is_digit(*p)) return false;
+    prev_us = false;
+    unsigned d = (unsigned)(*p - '0');
+    if (acc > (lim - d) / 10) return false;  // would not fit int64 (numpy would raise OverflowError)
+    acc = acc * 10 + d;
+  }
+  *out = neg ? (int64_t)(0ull - acc) : (int64_t)acc;
+  return true;
+}
+
+inline bool ieq(const char* b, const char* e, const char* word) {
+  size_t n = strlen(word);
+  if ((size_t)(e - b) != n) return false;
+  for (size_t i = 0; i < n; ++i) {
+    char c = b[i];
+    if (c >= 'A' && c <= 'Z') c = (char)(c - 'A' + 'a');
+    if (c != word[i]) return false;
+  }
+  return true;
+}
+
+// Python float(str): [ws] [+-] (inf|infinity|nan | digits [. digits?] [exp] | . digits [exp]) [ws]
+// digits may carry single underscores between digits.
+bool parse_py_float(Span s, double* out) {
+  s = strip(s);
+  if (s.empty()) return false;
+  char buf[96];
+  size_t n = 0;
+  const char* p = s.b;
+  if (*p == '+' || *p == '-') buf[n++] = *p++;
+  if (p >= s.e) return false;
+  if (ieq(p, s.e, "inf") || ieq(p, s.e, "infinity")) {
+    *out = (buf[0] == '-' && n == 1) ? -std::numeric_limits<double>::infinity()
+                                     : std::numeric_limits<double>::infinity();
+    return true;
+  }
+  if (ieq(p, s.e, "nan")) {
+    *out = std::numeric_limits<double>::quiet_NaN();
+    return true;
+  }
+  auto digits = [&](bool* any) -> bool {
+    bool prev_us = false;
+    *any = false;
+    while (p < s.e && (is_digit(*p) || *p == '_')) {
+      if (*p == '_') {
+        if (!*any || prev_us || p + 1 >= s.e || !is_digit(p[1])) return false;
+        prev_us = true;
+      } else {
+        if (n >= sizeof(buf) - 2) return false;
+        buf[n++] = *p;
+        *any = true;
+        prev_us = false;
+      }
+      ++p;
+    }
+    return true;
+  };
+  bool int_any = false, frac_any = false;
+  if (!digits(&int_any)) return false;
+  if (p < s.e && *p == '.') {
+    if (n >= sizeof(buf) - 2) return false;
+    buf[n++] = *p++;
+    if (!digits(&frac_any)) return false;
+  }
+  if (!int_any && !frac_any) return false;
+  if (p < s.e && (*p == 'e' || *p == 'E')) {
+    if (n >= sizeof(buf) - 4) return false;
+    buf[n++] = 'e';
+    ++p;
+    if (p < s.e && (*p == '+' || *p == '-')) buf[n++] = *p++;
+    bool exp_any = false;
+    if (!digits(&exp_any) || !exp_any) return false;
+  }
+  if (p != s.e) return false;
+  buf[n] = 0;
+  char* endp = nullptr;
+  errno = 0;
+  *out = strtod(buf, &endp);
+  return endp == buf + n;
+}
+
+}  // namespace
+}  // namespace xdfm
+
+using xdfm::Span;
+
+struct xdfm_ffm_reader {
+  int fd = -1;
+  const char* data = nullptr;
+  size_t size = 0;
+  size_t pos = 0;
+  int64_t line_no = 0;  // lines consumed so far
+  int64_t F = 0, N = 0;
+  char col_sep = ' ', id_sep = '%';
+  // staged batch, file order
+  int64_t first_line = 0;
+  std::vector<float> labels;
+  std::vector<int64_t> tok_sample, tok_feat, dnn_row, dnn_col;
+  std::vector<float> tok_val;
+  std::vector<uint32_t> order;  // dnn view permutation (stable by (row, col))
+  std::vector<int64_t> imp_off;
+  std::vector<uint8_t> imp_present;
+  std::string imp_chars;
+  int64_t dnn_width = 0;
+  // per-sample scratch: running count per field (reference: dnn_feat_dic, :178-185)
+  std::vector<std::pair<int64_t, int64_t>> field_count;
+};
+
+extern "C" int xdfm_abi_version(void) { return XDFM_ABI_VERSION; }
+extern "C" const char* xdfm_last_error(void) { return xdfm::error_buffer(); }
+
+extern "C" int xdfm_ffm_open(const char* path, int64_t field_count, int64_t feature_count,
+                             char col_sep, char id_sep, xdfm_ffm_reader** out) {
+  XDFM_REQUIRE(path && out, "xdfm_ffm_open: null argument");
+  XDFM_REQUIRE(field_count > 0, "xdfm_ffm_open: FIELD_COUNT must be positive");
+  XDFM_REQUIRE(col_sep != ':' && id_sep != ':' && col_sep != id_sep,
+               "xdfm_ffm_open: separators must differ from ':' and from each other");
+  int fd = open(path, O_RDONLY);
+  if (fd < 0) return xdfm::fail(XDFM_E_IO, "cannot open %s: %s", path, strerror(errno));
+  struct stat st;
+  if (fstat(fd, &st) != 0) {
+    close(fd);
+    return xdfm::fail(XDFM_E_IO, "cannot stat %s: %s", path, strerror(errno));
+  }
+  const char* data = nullptr;
+  if (st.st_size > 0) {
+    void* m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+    if (m == MAP_FAILED) {
+      close(fd);
+      return xdfm::fail(XDFM_E_IO, "cannot mmap %s: %s", path, strerror(errno));
+    }
+    madvise(m, (size_t)st.st_size, MADV_SEQUENTIAL);
+    data = (const char*)m;
+  }
+  auto* r = new xdfm_ffm_reader();
+  r->fd = fd;
+  r->data = data;
+  r->size = (size_t)st.st_size;
+  r->F = field_count;
+  r->N = feature_count;
+  r->col_sep = col_sep;
+  r->id_sep = id_sep;
+  *out = r;
+  return XDFM_OK;
+}
+
+extern "C" int xdfm_ffm_close(xdfm_ffm_reader* r) {
+  if (!r) return XDFM_OK;
+  if (r->data) munmap((void*)r->data, r->size);
+  if (r->fd >= 0) close(r->fd);
+  delete r;
+  return XDFM_OK;
+}
+
+namespace {
+
+// one sample; appends to the reader's staging vectors
+int parse_line(xdfm_ffm_reader* r, Span line, int64_t sample) {
+  using namespace xdfm;
+  const int64_t ln = r->line_no;  // already incremented: 1-based number of this line
+  line = strip(line);
+  // words = line.split(ID_spliter); impression id only when len(words) == 2
+  const char* first_sep = nullptr;
+  int seps = 0;
+  for (const char* p = line.b; p < line.e; ++p)
+    if (*p == r->id_sep) {
+      if (!first_sep) first_sep = p;
+      ++seps;
+    }
+  Span head = line;
+  if (first_sep) head.e = first_sep;
+  r->imp_off.push_back((int64_t)r->imp_chars.size());
+  if (seps == 1) {
+    Span imp = strip(Span{first_sep + 1, line.e});
+    r->imp_chars.append(imp.b, imp.e);
+    r->imp_present.push_back(1);
+  } else {
+    r->imp_present.push_back(0);
+  }
+  head = strip(head);
+
+  // cols = head.split(col_spliter)
+  const char* p = head.b;
+  auto next_word = [&](Span* w) -> bool {
+    if (p > head.e) return false;
+    const char* q = p;
+    while (q < head.e && *q != r->col_sep) ++q;
+    *w = Span{p, q};
+    p = q + 1;  // past the separator (or past the end -> terminates)
+    return true;
+  };
+  Span w;
+  next_word(&w);  // str.split always yields at least one (possibly empty) word
+  double label;
+  if (!parse_py_float(w, &label))
+    return fail(XDFM_E_PARSE, "line %lld: could not convert label '%.*s' to float", (long long)ln,
+                (int)std::min<ptrdiff_t>(w.e - w.b, 40), w.b);
+  r->labels.push_back((float)label);
+
+  r->field_count.clear();
+  while (next_word(&w)) {
+    if (strip(w).empty()) continue;
+    // tokens = word.split(':'); tokens[0..2] used, extra ones ignored
+    const char* c1 = (const char*)memchr(w.b, ':', (size_t)(w.e - w.b));
+    const char* c2 = c1 ? (const char*)memchr(c1 + 1, ':', (size_t)(w.e - c1 - 1)) : nullptr;
+    if (!c1 || !c2)
+      return fail(XDFM_E_PARSE, "line %lld: token '%.*s' is not field:feature:value",
+                  (long long)ln, (int)std::min<ptrdiff_t>(w.e - w.b, 40), w.b);
+    const char* c3 = (const char*)memchr(c2 + 1, ':', (size_t)(w.e - c2 - 1));
+    int64_t field, feat;
+    double val;
+    if (!parse_py_int(Span{w.b, c1}, &field) || !parse_py_int(Span{c1 + 1, c2}, &feat) ||
+        !parse_py_float(Span{c2 + 1, c3 ? c3 : w.e}, &val))
+      return fail(XDFM_E_PARSE, "line %lld: invalid literal in token '%.*s'", (long long)ln,
+                  (int)std::min<ptrdiff_t>(w.e - w.b, 40), w.b);
+    field -= 1;
+    feat -= 1;
+    // running count of this field inside the sample (column of the dnn view)
+    int64_t col = 0;
+    bool seen = false;
+    for (auto& fc : r->field_count)
+      if (fc.first == field) {
+        col = ++fc.second;
+        seen = true;
+        break;
+      }
+    if (!seen) r->field_count.emplace_back(field, 0);
+    r->tok_sample.push_back(sample);
+    r->tok_feat.push_back(feat);
+    r->tok_val.push_back((float)val);
+    r->dnn_row.push_back(sample * r->F + field);
+    r->dnn_col.push_back(col);
+    if (col + 1 > r->dnn_width) r->dnn_width = col + 1;
+  }
+  return XDFM_OK;
+}
+
+}  // namespace
+
+extern "C" int xdfm_ffm_next(xdfm_ffm_reader* r, int64_t batch_size, xdfm_ffm_batch_info* info) {
+  XDFM_REQUIRE(r && info, "xdfm_ffm_next: null argument");
+  XDFM_REQUIRE(batch_size > 0, "xdfm_ffm_next: batch_size must be positive");
+  r->labels.clear();
+  r->tok_sample.clear();
+  r->tok_feat.clear();
+  r->tok_val.clear();
+  r->dnn_row.clear();
+  r->dnn_col.clear();
+  r->imp_off.clear();
+  r->imp_present.clear();
+  r->imp_chars.clear();
+  r->dnn_width = 0;
+  r->first_line = r->line_no + 1;
+
+  int64_t n = 0;
+  while (n < batch_size && r->pos < r->size) {
+    const char* b = r->data + r->pos;
+    const char* end = r->data + r->size;
+    const char* e = b;
+    while (e < end && *e != '\n' && *e != '\r') ++e;
+    size_t next = (size_t)(e - r->data);
+    if (e < end) next += (*e == '\r' && e + 1 < end && e[1] == '\n') ? 2 : 1;
+    r->pos = next;
+    r->line_no += 1;
+    int rc = parse_line(r, Span{b, e}, n);
+    if (rc != XDFM_OK) return rc;
+    ++n;
+  }
+  if (n == 0) return xdfm::fail(XDFM_E_EOF, "end of file");
+  r->imp_off.push_back((int64_t)r->imp_chars.size());
+
+  // dnn view order: stable by (row, col)   (iterator.py:198-201)
+  const size_t nnz = r->dnn_row.size();
+  r->order.resize(nnz);
+  std::iota(r->order.begin(), r->order.end(), 0u);
+  bool sorted = true;
+  for (size_t k = 1; k < nnz && sorted; ++k)
+    sorted = std::make_pair(r->dnn_row[k - 1], r->dnn_col[k - 1]) <=
+             std::make_pair(r->dnn_row[k], r->dnn_col[k]);
+  if (!sorted)
+    std::stable_sort(r->order.begin(), r->order.end(), [r](uint32_t a, uint32_t b) {
+      if (r->dnn_row[a] != r->dnn_row[b]) return r->dnn_row[a] < r->dnn_row[b];
+      return r->dnn_col[a] < r->dnn_col[b];
+    });
+
+  info->n_rows = n;
+  info->nnz = (int64_t)nnz;
+  info->dnn_width = r->dnn_width;
+  info->imp_bytes = (int64_t)r->imp_chars.size();
+  info->first_line = r->first_line;
+  return XDFM_OK;
+}
+
+extern "C" int xdfm_ffm_fill(xdfm_ffm_reader* r, float* labels, int64_t* fm_feat_indices,
+                             float* fm_feat_values, int64_t* dnn_feat_indices,
+                             int64_t* dnn_feat_values, float* dnn_feat_weights,
+                             int32_t* row_ptr, int64_t* imp_offsets, char* imp_chars,
+                             uint8_t* imp_present) {
+  XDFM_REQUIRE(r, "xdfm_ffm_fill: null reader");
+  const size_t n = r->labels.size();
+  const size_t nnz = r->dnn_row.size();
+  if (labels) memcpy(labels, r->labels.data(), n * sizeof(float));
+  if (fm_feat_indices)
+    for (size_t k = 0; k < nnz; ++k) {
+      fm_feat_indices[2 * k] = r->tok_sample[k];
+      fm_feat_indices[2 * k + 1] = r->tok_feat[k];
+    }
+  if (fm_feat_values) memcpy(fm_feat_values, r->tok_val.data(), nnz * sizeof(float));
+  for (size_t k = 0; k < nnz; ++k) {
+    const uint32_t s = r->order[k];
+    if (dnn_feat_indices) {
+      dnn_feat_indices[2 * k] = r->dnn_row[s];
+      dnn_feat_indices[2 * k + 1] = r->dnn_col[s];
+    }
+    if (dnn_feat_values) dnn_feat_values[k] = r->tok_feat[s];
+    if (dnn_feat_weights) dnn_feat_weights[k] = r->tok_val[s];
+  }
+  if (row_ptr) {
+    const int64_t rows = (int64_t)n * r->F;
+    XDFM_REQUIRE(rows + 1 < (int64_t)1 << 31 && nnz < ((size_t)1 << 31),
+                 "xdfm_ffm_fill: batch too large for int32 CSR offsets");
+    memset(row_ptr, 0, (size_t)(rows + 1) * sizeof(int32_t));
+    for (size_t k = 0; k < nnz; ++k) {
+      const int64_t row = r->dnn_row[k];
+      if (row < 0 || row >= rows)
+        return xdfm::fail(XDFM_E_INVALID,
+                          "batch starting at line %lld: field index outside [1, FIELD_COUNT=%lld]",
+                          (long long)r->first_line, (long long)r->F);
+      row_ptr[row + 1] += 1;
+    }
+    for (int64_t i = 0; i < rows; ++i) row_ptr[i + 1] += row_ptr[i];
+  }
+  if (imp_offsets) memcpy(imp_offsets, r->imp_off.data(), (n + 1) * sizeof(int64_t));
+  if (imp_chars && !r->imp_chars.empty()) memcpy(imp_chars, r->imp_chars.data(), r->imp_chars.size());
+  if (imp_present) memcpy(imp_present, r->imp_present.data(), n);
+  return XDFM_OK;
+}

@@ -1,0 +1,528 @@
+// Dense optimizer step with folded regulariser gradients, logit/pred/data-loss, and the
+// fused AUC + logloss evaluation, gfx950.
+//
+// Reference call sites replaced (recommenders/models/deeprec/):
+//   models/base_model.py:121-167, :264-272   l2 / l1 / cross regularisation
+//   models/base_model.py:283-302, :305-322   optimizer choice, clip_by_norm, apply_gradients
+//   models/xDeepFM.py:46-71 + base_model.py:91-112, :215-262   logit sum, pred, data loss
+//   deeprec_utils.py:535-545 (cal_metric auc / logloss) as used by run_eval base_model.py:588
+//
+// All reductions are two-level with a fixed association (per-block partial, then one
+// block adds the partials in index order): no float atomics, run-to-run bit identical.
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <rocprim/rocprim.hpp>
+
+#include "xdfm_common.h"
+
+namespace {
+
+constexpr int kMaxSeg = 32;
+constexpr int kStatBlocks = 128;  // partial blocks per segment
+
+struct SegTable {
+  int n;
+  long long off[kMaxSeg + 1];
+  float l2[kMaxSeg], l1[kMaxSeg], nl2[kMaxSeg];
+};
+
+struct OptDev {
+  int kind;
+  float lr, alpha, one_minus_b1, one_minus_b2, eps, clip;
+};
+
+// block-wide sum, result valid in thread 0; fixed tree => deterministic
+template <typename T, int THREADS>
+__device__ __forceinline__ T block_sum(T v, T* sh) {
+  sh[threadIdx.x] = v;
+  __syncthreads();
+  for (int s = THREADS / 2; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) sh[threadIdx.x] += sh[threadIdx.x + s];
+    __syncthreads();
+  }
+  T r = sh[0];
+  __syncthreads();
+  return r;
+}
+
+__device__ __forceinline__ float sgn(float p) { return p > 0.f ? 1.f : (p < 0.f ? -1.f : 0.f); }
+
+// total gradient of one element: data gradient + regulariser gradients
+__device__ __forceinline__ float total_grad(float g, float p, float l2, float l1, float nl2,
+                                            float inv_norm) {
+  float t = g;
+  if (l2 != 0.f) t += l2 * p;                      // d/dp l2*sum(p^2)/2
+  if (l1 != 0.f) t += l1 * sgn(p);                 // d/dp l1*sum|p|
+  if (nl2 != 0.f) t += nl2 * (p * inv_norm);       // d/dp nl2*sqrt(sum p^2)
+  return t;
+}
+
+// pass 0: partial sums of p^2 and |p| ; pass 1: partial sums of (total gradient)^2
+__global__ __launch_bounds__(256) void dense_stats_kernel(SegTable tab, const float* __restrict__ param,
+                                                          const float* __restrict__ grad,
+                                                          const float* __restrict__ stats, int pass,
+                                                          float* __restrict__ partial) {
+  __shared__ float sh[256];
+  const int s = blockIdx.y;
+  const long long beg = tab.off[s], end = tab.off[s + 1];
+  float a = 0.f, b = 0.f;
+  float inv_norm = 0.f;
+  if (pass == 1) {
+    const float nrm = sqrtf(stats[s * 4 + 0]);
+    inv_norm = nrm > 0.f ? 1.f / nrm : 0.f;
+  }
+  for (long long i = beg + (long long)blockIdx.x * 256 + threadIdx.x; i < end;
+       i += (long long)kStatBlocks * 256) {
+    const float p = param[i];
+    if (pass == 0) {
+      a += p * p;
+      b += fabsf(p);
+    } else {
+      const float t = total_grad(grad ? grad[i] : 0.f, p, tab.l2[s], tab.l1[s], tab.nl2[s], inv_norm);
+      a += t * t;
+    }
+  }
+  a = block_sum<float, 256>(a, sh);
+  b = block_sum<float, 256>(b, sh);
+  if (threadIdx.x == 0) {
+    partial[((size_t)s * kStatBlocks + blockIdx.x) * 2 + 0] = a;
+    partial[((size_t)s * kStatBlocks + blockIdx.x) * 2 + 1] = b;
+  }
+}
+
+// one block: finish the per-segment sums; pass 0 also produces the regularisation loss
+__global__ __launch_bounds__(kStatBlocks) void dense_stats_final_kernel(
+    SegTable tab, const float* __restrict__ partial, int pass, float* __restrict__ stats,
+    float* reg_loss, int accumulate) {
+  __shared__ float sh[kStatBlocks];
+  float reg = 0.f;
+  for (int s = 0; s < tab.n; ++s) {
+    const float a = block_sum<float, kStatBlocks>(partial[((size_t)s * kStatBlocks + threadIdx.x) * 2], sh);
+    const float b = block_sum<float, kStatBlocks>(partial[((size_t)s * kStatBlocks + threadIdx.x) * 2 + 1], sh);
+    if (threadIdx.x == 0) {
+      if (pass == 0) {
+        stats[s * 4 + 0] = a;  // sum p^2
+        stats[s * 4 + 1] = b;  // sum |p|
+        // base_model.py:126-131 (l2_loss = sum/2), :141-147 (norm ord=1), :161-165 (ord=1, ord=2)
+        reg += tab.l2[s] * (a * 0.5f) + tab.l1[s] * b + tab.nl2[s] * sqrtf(a);
+      } else {
+        stats[s * 4 + 2] = a;  // sum (total grad)^2
+      }
+    }
+  }
+  if (threadIdx.x == 0 && pass == 0 && reg_loss) *reg_loss = accumulate ? *reg_loss + reg : reg;
+}
+
+__global__ __launch_bounds__(256) void dense_update_kernel(SegTable tab, OptDev o, float* __restrict__ param,
+                                                           const float* __restrict__ grad,
+                                                           float* __restrict__ slot_m,
+                                                           float* __restrict__ slot_v,
+                                                           const float* __restrict__ stats) {
+  const long long total = tab.off[tab.n];
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total;
+       i += (long long)gridDim.x * 256) {
+    int s = 0;
+    while (s + 1 < tab.n && i >= tab.off[s + 1]) ++s;
+    float p = param[i];
+    float inv_norm = 0.f;
+    if (tab.nl2[s] != 0.f) {
+      const float nrm = sqrtf(stats[s * 4 + 0]);
+      inv_norm = nrm > 0.f ? 1.f / nrm : 0.f;
+    }
+    float g = total_grad(grad ? grad[i] : 0.f, p, tab.l2[s], tab.l1[s], tab.nl2[s], inv_norm);
+    if (o.clip > 0.f) {
+      // tf.clip_by_norm: g * clip / max(||g||, clip), per tensor (base_model.py:315-321)
+      const float nrm = sqrtf(stats[s * 4 + 2]);
+      g = g * o.clip / (nrm > o.clip ? nrm : o.clip);
+    }
+    if (o.kind == XDFM_OPT_ADAM) {
+      float m = slot_m[i], v = slot_v[i];
+      m = m + (g - m) * o.one_minus_b1;
+      v = v + (g * g - v) * o.one_minus_b2;
+      p = p - (m * o.alpha) / (sqrtf(v) + o.eps);
+      slot_m[i] = m;
+      slot_v[i] = v;
+    } else if (o.kind == XDFM_OPT_ADAGRAD) {
+      float a = slot_m[i];
+      a = a + g * g;
+      p = p - (g * o.lr) / sqrtf(a);
+      slot_m[i] = a;
+    } else {
+      p = p - g * o.lr;
+    }
+    param[i] = p;
+  }
+}
+
+// ------------------------------------------------------------------ loss
+struct LossArgs {
+  const float *part[4], *bias, *labels;
+  long long B;
+  int classification, loss_kind;
+  float *logit, *pred, *g_logit;
+};
+
+__device__ __forceinline__ float sigmoidf(float z) {
+  // same split as Eigen's logistic: no overflow for large |z|
+  if (z >= 0.f) return 1.f / (1.f + expf(-z));
+  const float e = expf(z);
+  return e / (1.f + e);
+}
+
+__device__ __forceinline__ float sample_logit(const LossArgs& a, long long i) {
+  float z = 0.f;
+  bool first = true;
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    if (a.part[k]) {
+      float v = a.part[k][i];
+      if (k == 0 && a.bias) v += a.bias[0];  // linear part: matmul + b (xDeepFM.py:128)
+      z = first ? v : z + v;
+      first = false;
+    }
+  return z;
+}
+
+constexpr float kLogEps = 1e-7f;  // tf.compat.v1.losses.log_loss default epsilon
+
+// pass A: logit, pred, per-sample loss term -> per-block partial sums
+__global__ __launch_bounds__(256) void loss_fwd_kernel(LossArgs a, float* __restrict__ partial) {
+  __shared__ float sh[256];
+  float acc = 0.f;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < a.B;
+       i += (long long)gridDim.x * 256) {
+    const float z = sample_logit(a, i);
+    const float p = a.classification ? sigmoidf(z) : z;
+    a.logit[i] = z;
+    a.pred[i] = p;
+    if (a.labels) {
+      const float y = a.labels[i];
+      float l;
+      if (a.loss_kind == XDFM_LOSS_LOG) {
+        l = -y * logf(p + kLogEps) - (1.f - y) * logf(1.f - p + kLogEps);
+      } else if (a.loss_kind == XDFM_LOSS_CROSS_ENTROPY) {
+        // max(z,0) - z*y + log(1+exp(-|z|))
+        l = fmaxf(z, 0.f) - z * y + log1pf(expf(-fabsf(z)));
+      } else {
+        const float d = p - y;
+        l = d * d;
+      }
+      acc += l;
+    }
+  }
+  acc = block_sum<float, 256>(acc, sh);
+  if (threadIdx.x == 0) partial[blockIdx.x] = acc;
+}
+
+// pass B: finish the mean (and sqrt for square_loss), then d loss / d logit
+__global__ __launch_bounds__(256) void loss_bwd_kernel(LossArgs a, const float* __restrict__ partial,
+                                                       int n_partial, float* loss_out) {
+  __shared__ float sh[256];
+  float s = 0.f;
+  for (int k = threadIdx.x; k < n_partial; k += 256) s += partial[k];
+  s = block_sum<float, 256>(s, sh);
+  __shared__ float loss_sh;
+  if (threadIdx.x == 0) {
+    float mean = s / (float)a.B;
+    loss_sh = (a.loss_kind == XDFM_LOSS_SQUARE) ? sqrtf(mean) : mean;
+    if (loss_out && blockIdx.x == 0) *loss_out = loss_sh;
+  }
+  __syncthreads();
+  if (!a.g_logit) return;
+  const float loss = loss_sh;
+  const float invB = 1.f / (float)a.B;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < a.B;
+       i += (long long)gridDim.x * 256) {
+    const float z = a.logit[i], p = a.pred[i], y = a.labels[i];
+    const float dp_dz = a.classification ? p * (1.f - p) : 1.f;
+    float g;
+    if (a.loss_kind == XDFM_LOSS_LOG) {
+      g = (-y / (p + kLogEps) + (1.f - y) / (1.f - p + kLogEps)) * dp_dz * invB;
+    } else if (a.loss_kind == XDFM_LOSS_CROSS_ENTROPY) {
+      g = (sigmoidf(z) - y) * invB;
+    } else {
+      // d sqrt(mean d^2) = d / (B * rmse)
+      g = loss > 0.f ? (p - y) * dp_dz * invB / loss : 0.f;
+    }
+    a.g_logit[i] = g;
+  }
+}
+
+// ------------------------------------------------------------------ eval
+__device__ __forceinline__ uint32_t float_key(float f) {
+  uint32_t u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);  // ascending order-preserving
+}
+
+__global__ void eval_keys_kernel(const float* __restrict__ preds, const float* __restrict__ labels,
+                                 long long n, uint32_t* __restrict__ keys, uint32_t* __restrict__ pos) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  keys[i] = float_key(preds[i]);
+  pos[i] = labels[i] > 0.5f ? 1u : 0u;
+}
+
+// after the sort: neg flag per sorted position
+__global__ void eval_negflag_kernel(const uint32_t* __restrict__ pos_sorted, long long n,
+                                    int32_t* __restrict__ neg) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) neg[i] = 1 - (int32_t)pos_sorted[i];
+}
+
+// per tie-group head: 2*U contribution = pos_in*(2*neg_before + neg_in); integer, exact
+__global__ __launch_bounds__(256) void eval_auc_kernel(const uint32_t* __restrict__ keys,
+                                                       const int32_t* __restrict__ cneg /*exclusive*/,
+                                                       long long n, unsigned long long* u2) {
+  __shared__ unsigned long long sh[256];
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  unsigned long long c = 0;
+  if (i < n) {
+    const uint32_t k = keys[i];
+    if (i == 0 || keys[i - 1] != k) {
+      long long lo = i + 1, hi = n;  // first position with key > k
+      while (lo < hi) {
+        const long long mid = (lo + hi) >> 1;
+        if (keys[mid] == k) lo = mid + 1; else hi = mid;
+      }
+      const long long e = lo;
+      const long long neg_total_e = (e < n) ? cneg[e] : -1;
+      // cneg has n entries (exclusive scan); the count up to n is cneg[n-1] + neg[n-1]:
+      // the caller stores that total at cneg[n].
+      const long long neg_e = (e < n) ? neg_total_e : cneg[n];
+      const long long neg_b = cneg[i];
+      const long long neg_in = neg_e - neg_b;
+      const long long pos_in = (e - i) - neg_in;
+      c = (unsigned long long)pos_in * (unsigned long long)(2 * neg_b + neg_in);
+    }
+  }
+  c = block_sum<unsigned long long, 256>(c, sh);
+  if (threadIdx.x == 0 && c) atomicAdd(u2, c);  // integer: order independent
+}
+
+__global__ void eval_total_kernel(const int32_t* __restrict__ cneg, const int32_t* __restrict__ neg,
+                                  long long n, int32_t* cneg_n) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) *cneg_n = n > 0 ? cneg[n - 1] + neg[n - 1] : 0;
+}
+
+__global__ __launch_bounds__(256) void eval_logloss_kernel(const float* __restrict__ preds,
+                                                           const float* __restrict__ labels,
+                                                           long long n, double* __restrict__ partial) {
+  __shared__ double sh[256];
+  double acc = 0.0;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n;
+       i += (long long)gridDim.x * 256) {
+    double p = (double)preds[i];
+    p = fmin(fmax(p, 10e-12), 1.0 - 10e-12);  // deeprec_utils.py:543
+    const double y = (double)labels[i];
+    acc += -(y * log(p) + (1.0 - y) * log(1.0 - p));
+  }
+  acc = block_sum<double, 256>(acc, sh);
+  if (threadIdx.x == 0) partial[blockIdx.x] = acc;
+}
+
+__global__ __launch_bounds__(256) void eval_final_kernel(const double* __restrict__ partial, int n_partial,
+                                                         const unsigned long long* u2,
+                                                         const int32_t* cneg_n, long long n,
+                                                         double* out) {
+  __shared__ double sh[256];
+  double s = 0.0;
+  for (int k = threadIdx.x; k < n_partial; k += 256) s += partial[k];
+  s = block_sum<double, 256>(s, sh);
+  if (threadIdx.x == 0) {
+    const double n_neg = (double)*cneg_n;
+    const double n_pos = (double)n - n_neg;
+    out[0] = (n_pos > 0 && n_neg > 0) ? (double)*u2 / (2.0 * n_pos * n_neg) : nan("");
+    out[1] = n > 0 ? s / (double)n : nan("");
+    out[2] = n_pos;
+    out[3] = (double)n;
+  }
+}
+
+inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+struct EvalLayout {
+  size_t keys_in, keys_out, pos_in, pos_out, neg, cneg, partial, u2, tmp, tmp_bytes, total;
+};
+
+int eval_layout(long long n, EvalLayout* L) {
+  size_t sort_tmp = 0, scan_tmp = 0;
+  uint32_t* nul = nullptr;
+  int32_t* nuli = nullptr;
+  if (rocprim::radix_sort_pairs(nullptr, sort_tmp, nul, nul, nul, nul, (size_t)n, 0u, 32u,
+                                (hipStream_t)0, false) != hipSuccess)
+    return xdfm::fail(XDFM_E_HIP, "rocprim sort size query failed");
+  if (rocprim::exclusive_scan(nullptr, scan_tmp, nuli, nuli, 0, (size_t)n, rocprim::plus<int32_t>(),
+                              (hipStream_t)0, false) != hipSuccess)
+    return xdfm::fail(XDFM_E_HIP, "rocprim scan size query failed");
+  size_t off = 0;
+  auto take = [&](size_t bytes) {
+    size_t o = off;
+    off += align_up(bytes, 256);
+    return o;
+  };
+  const size_t nn = (size_t)n;
+  L->keys_in = take(nn * 4);
+  L->keys_out = take(nn * 4);
+  L->pos_in = take(nn * 4);
+  L->pos_out = take(nn * 4);
+  L->neg = take(nn * 4);
+  L->cneg = take((nn + 1) * 4);
+  L->partial = take(1024 * sizeof(double));
+  L->u2 = take(sizeof(unsigned long long));
+  L->tmp_bytes = sort_tmp > scan_tmp ? sort_tmp : scan_tmp;
+  L->tmp = take(L->tmp_bytes);
+  L->total = off + 256;
+  return XDFM_OK;
+}
+
+}  // namespace
+
+extern "C" int xdfm_dense_update(float* param, const float* grad, float* slot_m, float* slot_v,
+                                 int32_t n_seg, const int64_t* seg_off, const float* seg_l2,
+                                 const float* seg_l1, const float* seg_norm_l2,
+                                 const xdfm_opt_args* opt, float* stats, float* reg_loss,
+                                 int32_t accumulate_reg_loss, void* stream) {
+  XDFM_REQUIRE(param && seg_off && opt && stats, "xdfm_dense_update: null argument");
+  XDFM_REQUIRE(n_seg > 0 && n_seg <= kMaxSeg, "xdfm_dense_update: n_seg %d outside [1,%d]", n_seg, kMaxSeg);
+  XDFM_REQUIRE(opt->kind == XDFM_OPT_SGD || opt->kind == XDFM_OPT_ADAM || opt->kind == XDFM_OPT_ADAGRAD,
+               "xdfm_dense_update: unknown optimizer kind %d", opt->kind);
+  XDFM_REQUIRE(opt->kind == XDFM_OPT_SGD || slot_m, "xdfm_dense_update: slot_m missing");
+  XDFM_REQUIRE(opt->kind != XDFM_OPT_ADAM || slot_v, "xdfm_dense_update: slot_v missing");
+  SegTable tab;
+  memset(&tab, 0, sizeof(tab));
+  tab.n = n_seg;
+  bool need_stats = (reg_loss != nullptr) || opt->clip_norm > 0.f;
+  for (int s = 0; s <= n_seg; ++s) {
+    tab.off[s] = seg_off[s];
+    XDFM_REQUIRE(s == 0 || seg_off[s] >= seg_off[s - 1], "xdfm_dense_update: seg_off not ascending");
+  }
+  XDFM_REQUIRE(seg_off[0] == 0, "xdfm_dense_update: seg_off[0] must be 0");
+  for (int s = 0; s < n_seg; ++s) {
+    tab.l2[s] = seg_l2 ? seg_l2[s] : 0.f;
+    tab.l1[s] = seg_l1 ? seg_l1[s] : 0.f;
+    tab.nl2[s] = seg_norm_l2 ? seg_norm_l2[s] : 0.f;
+    if (tab.nl2[s] != 0.f) need_stats = true;
+  }
+  OptDev o;
+  o.kind = opt->kind;
+  o.lr = opt->lr;
+  o.eps = opt->eps;
+  o.one_minus_b1 = 1.f - opt->beta1;
+  o.one_minus_b2 = 1.f - opt->beta2;
+  o.clip = opt->clip_norm;
+  o.alpha = (opt->kind == XDFM_OPT_ADAM)
+                ? opt->lr * sqrtf(1.f - opt->beta2_power) / (1.f - opt->beta1_power)
+                : 0.f;
+  hipStream_t st = (hipStream_t)stream;
+  const long long total = tab.off[n_seg];
+  if (total == 0) {
+    if (reg_loss && !accumulate_reg_loss) XDFM_HIP(hipMemsetAsync(reg_loss, 0, sizeof(float), st));
+    return XDFM_OK;
+  }
+  float* partial = stats + (size_t)n_seg * 4;
+  if (need_stats) {
+    hipLaunchKernelGGL(dense_stats_kernel, dim3(kStatBlocks, n_seg), dim3(256), 0, st, tab, param, grad,
+                       stats, 0, partial);
+    hipLaunchKernelGGL(dense_stats_final_kernel, dim3(1), dim3(kStatBlocks), 0, st, tab, partial, 0,
+                       stats, reg_loss, accumulate_reg_loss);
+    if (opt->clip_norm > 0.f) {
+      hipLaunchKernelGGL(dense_stats_kernel, dim3(kStatBlocks, n_seg), dim3(256), 0, st, tab, param,
+                         grad, stats, 1, partial);
+      hipLaunchKernelGGL(dense_stats_final_kernel, dim3(1), dim3(kStatBlocks), 0, st, tab, partial, 1,
+                         stats, nullptr, 0);
+    }
+  }
+  long long blocks = (total + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(dense_update_kernel, dim3((unsigned)blocks), dim3(256), 0, st, tab, o, param, grad,
+                     slot_m, slot_v, stats);
+  XDFM_LAUNCH_CHECK();
+  return XDFM_OK;
+}
+
+extern "C" int xdfm_logit_loss(const float* part0, const float* part1, const float* part2,
+                               const float* part3, const float* bias, const float* labels, int64_t B,
+                               int32_t classification, int32_t loss_kind, float* logit, float* pred,
+                               float* g_logit, float* loss, float* scratch, void* stream) {
+  XDFM_REQUIRE(logit && pred && scratch, "xdfm_logit_loss: null output");
+  XDFM_REQUIRE(part0 || part1 || part2 || part3, "xdfm_logit_loss: no logit part given");
+  XDFM_REQUIRE(B > 0, "xdfm_logit_loss: empty batch");
+  XDFM_REQUIRE(loss_kind >= XDFM_LOSS_LOG && loss_kind <= XDFM_LOSS_SQUARE,
+               "xdfm_logit_loss: unknown loss %d", loss_kind);
+  XDFM_REQUIRE(labels || (!g_logit && !loss), "xdfm_logit_loss: loss/gradient need labels");
+  XDFM_REQUIRE(!bias || part0, "xdfm_logit_loss: bias belongs to part0 (the linear part)");
+  LossArgs a;
+  a.part[0] = part0;
+  a.part[1] = part1;
+  a.part[2] = part2;
+  a.part[3] = part3;
+  a.bias = bias;
+  a.labels = labels;
+  a.B = B;
+  a.classification = classification;
+  a.loss_kind = loss_kind;
+  a.logit = logit;
+  a.pred = pred;
+  a.g_logit = g_logit;
+  hipStream_t st = (hipStream_t)stream;
+  long long blocks = (B + 255) / 256;
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(loss_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a, scratch);
+  if (labels && (g_logit || loss))
+    hipLaunchKernelGGL(loss_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a, scratch,
+                       (int)blocks, loss);
+  XDFM_LAUNCH_CHECK();
+  return XDFM_OK;
+}
+
+extern "C" int xdfm_eval_workspace_bytes(int64_t n, size_t* bytes) {
+  XDFM_REQUIRE(bytes && n > 0 && n < ((int64_t)1 << 31), "xdfm_eval_workspace_bytes: bad argument");
+  EvalLayout L;
+  int rc = eval_layout(n, &L);
+  if (rc) return rc;
+  *bytes = L.total;
+  return XDFM_OK;
+}
+
+extern "C" int xdfm_eval_auc_logloss(const float* preds, const float* labels, int64_t n, double* out,
+                                     void* ws, size_t ws_bytes, void* stream) {
+  XDFM_REQUIRE(preds && labels && out && ws, "xdfm_eval_auc_logloss: null argument");
+  XDFM_REQUIRE(n > 0 && n < ((int64_t)1 << 31), "xdfm_eval_auc_logloss: n out of range");
+  EvalLayout L;
+  int rc = eval_layout(n, &L);
+  if (rc) return rc;
+  if (ws_bytes < L.total)
+    return xdfm::fail(XDFM_E_WORKSPACE, "xdfm_eval_auc_logloss: workspace %zu < %zu", ws_bytes, L.total);
+  char* base = (char*)ws;
+  uint32_t* keys_in = (uint32_t*)(base + L.keys_in);
+  uint32_t* keys_out = (uint32_t*)(base + L.keys_out);
+  uint32_t* pos_in = (uint32_t*)(base + L.pos_in);
+  uint32_t* pos_out = (uint32_t*)(base + L.pos_out);
+  int32_t* neg = (int32_t*)(base + L.neg);
+  int32_t* cneg = (int32_t*)(base + L.cneg);
+  double* partial = (double*)(base + L.partial);
+  unsigned long long* u2 = (unsigned long long*)(base + L.u2);
+  void* tmp = base + L.tmp;
+  size_t tmp_bytes = L.tmp_bytes;
+  hipStream_t st = (hipStream_t)stream;
+  const unsigned blocks = (unsigned)((n + 255) / 256);
+  XDFM_HIP(hipMemsetAsync(u2, 0, sizeof(unsigned long long), st));
+  hipLaunchKernelGGL(eval_keys_kernel, dim3(blocks), dim3(256), 0, st, preds, labels, (long long)n,
+                     keys_in, pos_in);
+  XDFM_HIP(rocprim::radix_sort_pairs(tmp, tmp_bytes, keys_in, keys_out, pos_in, pos_out, (size_t)n, 0u,
+                                     32u, st, false));
+  hipLaunchKernelGGL(eval_negflag_kernel, dim3(blocks), dim3(256), 0, st, pos_out, (long long)n, neg);
+  tmp_bytes = L.tmp_bytes;
+  XDFM_HIP(rocprim::exclusive_scan(tmp, tmp_bytes, neg, cneg, 0, (size_t)n, rocprim::plus<int32_t>(), st,
+                                   false));
+  hipLaunchKernelGGL(eval_total_kernel, dim3(1), dim3(64), 0, st, cneg, neg, (long long)n, cneg + n);
+  hipLaunchKernelGGL(eval_auc_kernel, dim3(blocks), dim3(256), 0, st, keys_out, cneg, (long long)n, u2);
+  unsigned lblocks = blocks > 1024 ? 1024 : blocks;
+  hipLaunchKernelGGL(eval_logloss_kernel, dim3(lblocks), dim3(256), 0, st, preds, labels, (long long)n,
+                     partial);
+  hipLaunchKernelGGL(eval_final_kernel, dim3(1), dim3(256), 0, st, partial, (int)lblocks, u2, cneg + n,
+                     (long long)n, out);
+  XDFM_LAUNCH_CHECK();
+  return XDFM_OK;
+}

@@ -1,0 +1,623 @@
+"""Device engine of the xDeepFM path: owns the parameters / optimizer slots in HBM and
+drives the HIP kernels of libxdfm.so through the C ABI (include/xdfm.h).
+
+This replaces what `sess.run` does for the reference (base_model.py:379-388, :402, :416):
+one forward (+ backward + optimizer) pass of the graph XDeepFMModel._build_graph builds
+(xDeepFM.py:24-71).  PyTorch is used for device memory, streams and H2D copies only; all
+arithmetic on the path is in the library.  There is no CPU fallback: constructing an
+engine without a visible GPU raises.
+"""
+
+import ctypes
+
+import numpy as np
+import torch
+
+from recommenders_amd import _lib
+
+_ACT = {"identity": 0, "relu": 1, "sigmoid": 2, "tanh": 3, "elu": 4}
+_LOSS = {"log_loss": 0, "cross_entropy_loss": 1, "square_loss": 2}
+_OPT = {"sgd": 0, "gd": 0, "adam": 1, "adagrad": 2}
+
+_DEVERR = {
+    1: "a feature index is outside [1, FEATURE_COUNT]",
+    2: "a field index is outside [1, FIELD_COUNT]",
+    4: "dnn_feat_indices rows are not sorted",
+}
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def cin_shapes(hp):
+    """(H_k, L_k, n_hidden_k) per CIN layer (xDeepFM.py:191-267; field_nums bookkeeping :262)."""
+    out = []
+    prev = hp.FIELD_COUNT
+    n_layers = len(hp.cross_layer_sizes)
+    for idx, layer_size in enumerate(hp.cross_layer_sizes):
+        n_hidden = int(layer_size / 2) if idx != n_layers - 1 else 0
+        out.append((prev, int(layer_size), n_hidden))
+        prev = int(layer_size / 2)
+    return out
+
+
+def dense_param_shapes(hp):
+    """Ordered name -> shape of every dense (non table-sized) variable of the graph."""
+    shapes = {}
+    if hp.use_Linear_part:
+        shapes["lin_b"] = (1,)
+    if hp.use_CIN_part:
+        for k, (H, L, _) in enumerate(cin_shapes(hp)):
+            shapes["cin_f_%d" % k] = (H * hp.FIELD_COUNT, L)
+        shapes["cin_w_out"] = (sum(L - nh for (_, L, nh) in cin_shapes(hp)), 1)
+        shapes["cin_b_out"] = (1,)
+    if hp.use_DNN_part:
+        last = hp.FIELD_COUNT * hp.dim
+        for k, size in enumerate(hp.layer_sizes):
+            shapes["dnn_w_%d" % k] = (last, int(size))
+            shapes["dnn_b_%d" % k] = (int(size),)
+            last = int(size)
+        shapes["dnn_w_out"] = (last, 1)
+        shapes["dnn_b_out"] = (1,)
+    return shapes
+
+
+class DeviceBatch(object):
+    """One mini-batch resident in HBM (the dnn view of the iterator as CSR)."""
+
+    __slots__ = ("B", "nnz", "labels", "ids", "weights", "row_ptr", "tok_row", "sorted_ids",
+                 "sorted_tok", "planned")
+
+
+class XDeepFMEngine(object):
+    def __init__(self, hp, device=None, seed=None, embedding_update="dense_exact"):
+        if not torch.cuda.is_available():
+            raise RuntimeError(
+                "recommenders_amd needs a ROCm GPU: the xDeepFM path runs in HIP kernels "
+                "(libxdfm.so) and has no CPU fallback"
+            )
+        self.hp = hp
+        self.device = torch.device(device) if device is not None else torch.device(
+            "cuda", torch.cuda.current_device()
+        )
+        self.lib = _lib.lib
+        self.N, self.F, self.D = int(hp.FEATURE_COUNT), int(hp.FIELD_COUNT), int(hp.dim)
+        if hp.fast_CIN_d > 0:
+            raise NotImplementedError("fast_CIN_d > 0 (xDeepFM.py:295-451) is not built yet")
+        if hp.enable_BN is True:
+            raise NotImplementedError("enable_BN (xDeepFM.py:234-240, :497-503) is not built yet")
+        if hp.user_dropout:
+            raise NotImplementedError("user_dropout (base_model.py:335-336) is not built yet")
+        if hp.use_CIN_part and hp.cross_activation != "identity":
+            raise NotImplementedError("cross_activation other than identity is not built yet")
+        if hp.loss not in _LOSS:
+            raise ValueError("this loss not defined {0}".format(hp.loss))
+        if hp.method not in ("classification", "regression"):
+            raise ValueError(
+                "method must be regression or classification, but now is {0}".format(hp.method)
+            )
+        if hp.use_DNN_part:
+            for k in range(len(hp.layer_sizes)):
+                if hp.activation[k] not in _ACT:
+                    raise ValueError("this activations not defined {0}".format(hp.activation[k]))
+        if not (hp.use_Linear_part or hp.use_FM_part or hp.use_CIN_part or hp.use_DNN_part):
+            raise ValueError("xDeepFM needs at least one of the Linear/FM/CIN/DNN parts")
+        if embedding_update not in ("dense_exact", "sparse_rows"):
+            raise ValueError("embedding_update must be dense_exact or sparse_rows")
+        self.embedding_update = embedding_update
+        self.opt_kind = _OPT.get(hp.optimizer)
+        if self.opt_kind is None:
+            if hp.optimizer in ("adadelta", "ftrl", "padagrad", "pgd", "rmsprop"):
+                raise NotImplementedError("optimizer {0} is not built yet".format(hp.optimizer))
+            self.opt_kind = 0  # unknown names fall back to SGD (base_model.py:301-302)
+        if embedding_update == "sparse_rows":
+            if hp.embed_l1 != 0.0 or hp.embed_l2 != 0.0:
+                raise ValueError("sparse_rows needs embed_l1 = embed_l2 = 0 (their gradient is dense)")
+            if hp.use_Linear_part and (hp.layer_l1 != 0.0 or hp.layer_l2 != 0.0):
+                raise ValueError(
+                    "sparse_rows with the linear part needs layer_l1 = layer_l2 = 0 (lin_w is a "
+                    "FEATURE_COUNT-sized layer parameter)"
+                )
+            if hp.is_clip_norm:
+                raise ValueError("sparse_rows cannot clip by the norm of a dense gradient")
+
+        dev = self.device
+        f32 = torch.float32
+        # ---- parameters (values are set by load_state / init)
+        self.table = torch.zeros((self.N, self.D), dtype=f32, device=dev)
+        self.lin_w = torch.zeros((self.N,), dtype=f32, device=dev) if hp.use_Linear_part else None
+        self.dense_shapes = dense_param_shapes(hp)
+        offs = [0]
+        for shape in self.dense_shapes.values():
+            offs.append(offs[-1] + int(np.prod(shape)))
+        self.dense_off = offs
+        n_dense = max(offs[-1], 1)
+        self.dense = torch.zeros((n_dense,), dtype=f32, device=dev)
+        self.dense_grad = torch.zeros((n_dense,), dtype=f32, device=dev)
+        self.views, self.grad_views = {}, {}
+        for i, (name, shape) in enumerate(self.dense_shapes.items()):
+            self.views[name] = self.dense[offs[i] : offs[i + 1]].view(shape)
+            self.grad_views[name] = self.dense_grad[offs[i] : offs[i + 1]].view(shape)
+        # ---- optimizer slots
+        slot_init = 0.1 if self.opt_kind == 2 else 0.0  # Adagrad initial_accumulator_value
+        need_m = self.opt_kind in (1, 2)
+        need_v = self.opt_kind == 1
+
+        def slot(like, on):
+            return torch.full_like(like, slot_init) if on else None
+
+        self.table_m, self.table_v = slot(self.table, need_m), slot(self.table, need_v)
+        self.lin_m = slot(self.lin_w, need_m) if self.lin_w is not None else None
+        self.lin_v = slot(self.lin_w, need_v) if self.lin_w is not None else None
+        self.dense_m, self.dense_v = slot(self.dense, need_m), slot(self.dense, need_v)
+        self.step = 0
+        self.b1p = np.float32(1.0)
+        self.b2p = np.float32(1.0)
+        # dense_exact keeps a dense gradient image of the table, all zero between steps
+        if embedding_update == "dense_exact":
+            self.grad_table = torch.zeros_like(self.table)
+            self.grad_lin = torch.zeros_like(self.lin_w) if self.lin_w is not None else None
+        else:
+            self.grad_table = self.grad_lin = None
+        # segment tables for xdfm_dense_update (host arrays)
+        self._seg = self._segment_tables()
+        self.err_flag = torch.zeros((1,), dtype=torch.int32, device=dev)
+        self.reg_loss = torch.zeros((1,), dtype=f32, device=dev)
+        self.data_loss = torch.zeros((1,), dtype=f32, device=dev)
+        self.stats = torch.zeros((max(len(self.dense_shapes), 1) * 260 + 520,), dtype=f32, device=dev)
+        self.loss_scratch = torch.zeros((1024,), dtype=f32, device=dev)
+        self._cap_B = self._cap_nnz = 0
+        self.ws = {}
+        self._eval_ws = None
+        self.init_parameters(seed)
+
+    # ------------------------------------------------------------------ params
+    def init_parameters(self, seed=None):
+        """Initialise like base_model.py:169-213 (distribution only: TF's random stream is
+        not reproducible; parity runs use load_state)."""
+        hp = self.hp
+        gen = torch.Generator(device="cpu")
+        gen.manual_seed(0 if seed is None else int(seed))
+
+        def draw(shape):
+            method = hp.init_method
+            fan_in = shape[0]
+            fan_out = shape[1] if len(shape) > 1 else shape[0]
+            n = int(np.prod(shape))
+            if method == "uniform":
+                t = (torch.rand(n, generator=gen) * 2 - 1) * hp.init_value
+            elif method == "normal":
+                t = torch.randn(n, generator=gen) * hp.init_value
+            elif method in ("xavier_uniform", "he_uniform"):
+                scale, fan = (1.0, (fan_in + fan_out) / 2.0) if method.startswith("xavier") else (2.0, fan_in)
+                t = (torch.rand(n, generator=gen) * 2 - 1) * float(np.sqrt(3.0 * scale / fan))
+            else:
+                if method in ("xavier_normal", "he_normal"):
+                    scale, fan = (1.0, (fan_in + fan_out) / 2.0) if method.startswith("xavier") else (2.0, fan_in)
+                    std = float(np.sqrt(scale / fan)) / 0.87962566103423978
+                else:  # tnormal and the fallback
+                    std = hp.init_value
+                t = torch.empty(n)
+                torch.nn.init.trunc_normal_(t, mean=0.0, std=1.0, a=-2.0, b=2.0, generator=gen)
+                t = t * std
+            return t.view(shape)
+
+        self.table.copy_(draw((self.N, self.D)))
+        if self.lin_w is not None:
+            self.lin_w.copy_(draw((self.N, 1)).view(-1))
+        for name, shape in self.dense_shapes.items():
+            if name.endswith("_b") or "_b_" in name:
+                self.views[name].zero_()
+            else:
+                self.views[name].copy_(draw(shape))
+
+    def state_dict(self):
+        sd = {"embedding": self.table, "step": self.step, "b1p": float(self.b1p), "b2p": float(self.b2p)}
+        if self.lin_w is not None:
+            sd["lin_w"] = self.lin_w.view(-1, 1)
+        for name in self.dense_shapes:
+            sd[name] = self.views[name]
+        for key, t in (("slot/table_m", self.table_m), ("slot/table_v", self.table_v),
+                       ("slot/lin_m", self.lin_m), ("slot/lin_v", self.lin_v),
+                       ("slot/dense_m", self.dense_m), ("slot/dense_v", self.dense_v)):
+            if t is not None:
+                sd[key] = t
+        return sd
+
+    def load_state(self, sd, strict=True):
+        """Load parameters (and, when present, optimizer slots) from a dict of tensors /
+        arrays keyed like state_dict()."""
+        def put(dst, src):
+            src = torch.as_tensor(np.asarray(src) if not torch.is_tensor(src) else src)
+            dst.copy_(src.to(torch.float32).reshape(dst.shape))
+
+        names = ["embedding"] + (["lin_w"] if self.lin_w is not None else []) + list(self.dense_shapes)
+        for name in names:
+            if name not in sd:
+                if strict:
+                    raise KeyError("missing parameter {0}".format(name))
+                continue
+            if name == "embedding":
+                put(self.table, sd[name])
+            elif name == "lin_w":
+                put(self.lin_w, sd[name])
+            else:
+                put(self.views[name], sd[name])
+        for key, t in (("slot/table_m", self.table_m), ("slot/table_v", self.table_v),
+                       ("slot/lin_m", self.lin_m), ("slot/lin_v", self.lin_v),
+                       ("slot/dense_m", self.dense_m), ("slot/dense_v", self.dense_v)):
+            if t is not None and key in sd:
+                put(t, sd[key])
+        if "step" in sd:
+            self.step = int(sd["step"])
+            self.b1p = np.float32(sd.get("b1p", 0.9 ** self.step))
+            self.b2p = np.float32(sd.get("b2p", 0.999 ** self.step))
+
+    def _segment_tables(self):
+        hp = self.hp
+        n = len(self.dense_shapes)
+        l2 = np.zeros(max(n, 1), dtype=np.float32)
+        l1 = np.zeros(max(n, 1), dtype=np.float32)
+        nl2 = np.zeros(max(n, 1), dtype=np.float32)
+        for i, name in enumerate(self.dense_shapes):
+            if name.startswith("cin_f_"):  # cross_params (base_model.py:158-166)
+                l1[i] = hp.cross_l1
+                nl2[i] = hp.cross_l2
+            else:  # layer_params (base_model.py:128-132, :143-148); biases included
+                l2[i] = hp.layer_l2
+                l1[i] = hp.layer_l1
+        off = np.asarray(self.dense_off, dtype=np.int64)
+        return {"off": off, "l2": l2, "l1": l1, "nl2": nl2}
+
+    # --------------------------------------------------------------- workspace
+    def _stream(self):
+        return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _ensure_ws(self, B, nnz):
+        if B <= self._cap_B and nnz <= self._cap_nnz:
+            return
+        hp, dev, f32 = self.hp, self.device, torch.float32
+        B = max(B, self._cap_B, int(hp.batch_size))
+        nnz = max(nnz, self._cap_nnz, B * self.F)
+        F, D = self.F, self.D
+        ws = {}
+
+        def buf(name, *shape, dtype=f32):
+            ws[name] = torch.zeros(shape, dtype=dtype, device=dev)
+
+        buf("emb_out", B, F * D)
+        buf("d_emb", B, F * D)
+        buf("logit", B)
+        buf("pred", B)
+        buf("g_logit", B)
+        buf("dummy", 8)
+        if hp.use_Linear_part:
+            buf("lin_out", B)
+        if hp.use_FM_part:
+            buf("fm_out", B)
+            buf("fm_sum", B, D)
+        sz = ctypes.c_size_t()
+        _lib.check(self.lib.xdfm_dense_bwd_workspace_floats(B, 1, 1, ctypes.byref(sz)))
+        part_floats = sz.value
+        if hp.use_CIN_part:
+            shapes = cin_shapes(hp)
+            final_len = sum(L - nh for (_, L, nh) in shapes)
+            buf("pooled", B, final_len)
+            buf("d_pooled", B, final_len)
+            buf("cin_out", B)
+            for k, (H, L, nh) in enumerate(shapes):
+                if nh > 0:
+                    buf("hid_%d" % k, B, nh * D)
+                    buf("d_hid_%d" % k, B, nh * D)
+                _lib.check(self.lib.xdfm_cin_bwd_workspace_floats(B, F, H, D, L, ctypes.byref(sz)))
+                part_floats = max(part_floats, sz.value)
+            _lib.check(self.lib.xdfm_dense_bwd_workspace_floats(B, final_len, 1, ctypes.byref(sz)))
+            part_floats = max(part_floats, sz.value)
+        if hp.use_DNN_part:
+            last = F * D
+            for k, size in enumerate(hp.layer_sizes):
+                buf("h_%d" % k, B, int(size))
+                buf("d_h_%d" % k, B, int(size))
+                _lib.check(self.lib.xdfm_dense_bwd_workspace_floats(B, last, int(size), ctypes.byref(sz)))
+                part_floats = max(part_floats, sz.value)
+                last = int(size)
+            buf("dnn_out", B)
+            _lib.check(self.lib.xdfm_dense_bwd_workspace_floats(B, last, 1, ctypes.byref(sz)))
+            part_floats = max(part_floats, sz.value)
+        buf("part", max(part_floats, 1))
+        buf("pieces", nnz * (D + 1) + 1)
+        buf("long_list", nnz + 2, dtype=torch.int32)
+        _lib.check(self.lib.xdfm_embed_plan_workspace_bytes(nnz, self.N, ctypes.byref(sz)))
+        buf("plan_ws", sz.value, dtype=torch.uint8)
+        self.ws = ws
+        self._cap_B, self._cap_nnz = B, nnz
+
+    # ------------------------------------------------------------------- batch
+    def upload(self, labels, dnn_feat_indices, dnn_feat_values, dnn_feat_weights):
+        """numpy arrays of the iterator (iterator.py:204-218) -> DeviceBatch."""
+        dev = self.device
+        labels = np.ascontiguousarray(np.asarray(labels, dtype=np.float32).reshape(-1))
+        ids = np.ascontiguousarray(np.asarray(dnn_feat_values, dtype=np.int64).reshape(-1))
+        w = np.ascontiguousarray(np.asarray(dnn_feat_weights, dtype=np.float32).reshape(-1))
+        idx = np.ascontiguousarray(np.asarray(dnn_feat_indices, dtype=np.int64).reshape(-1, 2))
+        if not (len(ids) == len(w) == len(idx)):
+            raise ValueError("dnn_feat_indices / values / weights disagree in length")
+        return self.make_batch(
+            torch.from_numpy(labels).to(dev, non_blocking=True),
+            torch.from_numpy(idx).to(dev, non_blocking=True),
+            torch.from_numpy(ids).to(dev, non_blocking=True),
+            torch.from_numpy(w).to(dev, non_blocking=True),
+        )
+
+    def make_batch(self, labels, dnn_idx, ids, weights):
+        """Device tensors -> DeviceBatch (builds the CSR offsets on the device)."""
+        b = DeviceBatch()
+        b.B = int(labels.numel())
+        b.nnz = int(ids.numel())
+        b.labels, b.ids, b.weights = labels, ids, weights
+        b.row_ptr = torch.empty((b.B * self.F + 1,), dtype=torch.int32, device=self.device)
+        b.tok_row = torch.empty((max(b.nnz, 1),), dtype=torch.int32, device=self.device)
+        _lib.check(
+            self.lib.xdfm_build_row_ptr(_ptr(dnn_idx), b.nnz, b.B * self.F, _ptr(b.row_ptr),
+                                        _ptr(b.tok_row), _ptr(self.err_flag), self._stream())
+        )
+        b.sorted_ids = b.sorted_tok = None
+        b.planned = False
+        return b
+
+    def plan(self, batch):
+        """Sort the batch's tokens by feature id (needed by the backward only)."""
+        if batch.planned:
+            return
+        self._ensure_ws(batch.B, batch.nnz)
+        batch.sorted_ids = torch.empty((max(batch.nnz, 1),), dtype=torch.int32, device=self.device)
+        batch.sorted_tok = torch.empty((max(batch.nnz, 1),), dtype=torch.int32, device=self.device)
+        ws = self.ws["plan_ws"]
+        _lib.check(
+            self.lib.xdfm_embed_plan(_ptr(batch.ids), batch.nnz, self.N, _ptr(batch.sorted_ids),
+                                     _ptr(batch.sorted_tok), _ptr(ws), ws.numel(), self._stream())
+        )
+        batch.planned = True
+
+    def check_errors(self):
+        """Read the device error flag (synchronises) and raise like the reference's
+        runtime would for out-of-range indices."""
+        flag = int(self.err_flag.item())
+        if flag:
+            self.err_flag.zero_()
+            msgs = [m for bit, m in _DEVERR.items() if flag & bit]
+            raise ValueError("invalid batch: " + "; ".join(msgs))
+
+    # ----------------------------------------------------------------- forward
+    def forward(self, batch, with_loss=True, with_grad=False):
+        hp, lib, ws, st = self.hp, self.lib, None, self._stream()
+        self._ensure_ws(batch.B, batch.nnz)
+        ws = self.ws
+        B, F, D = batch.B, self.F, self.D
+        use_lin, use_fm = bool(hp.use_Linear_part), bool(hp.use_FM_part)
+        _lib.check(
+            lib.xdfm_embed_fwd(
+                _ptr(self.table), _ptr(self.lin_w) if use_lin else None, self.N, D, F, B,
+                _ptr(batch.row_ptr), _ptr(batch.ids), _ptr(batch.weights), batch.nnz,
+                _ptr(ws["emb_out"]), _ptr(ws["lin_out"]) if use_lin else None,
+                _ptr(ws["fm_out"]) if use_fm else None, _ptr(ws["fm_sum"]) if use_fm else None,
+                _ptr(self.err_flag), st,
+            )
+        )
+        if hp.use_CIN_part:
+            shapes = cin_shapes(hp)
+            final_len = ws["pooled"].shape[1]
+            off = 0
+            x0 = ws["emb_out"]
+            xk = x0
+            for k, (H, L, nh) in enumerate(shapes):
+                xnext = ws["hid_%d" % k] if nh > 0 else None
+                _lib.check(
+                    lib.xdfm_cin_fwd(_ptr(x0), _ptr(xk), _ptr(self.views["cin_f_%d" % k]), B, F, H, D,
+                                     L, nh, 1 if k == 0 else 0, _ptr(xnext), _ptr(ws["pooled"]),
+                                     final_len, off, st)
+                )
+                off += L - nh
+                xk = xnext
+            _lib.check(
+                lib.xdfm_cin_head_fwd(_ptr(ws["pooled"]), _ptr(self.views["cin_w_out"]),
+                                      _ptr(self.views["cin_b_out"]), B, final_len,
+                                      _ptr(ws["cin_out"]), st)
+            )
+        if hp.use_DNN_part:
+            x, K = ws["emb_out"], F * D
+            for k, size in enumerate(hp.layer_sizes):
+                _lib.check(
+                    lib.xdfm_dense_fwd(_ptr(x), _ptr(self.views["dnn_w_%d" % k]),
+                                       _ptr(self.views["dnn_b_%d" % k]), B, K, int(size),
+                                       _ACT[hp.activation[k]], _ptr(ws["h_%d" % k]), st)
+                )
+                x, K = ws["h_%d" % k], int(size)
+            _lib.check(
+                lib.xdfm_dense_fwd(_ptr(x), _ptr(self.views["dnn_w_out"]), _ptr(self.views["dnn_b_out"]),
+                                   B, K, 1, 0, _ptr(ws["dnn_out"]), st)
+            )
+        _lib.check(
+            lib.xdfm_logit_loss(
+                _ptr(ws["lin_out"]) if use_lin else None, _ptr(ws["fm_out"]) if use_fm else None,
+                _ptr(ws["cin_out"]) if hp.use_CIN_part else None,
+                _ptr(ws["dnn_out"]) if hp.use_DNN_part else None,
+                _ptr(self.views["lin_b"]) if use_lin else None,
+                _ptr(batch.labels) if with_loss else None, B,
+                1 if hp.method == "classification" else 0, _LOSS[hp.loss], _ptr(ws["logit"]),
+                _ptr(ws["pred"]), _ptr(ws["g_logit"]) if with_grad else None,
+                _ptr(self.data_loss) if with_loss else None, _ptr(self.loss_scratch), st,
+            )
+        )
+        return ws["pred"][:B]
+
+    # ---------------------------------------------------------------- backward
+    def backward(self, batch):
+        """Gradients of the data loss w.r.t. every dense parameter (into dense_grad) and
+        w.r.t. emb_out (into ws['d_emb']).  forward(with_grad=True) must have run."""
+        hp, lib, ws, st = self.hp, self.lib, self.ws, self._stream()
+        B, F, D = batch.B, self.F, self.D
+        g = ws["g_logit"]
+        d_emb = ws["d_emb"]
+        gv = self.grad_views
+        wrote_d_emb = False
+        if hp.use_Linear_part:
+            # d lin_b = sum_b g  -- the bias row of a [1]->[1] identity layer
+            _lib.check(
+                lib.xdfm_dense_bwd(_ptr(g), _ptr(self.views["lin_b"]), _ptr(g), _ptr(g), B, 1, 1, 0, None,
+                                   0, _ptr(ws["dummy"]), _ptr(gv["lin_b"]), _ptr(ws["part"]), st)
+            )
+        if hp.use_DNN_part:
+            n_layers = len(hp.layer_sizes)
+            sizes = [F * D] + [int(s) for s in hp.layer_sizes]
+            acts = [ws["emb_out"]] + [ws["h_%d" % k] for k in range(n_layers)]
+            d_acts = [d_emb] + [ws["d_h_%d" % k] for k in range(n_layers)]
+            _lib.check(
+                lib.xdfm_dense_bwd(_ptr(acts[-1]), _ptr(self.views["dnn_w_out"]), _ptr(ws["dnn_out"]),
+                                   _ptr(g), B, sizes[-1], 1, 0, _ptr(d_acts[-1]), 0, _ptr(gv["dnn_w_out"]),
+                                   _ptr(gv["dnn_b_out"]), _ptr(ws["part"]), st)
+            )
+            for k in range(n_layers - 1, -1, -1):
+                _lib.check(
+                    lib.xdfm_dense_bwd(_ptr(acts[k]), _ptr(self.views["dnn_w_%d" % k]), _ptr(acts[k + 1]),
+                                       _ptr(d_acts[k + 1]), B, sizes[k], sizes[k + 1],
+                                       _ACT[hp.activation[k]], _ptr(d_acts[k]), 0,
+                                       _ptr(gv["dnn_w_%d" % k]), _ptr(gv["dnn_b_%d" % k]),
+                                       _ptr(ws["part"]), st)
+                )
+            wrote_d_emb = True
+        if not wrote_d_emb:
+            d_emb[:B].zero_()
+        if hp.use_CIN_part:
+            shapes = cin_shapes(hp)
+            final_len = ws["pooled"].shape[1]
+            _lib.check(
+                lib.xdfm_cin_head_bwd(_ptr(ws["pooled"]), _ptr(self.views["cin_w_out"]), _ptr(g), B,
+                                      final_len, _ptr(ws["d_pooled"]), _ptr(gv["cin_w_out"]),
+                                      _ptr(gv["cin_b_out"]), _ptr(ws["part"]), st)
+            )
+            offs, off = [], 0
+            for (H, L, nh) in shapes:
+                offs.append(off)
+                off += L - nh
+            x0 = ws["emb_out"]
+            for k in range(len(shapes) - 1, -1, -1):
+                H, L, nh = shapes[k]
+                xk = x0 if k == 0 else ws["hid_%d" % (k - 1)]
+                d_xnext = ws["d_hid_%d" % k] if nh > 0 else None
+                d_xk = None if k == 0 else ws["d_hid_%d" % (k - 1)]
+                _lib.check(
+                    lib.xdfm_cin_bwd(_ptr(x0), _ptr(xk), _ptr(self.views["cin_f_%d" % k]), B, F, H, D, L,
+                                     nh, 1 if k == 0 else 0, _ptr(d_xnext), _ptr(ws["d_pooled"]),
+                                     final_len, offs[k], _ptr(d_xk), _ptr(d_emb),
+                                     _ptr(gv["cin_f_%d" % k]), _ptr(ws["part"]), st)
+                )
+
+    def _opt_args(self, l2=0.0, l1=0.0, clip=0.0):
+        hp = self.hp
+        return _lib.OptArgs(self.opt_kind, float(hp.learning_rate), 0.9, 0.999, 1e-8,
+                            float(self.b1p), float(self.b2p), float(l2), float(l1), float(clip))
+
+    def update(self, batch):
+        """apply_gradients (base_model.py:305-322) for every variable + regular_loss
+        (base_model.py:264-272, value before the update) into self.reg_loss."""
+        hp, lib, ws, st = self.hp, self.lib, self.ws, self._stream()
+        self.step += 1
+        if self.opt_kind == 1:
+            self.b1p = np.float32(self.b1p * np.float32(0.9))
+            self.b2p = np.float32(self.b2p * np.float32(0.999))
+        clip = float(hp.max_grad_norm) if hp.is_clip_norm else 0.0
+        use_lin, use_fm = bool(hp.use_Linear_part), bool(hp.use_FM_part)
+        self.plan(batch)
+        sparse = self.embedding_update == "sparse_rows"
+        opt_sparse = self._opt_args()
+        _lib.check(
+            lib.xdfm_embed_bwd(
+                0 if sparse else 1, _ptr(self.table), _ptr(self.table_m), _ptr(self.table_v),
+                _ptr(self.lin_w) if use_lin else None, _ptr(self.lin_m) if use_lin else None,
+                _ptr(self.lin_v) if use_lin else None, _ptr(self.grad_table),
+                _ptr(self.grad_lin) if use_lin else None, self.N, self.D, self.F, batch.B,
+                _ptr(batch.sorted_ids), _ptr(batch.sorted_tok), _ptr(batch.tok_row),
+                _ptr(batch.weights), batch.nnz, _ptr(ws["d_emb"]),
+                _ptr(ws["g_logit"]) if (use_lin or use_fm) else None,
+                _ptr(ws["fm_sum"]) if use_fm else None, 1 if use_fm else 0,
+                ctypes.byref(opt_sparse), _ptr(ws["pieces"]), _ptr(ws["long_list"]), st,
+            )
+        )
+        first = True  # the first dense_update writes reg_loss, the others accumulate
+        if not sparse:
+            one = np.asarray([0, self.N * self.D], dtype=np.int64)
+            opt = self._opt_args(clip=clip)
+            _lib.check(
+                lib.xdfm_dense_update(
+                    _ptr(self.table), _ptr(self.grad_table), _ptr(self.table_m), _ptr(self.table_v), 1,
+                    one.ctypes.data_as(ctypes.c_void_p),
+                    np.asarray([hp.embed_l2], dtype=np.float32).ctypes.data_as(ctypes.c_void_p),
+                    np.asarray([hp.embed_l1], dtype=np.float32).ctypes.data_as(ctypes.c_void_p),
+                    None, ctypes.byref(opt), _ptr(self.stats), _ptr(self.reg_loss), 0, st,
+                )
+            )
+            first = False
+            if use_lin:
+                one = np.asarray([0, self.N], dtype=np.int64)
+                _lib.check(
+                    lib.xdfm_dense_update(
+                        _ptr(self.lin_w), _ptr(self.grad_lin), _ptr(self.lin_m), _ptr(self.lin_v), 1,
+                        one.ctypes.data_as(ctypes.c_void_p),
+                        np.asarray([hp.layer_l2], dtype=np.float32).ctypes.data_as(ctypes.c_void_p),
+                        np.asarray([hp.layer_l1], dtype=np.float32).ctypes.data_as(ctypes.c_void_p),
+                        None, ctypes.byref(opt), _ptr(self.stats), _ptr(self.reg_loss), 1, st,
+                    )
+                )
+            _lib.check(
+                lib.xdfm_embed_clear_rows(_ptr(self.grad_table), _ptr(self.grad_lin) if use_lin else None,
+                                          self.D, _ptr(batch.sorted_ids), batch.nnz, st)
+            )
+        n_seg = len(self.dense_shapes)
+        if n_seg:
+            seg = self._seg
+            opt = self._opt_args(clip=clip)
+            for s0 in range(0, n_seg, 32):
+                s1 = min(n_seg, s0 + 32)
+                base = int(seg["off"][s0])
+                off = (seg["off"][s0 : s1 + 1] - base).astype(np.int64)
+                sl = slice(base, int(seg["off"][s1]))
+                _lib.check(
+                    lib.xdfm_dense_update(
+                        _ptr(self.dense[sl]), _ptr(self.dense_grad[sl]),
+                        _ptr(self.dense_m[sl]) if self.dense_m is not None else None,
+                        _ptr(self.dense_v[sl]) if self.dense_v is not None else None, s1 - s0,
+                        off.ctypes.data_as(ctypes.c_void_p),
+                        np.ascontiguousarray(seg["l2"][s0:s1]).ctypes.data_as(ctypes.c_void_p),
+                        np.ascontiguousarray(seg["l1"][s0:s1]).ctypes.data_as(ctypes.c_void_p),
+                        np.ascontiguousarray(seg["nl2"][s0:s1]).ctypes.data_as(ctypes.c_void_p),
+                        ctypes.byref(opt), _ptr(self.stats), _ptr(self.reg_loss), 0 if first else 1, st,
+                    )
+                )
+                first = False
+        if first:
+            self.reg_loss.zero_()
+
+    def train_step(self, batch):
+        """One optimisation step; returns (total_loss, data_loss) as 0-dim device tensors."""
+        self.forward(batch, with_loss=True, with_grad=True)
+        self.backward(batch)
+        self.update(batch)
+        return (self.data_loss + self.reg_loss)[0], self.data_loss[0].clone()
+
+    # -------------------------------------------------------------------- eval
+    def eval_metrics(self, preds, labels):
+        """Fused AUC + logloss of device vectors -> (auc, logloss) python floats."""
+        n = int(preds.numel())
+        sz = ctypes.c_size_t()
+        _lib.check(self.lib.xdfm_eval_workspace_bytes(n, ctypes.byref(sz)))
+        if self._eval_ws is None or self._eval_ws.numel() < sz.value:
+            self._eval_ws = torch.empty((sz.value,), dtype=torch.uint8, device=self.device)
+        out = torch.zeros((4,), dtype=torch.float64, device=self.device)
+        _lib.check(
+            self.lib.xdfm_eval_auc_logloss(_ptr(preds), _ptr(labels), n, _ptr(out), _ptr(self._eval_ws),
+                                           self._eval_ws.numel(), self._stream())
+        )
+        auc, logloss, n_pos, _ = out.tolist()
+        return auc, logloss, n_pos
