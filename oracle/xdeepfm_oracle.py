@@ -376,7 +376,7 @@ def train_step(params, st, batch, hp, mode="dense_exact"):
         lookup = {"uniq": uniq}
 
         def remap(x):
-            return torch.searchsorted(lookup["uniq"], x)
+            return torch.searchsorted(lookup["uniq"], x.contiguous())
 
         sub = params["embedding"][uniq].clone().requires_grad_(True)
         leaves["embedding"] = sub
@@ -418,7 +418,7 @@ def train_step(params, st, batch, hp, mode="dense_exact"):
                 _apply(n, params[n], g, st, hp, rows=uniq)
             else:
                 _apply(n, params[n], g, st, hp)
-    return float(loss), float(dl), grads, aux
+    return float(loss.detach()), float(dl.detach()), grads, aux
 
 
 def _regular_loss_subset(params, hp):

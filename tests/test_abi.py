@@ -1,0 +1,62 @@
+"""The C-ABI library loads on a CPU-only box, exports every symbol include/xdfm.h declares,
+and the ctypes table agrees with the header's argument counts.  No compute call is made."""
+import ctypes
+import os
+import re
+
+from recommenders_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_decls():
+    text = open(os.path.join(ROOT, "include", "xdfm.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    decls = {}
+    for m in re.finditer(r"\b(int|const char\*)\s+(xdfm_\w+)\s*\(([^;{]*?)\)\s*;", text, flags=re.S):
+        args = m.group(3).strip()
+        n = 0 if args in ("", "void") else len([a for a in args.split(",") if a.strip()])
+        decls[m.group(2)] = n
+    return decls
+
+
+def test_every_declared_symbol_is_exported_and_bound():
+    decls = _header_decls()
+    assert len(decls) >= 20
+    handle = ctypes.CDLL(_lib.LIB_PATH)
+    for name, nargs in decls.items():
+        assert hasattr(handle, name), "libxdfm.so does not export " + name
+        if name == "xdfm_last_error":
+            continue
+        assert name in _lib.SIGNATURES, "no ctypes binding for " + name
+        assert len(_lib.SIGNATURES[name]) == nargs, name
+    for name in _lib.SIGNATURES:
+        assert name in decls, "binding without declaration: " + name
+
+
+def test_abi_version_and_error_channel():
+    assert _lib.lib.xdfm_abi_version() == 1
+    # argument validation happens on the host before any device work
+    sz = ctypes.c_size_t()
+    rc = _lib.lib.xdfm_dense_bwd_workspace_floats(-1, 0, 0, ctypes.byref(sz))
+    assert rc == -1
+    assert b"bad argument" in _lib.lib.xdfm_last_error()
+    rc = _lib.lib.xdfm_embed_fwd(None, None, 10, 4, 2, 1, None, None, None, 0, None, None, None,
+                                 None, None, None)
+    assert rc == -1 and b"null" in _lib.lib.xdfm_last_error()
+
+
+def test_struct_layouts_match_header():
+    assert ctypes.sizeof(_lib.OptArgs) == 40
+    assert ctypes.sizeof(_lib.BatchInfo) == 40
+
+
+def test_product_never_imports_the_oracle():
+    bad = []
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "recommenders_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cpp", ".h")):
+                src = open(os.path.join(dirpath, f)).read()
+                if re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M):
+                    bad.append(f)
+    assert not bad, bad

@@ -1,0 +1,245 @@
+"""GPU parity of every C-ABI entry point against the CPU oracle (oracle/), on seeded ragged
+inputs.  Bars (BASELINE.json north_star): embedding gather bit-exact; everything else fp32
+within 1e-5 relative to the tensor's scale; integer work (AUC pair counts, sort plans) exact."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import xdeepfm_oracle as X
+from recommenders_amd import _lib
+from recommenders_amd.models.deeprec import deeprec_utils as U
+from recommenders_amd.models.deeprec.models._engine import XDeepFMEngine, _ptr
+from tests.util import make_hp, random_batch
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-5  # the fp32 tolerance north_star states
+
+
+def close(got, exp, rtol=RTOL, what=""):
+    got = np.asarray(got, dtype=np.float64)
+    exp = np.asarray(exp, dtype=np.float64)
+    assert got.shape == exp.shape, (what, got.shape, exp.shape)
+    scale = max(float(np.abs(exp).max()), 1e-30)
+    err = float(np.abs(got - exp).max())
+    assert err <= rtol * scale, "%s: max err %.3e vs scale %.3e (rel %.2e)" % (what, err, scale, err / scale)
+
+
+def load_engine(hp, params, mode="dense_exact"):
+    eng = XDeepFMEngine(hp, embedding_update=mode)
+    eng.load_state({k: v.detach().clone() for k, v in params.items()})
+    return eng
+
+
+def upload(eng, b):
+    return eng.upload(b["labels"], b["dnn_feat_indices"], b["dnn_feat_values"], b["dnn_feat_weights"])
+
+
+@pytest.mark.parametrize("dim", [10, 16, 7, 64])
+def test_embedding_gather_bit_exact(dim):
+    rng = np.random.default_rng(dim)
+    hp = make_hp(dim=dim, FEATURE_COUNT=5000, FIELD_COUNT=39, use_CIN_part=False, use_DNN_part=False)
+    B = 257
+    b = random_batch(rng, hp, B, multi_p=0.2, missing_p=0.15, numeric_fields=13)
+    p = X.init_params(hp, seed=1)
+    eng = load_engine(hp, p)
+    db = upload(eng, b)
+    eng.forward(db, with_loss=False)
+    torch.cuda.synchronize()
+    eng.check_errors()
+    got = eng.ws["emb_out"][:B].cpu().numpy().reshape(B * hp.FIELD_COUNT, dim)
+    exp = X.embedding_lookup_sparse_np(p["embedding"].numpy(), b["dnn_feat_indices"], b["dnn_feat_values"],
+                                       b["dnn_feat_weights"], B * hp.FIELD_COUNT)
+    assert got.dtype == np.float32 and np.array_equal(got.view(np.uint32), exp.view(np.uint32))
+    # linear and FM side outputs of the same kernel
+    _, aux = X.forward({k: v.double() for k, v in p.items()}, b, hp)
+    close(eng.ws["lin_out"][:B].cpu().numpy() + p["lin_b"].numpy(), aux["linear"].numpy()[:, 0], what="linear")
+    close(eng.ws["fm_out"][:B].cpu().numpy(), aux["fm"].numpy()[:, 0], what="fm")
+
+
+def test_embedding_gather_edge_cases():
+    hp = make_hp(dim=8, FEATURE_COUNT=50, FIELD_COUNT=3, use_CIN_part=False, use_DNN_part=False,
+                 use_FM_part=False, use_Linear_part=True)
+    p = X.init_params(hp, seed=1)
+    eng = load_engine(hp, p)
+    # a batch whose last samples have no tokens at all (trailing empty rows -> zeros)
+    from oracle import ffm_iterator_oracle as O
+    b = O.convert([1.0, 0.0, 1.0], [[[0, 3, 1.0], [2, 49, 0.5]], [], []], 3, 50)
+    db = upload(eng, b)
+    eng.forward(db, with_loss=False)
+    got = eng.ws["emb_out"][:3].cpu().numpy().reshape(9, 8)
+    exp = X.embedding_lookup_sparse_np(p["embedding"].numpy(), b["dnn_feat_indices"], b["dnn_feat_values"],
+                                       b["dnn_feat_weights"], 9)
+    assert np.array_equal(got, exp) and not got[3:].any()
+    eng.check_errors()
+    # feature id out of range is reported, not read
+    bad = O.convert([1.0], [[[0, 50, 1.0]]], 3, 50)
+    eng.forward(upload(eng, bad), with_loss=False)
+    with pytest.raises(ValueError, match="feature index"):
+        eng.check_errors()
+    # field out of range (row beyond B*F) is reported by the CSR builder
+    bad = O.convert([1.0], [[[5, 1, 1.0]]], 3, 50)
+    upload(eng, bad)
+    with pytest.raises(ValueError, match="field index"):
+        eng.check_errors()
+
+
+CONFIGS = {
+    "all_parts": dict(),
+    "notebook_like": dict(FIELD_COUNT=39, dim=10, FEATURE_COUNT=3000, cross_layer_sizes=[20, 10],
+                          layer_sizes=[20, 20], activation=["relu", "relu"], use_FM_part=False),
+    "cin_only_odd": dict(FIELD_COUNT=5, dim=6, cross_layer_sizes=[10, 6, 7], use_Linear_part=False,
+                         use_FM_part=False, use_DNN_part=False),
+    "dnn_acts": dict(layer_sizes=[9, 33, 5], activation=["sigmoid", "elu", "identity"],
+                     dropout=[0.0, 0.0, 0.0], use_CIN_part=False),
+    "wide_dim": dict(FIELD_COUNT=6, dim=64, cross_layer_sizes=[34, 40], layer_sizes=[70], activation=["relu"]),
+}
+
+
+@pytest.mark.parametrize("name", list(CONFIGS))
+@pytest.mark.parametrize("loss", ["log_loss", "cross_entropy_loss", "square_loss"])
+def test_forward_and_gradients_match_oracle(name, loss):
+    if loss != "log_loss" and name not in ("all_parts", "cin_only_odd"):
+        pytest.skip("loss variants are covered on two configs")
+    rng = np.random.default_rng(11)
+    hp = make_hp(loss=loss, **CONFIGS[name])
+    B = 97
+    b = random_batch(rng, hp, B)
+    p32 = X.init_params(hp, seed=7)
+    for k in p32:
+        if k.endswith("_b") or "_b_" in k:
+            p32[k] = p32[k] + 0.05  # biases away from zero so their role is tested
+    eng = load_engine(hp, p32)
+    db = upload(eng, b)
+    eng.forward(db, with_loss=True, with_grad=True)
+    eng.backward(db)
+    # table / lin_w gradients through the scatter mode of the sorted-key segment sum
+    eng.plan(db)
+    use_lin, use_fm = bool(hp.use_Linear_part), bool(hp.use_FM_part)
+    opt = eng._opt_args()
+    _lib.check(eng.lib.xdfm_embed_bwd(
+        1, _ptr(eng.table), None, None, None, None, None, _ptr(eng.grad_table),
+        _ptr(eng.grad_lin) if use_lin else None, eng.N, eng.D, eng.F, db.B, _ptr(db.sorted_ids),
+        _ptr(db.sorted_tok), _ptr(db.tok_row), _ptr(db.weights), db.nnz, _ptr(eng.ws["d_emb"]),
+        _ptr(eng.ws["g_logit"]) if (use_lin or use_fm) else None,
+        _ptr(eng.ws["fm_sum"]) if use_fm else None, 1 if use_fm else 0, ctypes.byref(opt),
+        _ptr(eng.ws["pieces"]), _ptr(eng.ws["long_list"]), eng._stream()))
+    torch.cuda.synchronize()
+    eng.check_errors()
+
+    # oracle in float64: the yardstick both fp32 implementations are measured against
+    p64 = {k: v.double().requires_grad_(True) for k, v in p32.items()}
+    logit, aux = X.forward(p64, b, hp)
+    pred = X.pred_from_logit(logit, hp)
+    dl = X.data_loss(logit, pred, torch.as_tensor(b["labels"]).double(), hp)
+    dl.backward()
+
+    close(eng.ws["logit"][:B].cpu().numpy(), logit.detach().numpy()[:, 0], what="logit")
+    close(eng.ws["pred"][:B].cpu().numpy(), pred.detach().numpy()[:, 0], what="pred")
+    close(eng.data_loss.cpu().numpy()[0], dl.item(), what="data_loss")
+    for k in eng.dense_shapes:
+        close(eng.grad_views[k].cpu().numpy(), p64[k].grad.numpy().reshape(eng.dense_shapes[k]), what="d " + k)
+    close(eng.grad_table.cpu().numpy(), p64["embedding"].grad.numpy(), what="d embedding")
+    if use_lin:
+        close(eng.grad_lin.cpu().numpy(), p64["lin_w"].grad.numpy()[:, 0], what="d lin_w")
+    # also: the fp32 oracle is no closer to fp64 than the kernels are required to be
+    l32, _ = X.forward(p32, b, hp)
+    close(l32.numpy()[:, 0], logit.detach().numpy()[:, 0], rtol=5 * RTOL, what="oracle fp32 vs fp64")
+
+
+@pytest.mark.parametrize("optimizer", ["adam", "adagrad", "sgd"])
+@pytest.mark.parametrize("mode", ["dense_exact", "sparse_rows"])
+def test_training_steps_match_oracle(optimizer, mode):
+    reg = dict(embed_l2=0.01, layer_l2=0.01, cross_l2=0.01, embed_l1=0.001, layer_l1=0.001, cross_l1=0.001)
+    if mode == "sparse_rows":
+        reg = dict(cross_l2=0.01, cross_l1=0.001)
+    hp = make_hp(optimizer=optimizer, learning_rate=0.01, FEATURE_COUNT=300, **reg)
+    if mode == "sparse_rows":
+        hp = make_hp(optimizer=optimizer, learning_rate=0.01, FEATURE_COUNT=300, use_Linear_part=True, **reg)
+    rng = np.random.default_rng(5)
+    p32 = X.init_params(hp, seed=9)
+    eng = load_engine(hp, p32, mode)
+    p64 = {k: v.double() for k, v in p32.items()}
+    st = X.new_opt_state(p64, hp)
+    for step in range(4):
+        b = random_batch(rng, hp, 64 if step != 2 else 33)
+        db = upload(eng, b)
+        loss, dloss = eng.train_step(db)
+        o_loss, o_dl, _, _ = X.train_step(p64, st, b, hp, mode=mode)
+        close(float(dloss), o_dl, what="data loss step %d" % step)
+        close(float(loss), o_loss, what="total loss step %d" % step)
+    torch.cuda.synchronize()
+    eng.check_errors()
+    sd = eng.state_dict()
+    # a few Adam steps amplify fp32 rounding of tiny gradients by up to 1/sqrt(v): allow 2e-4 there
+    tol = 2e-4 if optimizer == "adam" else 2e-5
+    for k, v in p64.items():
+        close(sd[k].cpu().numpy().reshape(v.shape), v.numpy(), rtol=tol, what="param " + k)
+
+
+def test_clip_by_norm_matches_oracle():
+    hp = make_hp(is_clip_norm=1, max_grad_norm=0.05, optimizer="sgd", learning_rate=0.1, FEATURE_COUNT=200,
+                 embed_l2=0.01)
+    rng = np.random.default_rng(6)
+    p32 = X.init_params(hp, seed=3)
+    eng = load_engine(hp, p32)
+    p64 = {k: v.double() for k, v in p32.items()}
+    st = X.new_opt_state(p64, hp)
+    b = random_batch(rng, hp, 64)
+    eng.train_step(upload(eng, b))
+    X.train_step(p64, st, b, hp)
+    sd = eng.state_dict()
+    for k, v in p64.items():
+        close(sd[k].cpu().numpy().reshape(v.shape), v.numpy(), rtol=2e-5, what="param " + k)
+
+
+def test_backward_is_deterministic_with_heavy_duplicates():
+    """13 'numeric' fields collapse to 13 hot rows: thousands of tokens per row.  Two runs must
+    be bit identical (no float atomics) and equal the oracle."""
+    hp = make_hp(FIELD_COUNT=39, dim=16, FEATURE_COUNT=100000, use_CIN_part=False, use_FM_part=False,
+                 layer_sizes=[8], activation=["relu"], optimizer="adam")
+    rng = np.random.default_rng(8)
+    from recommenders_amd.synth import criteo_shape_ids
+    from oracle import ffm_iterator_oracle as O
+    B = 2048
+    ids = criteo_shape_ids(rng, B, hp.FEATURE_COUNT)
+    vals = np.where(np.arange(39)[None, :] < 13, np.round(rng.random((B, 39)), 3), 1.0)
+    feats = [[[f, int(ids[i, f]), float(vals[i, f])] for f in range(39)] for i in range(B)]
+    b = O.convert(list(rng.integers(0, 2, B).astype(float)), feats, 39, hp.FEATURE_COUNT)
+    p32 = X.init_params(hp, seed=2)
+    outs = []
+    for _ in range(2):
+        eng = load_engine(hp, p32, "sparse_rows")
+        eng.train_step(upload(eng, b))
+        torch.cuda.synchronize()
+        outs.append((eng.table.cpu().numpy().copy(), eng.lin_w.cpu().numpy().copy()))
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+    p64 = {k: v.double() for k, v in p32.items()}
+    X.train_step(p64, X.new_opt_state(p64, hp), b, hp, mode="sparse_rows")
+    close(outs[0][0], p64["embedding"].numpy(), rtol=2e-4, what="table after 1 sparse Adam step")
+
+
+def test_eval_auc_logloss_matches_cal_metric(golden):
+    hp = make_hp(use_CIN_part=False, use_DNN_part=False, use_FM_part=False)
+    eng = XDeepFMEngine(hp)
+    cases = [c for c in golden("cal_metric_golden.json") if c["metrics"][0] == "auc"]
+    rng = np.random.default_rng(3)
+    n = 200000
+    y = (rng.random(n) < 0.3).astype(np.float32)
+    p = np.round(rng.random(n), 3).astype(np.float32)  # many ties
+    p[:10] = [0.0, 1.0, 0.0, 1.0, 0.5, 0.5, 1e-12, 1 - 1e-7, 0.25, 0.75]
+    cases.append({"labels": y.tolist(), "preds": p.tolist(), "expected": None})
+    for c in cases:
+        labels = np.asarray(c["labels"], dtype=np.float32)
+        preds = np.asarray(c["preds"], dtype=np.float32)
+        auc, ll, n_pos = eng.eval_metrics(torch.from_numpy(preds).cuda(), torch.from_numpy(labels).cuda())
+        ref = U.cal_metric(list(labels), list(preds), ["auc", "logloss"])
+        assert n_pos == float(labels.sum())
+        assert round(auc, 4) == ref["auc"] and round(ll, 4) == ref["logloss"]
+        if c["expected"]:
+            assert round(auc, 4) == c["expected"]["auc"] and round(ll, 4) == c["expected"]["logloss"]
+        # unrounded: the AUC is an exact integer ratio
+        exact = U._binary_auc(labels, preds)
+        assert abs(auc - exact) < 1e-15

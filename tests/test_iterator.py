@@ -1,0 +1,135 @@
+"""FFMTextIterator: oracle and product against fixtures produced by the reference's own iterator
+(tests/golden/gen_golden.py), and product against oracle on synthetic ragged files.
+The C++ reader lives in libxdfm.so but is host code: no GPU needed."""
+import numpy as np
+import pytest
+
+from oracle import ffm_iterator_oracle as O
+from recommenders_amd.models.deeprec.io.iterator import FFMTextIterator
+from recommenders_amd.synth import write_plumbing_sample
+from tests.util import make_hp
+
+KEYS = ["labels", "fm_feat_indices", "fm_feat_values", "fm_feat_shape", "dnn_feat_indices",
+        "dnn_feat_values", "dnn_feat_weights", "dnn_feat_shape"]
+PH = {"labels": "label"}
+
+
+def _expect(arr):
+    return np.asarray(arr["data"], dtype=arr["dtype"]).reshape(arr["shape"])
+
+
+def _check_batch(got, exp_arrays, ctx):
+    for k in KEYS:
+        e = _expect(exp_arrays[PH.get(k, k)])
+        g = np.asarray(got[k])
+        assert g.dtype == e.dtype, (ctx, k, g.dtype, e.dtype)
+        assert g.shape == e.shape, (ctx, k, g.shape, e.shape)
+        assert np.array_equal(g, e), (ctx, k)
+
+
+def _write(tmp_path, name, text):
+    p = tmp_path / (name + ".txt")
+    with open(p, "w", newline="") as f:
+        f.write(text)
+    return str(p)
+
+
+def test_oracle_matches_reference_fixtures(golden, tmp_path):
+    cases = golden("ffm_iterator_golden.json")
+    assert "survey_8c3" in cases
+    for name, case in cases.items():
+        path = _write(tmp_path, name, case["text"])
+        out = list(O.batches(path, case["batch_size"], case["FIELD_COUNT"], case["FEATURE_COUNT"]))
+        assert len(out) == len(case["batches"])
+        for (arrays, imps, n), exp in zip(out, case["batches"]):
+            assert n == exp["n"] and imps == exp["impression_ids"]
+            _check_batch(arrays, exp["arrays"], name)
+
+
+@pytest.mark.parametrize("native", [True, False])
+def test_product_matches_reference_fixtures(golden, tmp_path, native):
+    cases = golden("ffm_iterator_golden.json")
+    for name, case in cases.items():
+        path = _write(tmp_path, name, case["text"])
+        hp = make_hp(FEATURE_COUNT=case["FEATURE_COUNT"], FIELD_COUNT=case["FIELD_COUNT"],
+                     batch_size=case["batch_size"])
+        it = FFMTextIterator(hp, None)
+        gen = it._load_native(path) if native else it._load_python(path)
+        out = list(gen)
+        assert len(out) == len(case["batches"]), name
+        for (feed, imps, n), exp in zip(out, case["batches"]):
+            assert isinstance(feed, dict)
+            assert n == exp["n"] and list(imps) == exp["impression_ids"], name
+            got = {k: feed[getattr(it, k)] for k in KEYS}
+            _check_batch(got, exp["arrays"], name)
+
+
+def test_survey_vector_literal(tmp_path):
+    """The outputs SURVEY.md 8(c)(3) records for the reference's iterator, typed in by hand."""
+    path = _write(tmp_path, "s", "1 1:1:1.0 2:4:0.5 2:5:0.25 3:9:1\n0 1:2:1 3:10:2.0%imp7\n1 2:6:1 1:3:1\n")
+    hp = make_hp(FEATURE_COUNT=10, FIELD_COUNT=3, batch_size=2)
+    it = FFMTextIterator(hp, None)
+    (f1, imp1, n1), (f2, imp2, n2) = list(it.load_data_from_file(path))
+    assert (n1, imp1) == (2, [0, "imp7"]) and (n2, imp2) == (1, [0])
+    assert f1[it.fm_feat_indices].tolist() == [[0, 0], [0, 3], [0, 4], [0, 8], [1, 1], [1, 9]]
+    assert f1[it.fm_feat_values].tolist() == [1, 0.5, 0.25, 1, 1, 2]
+    assert f1[it.fm_feat_shape].tolist() == [2, 10]
+    assert f1[it.dnn_feat_indices].tolist() == [[0, 0], [1, 0], [1, 1], [2, 0], [3, 0], [5, 0]]
+    assert f1[it.dnn_feat_values].tolist() == [0, 3, 4, 8, 1, 9]
+    assert f1[it.dnn_feat_weights].tolist() == [1, 0.5, 0.25, 1, 1, 2]
+    assert f1[it.dnn_feat_shape].tolist() == [6, 2]
+    assert f1[it.labels].tolist() == [[1], [0]]
+    assert f2[it.fm_feat_indices].tolist() == [[0, 5], [0, 2]]
+    assert f2[it.dnn_feat_indices].tolist() == [[0, 0], [1, 0]]
+    assert f2[it.dnn_feat_values].tolist() == [2, 5]
+    assert f2[it.dnn_feat_shape].tolist() == [3, 1]
+    assert f1.row_ptr.tolist() == [0, 1, 3, 4, 5, 5, 6]
+
+
+def test_native_reader_vs_oracle_on_plumbing_sample(tmp_path):
+    path = write_plumbing_sample(str(tmp_path / "s1.txt"), n=700, field_count=10, feature_count=1000)
+    hp = make_hp(FEATURE_COUNT=1000, FIELD_COUNT=10, batch_size=128)
+    it = FFMTextIterator(hp, None)
+    got = list(it.load_data_from_file(path))
+    exp = list(O.batches(path, 128, 10, 1000))
+    assert len(got) == len(exp) == 6 and got[-1][2] == 700 - 5 * 128
+    for (feed, imps, n), (arrays, eimps, en) in zip(got, exp):
+        assert n == en and list(imps) == eimps
+        for k in KEYS:
+            g, e = feed[getattr(it, k)], arrays[k]
+            assert g.dtype == e.dtype and g.shape == e.shape and np.array_equal(g, e), k
+        # the CSR offsets are the row histogram of the dnn view
+        rows = arrays["dnn_feat_indices"][:, 0]
+        ptr = np.concatenate([[0], np.cumsum(np.bincount(rows, minlength=n * 10))])
+        assert np.array_equal(feed.row_ptr, ptr)
+
+
+def test_parser_one_line_and_errors(tmp_path):
+    hp = make_hp(FEATURE_COUNT=10, FIELD_COUNT=3, batch_size=2)
+    it = FFMTextIterator(hp, None)
+    assert it.parser_one_line("1 1:2:0.5 3:4:1%abc \n") == (1.0, [[0, 1, 0.5], [2, 3, 1.0]], "abc")
+    assert it.parser_one_line("0  2:2:1e-1") == (0.0, [[1, 1, 0.1]], 0)
+    assert it.parser_one_line("1 1:1:1%a%b")[2] == 0  # two separators: no impression id
+    assert O.parse_line("1 1:2:0.5 3:4:1%abc \n") == (1.0, [(0, 1, 0.5), (2, 3, 1.0)], "abc")
+    for bad in ("x 1:1:1\n", "1 1:1\n", "1 a:1:1\n", "1 1:1:zz\n"):
+        p = _write(tmp_path, "bad", bad)
+        with pytest.raises(ValueError):
+            list(it.load_data_from_file(p))
+        with pytest.raises(ValueError):
+            list(it._load_python(p))
+    with pytest.raises(FileNotFoundError):
+        list(it.load_data_from_file(str(tmp_path / "nope.txt")))
+    empty = _write(tmp_path, "empty", "")
+    assert list(it.load_data_from_file(empty)) == []
+
+
+def test_field_out_of_range_aliases_like_reference(tmp_path):
+    # iterator.py does not validate: field >= F aliases into later rows; arrays must still match
+    p = _write(tmp_path, "alias", "1 5:1:1 1:2:1\n0 1:3:1\n")
+    hp = make_hp(FEATURE_COUNT=10, FIELD_COUNT=3, batch_size=2)
+    it = FFMTextIterator(hp, None)
+    (feed, _, n), = list(it.load_data_from_file(p))
+    (arrays, _, _), = list(O.batches(p, 2, 3, 10))
+    for k in KEYS:
+        assert np.array_equal(feed[getattr(it, k)], arrays[k]), k
+    assert feed.row_ptr is None or len(feed.row_ptr) == n * 3 + 1
