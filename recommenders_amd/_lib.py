@@ -9,6 +9,12 @@ missing or a symbol cannot be bound, importing a caller fails with
 import ctypes
 import os
 
+# PyTorch-ROCm ships its own libamdhip64.so.7.  libxdfm.so must bind to THAT runtime instance
+# (same device contexts, streams and allocations as torch), not to a second copy from
+# /opt/rocm: importing torch first puts its runtime in the process, and the dynamic loader
+# then satisfies libxdfm.so's NEEDED libamdhip64.so.7 by soname from the already loaded one.
+import torch  # noqa: F401  (must precede the CDLL below)
+
 __all__ = ["lib", "check", "XdfmLibraryError", "XdfmError", "OptArgs", "BatchInfo", "LIB_PATH"]
 
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libxdfm.so")

@@ -170,47 +170,47 @@ class XDeepFMEngine(object):
         self._cap_B = self._cap_nnz = 0
         self.ws = {}
         self._eval_ws = None
+        # name -> [(start_event, end_event)]: filled when bench.py asks for in-situ kernel times
+        self.kernel_events = None
         self.init_parameters(seed)
 
     # ------------------------------------------------------------------ params
     def init_parameters(self, seed=None):
         """Initialise like base_model.py:169-213 (distribution only: TF's random stream is
-        not reproducible; parity runs use load_state)."""
+        not reproducible; parity runs use load_state).  Drawn on the device, so a 33M-row
+        table does not pass through host memory."""
         hp = self.hp
-        gen = torch.Generator(device="cpu")
+        gen = torch.Generator(device=self.device)
         gen.manual_seed(0 if seed is None else int(seed))
 
-        def draw(shape):
+        def draw(dst, shape):
             method = hp.init_method
             fan_in = shape[0]
             fan_out = shape[1] if len(shape) > 1 else shape[0]
-            n = int(np.prod(shape))
             if method == "uniform":
-                t = (torch.rand(n, generator=gen) * 2 - 1) * hp.init_value
+                dst.uniform_(-hp.init_value, hp.init_value, generator=gen)
             elif method == "normal":
-                t = torch.randn(n, generator=gen) * hp.init_value
+                dst.normal_(0.0, hp.init_value, generator=gen)
             elif method in ("xavier_uniform", "he_uniform"):
                 scale, fan = (1.0, (fan_in + fan_out) / 2.0) if method.startswith("xavier") else (2.0, fan_in)
-                t = (torch.rand(n, generator=gen) * 2 - 1) * float(np.sqrt(3.0 * scale / fan))
+                lim = float(np.sqrt(3.0 * scale / fan))
+                dst.uniform_(-lim, lim, generator=gen)
             else:
                 if method in ("xavier_normal", "he_normal"):
                     scale, fan = (1.0, (fan_in + fan_out) / 2.0) if method.startswith("xavier") else (2.0, fan_in)
                     std = float(np.sqrt(scale / fan)) / 0.87962566103423978
                 else:  # tnormal and the fallback
-                    std = hp.init_value
-                t = torch.empty(n)
-                torch.nn.init.trunc_normal_(t, mean=0.0, std=1.0, a=-2.0, b=2.0, generator=gen)
-                t = t * std
-            return t.view(shape)
+                    std = float(hp.init_value)
+                torch.nn.init.trunc_normal_(dst, mean=0.0, std=std, a=-2.0 * std, b=2.0 * std, generator=gen)
 
-        self.table.copy_(draw((self.N, self.D)))
+        draw(self.table, (self.N, self.D))
         if self.lin_w is not None:
-            self.lin_w.copy_(draw((self.N, 1)).view(-1))
+            draw(self.lin_w, (self.N, 1))
         for name, shape in self.dense_shapes.items():
             if name.endswith("_b") or "_b_" in name:
                 self.views[name].zero_()
             else:
-                self.views[name].copy_(draw(shape))
+                draw(self.views[name], shape)
 
     def state_dict(self):
         sd = {"embedding": self.table, "step": self.step, "b1p": float(self.b1p), "b2p": float(self.b2p)}
@@ -271,6 +271,19 @@ class XDeepFMEngine(object):
         return {"off": off, "l2": l2, "l1": l1, "nl2": nl2}
 
     # --------------------------------------------------------------- workspace
+    def _mark(self, name):
+        """HIP events around one C-ABI call on the launch stream (bench.py only)."""
+        if self.kernel_events is None:
+            return None
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        self.kernel_events.setdefault(name, []).append(ev)
+        ev[0].record(torch.cuda.current_stream(self.device))
+        return ev
+
+    def _done(self, ev):
+        if ev is not None:
+            ev[1].record(torch.cuda.current_stream(self.device))
+
     def _stream(self):
         return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
@@ -374,10 +387,12 @@ class XDeepFMEngine(object):
         batch.sorted_ids = torch.empty((max(batch.nnz, 1),), dtype=torch.int32, device=self.device)
         batch.sorted_tok = torch.empty((max(batch.nnz, 1),), dtype=torch.int32, device=self.device)
         ws = self.ws["plan_ws"]
+        ev = self._mark("embed_plan")
         _lib.check(
             self.lib.xdfm_embed_plan(_ptr(batch.ids), batch.nnz, self.N, _ptr(batch.sorted_ids),
                                      _ptr(batch.sorted_tok), _ptr(ws), ws.numel(), self._stream())
         )
+        self._done(ev)
         batch.planned = True
 
     def check_errors(self):
@@ -396,6 +411,7 @@ class XDeepFMEngine(object):
         ws = self.ws
         B, F, D = batch.B, self.F, self.D
         use_lin, use_fm = bool(hp.use_Linear_part), bool(hp.use_FM_part)
+        ev = self._mark("embed_fwd")
         _lib.check(
             lib.xdfm_embed_fwd(
                 _ptr(self.table), _ptr(self.lin_w) if use_lin else None, self.N, D, F, B,
@@ -405,7 +421,9 @@ class XDeepFMEngine(object):
                 _ptr(self.err_flag), st,
             )
         )
+        self._done(ev)
         if hp.use_CIN_part:
+            ev = self._mark("cin_fwd")
             shapes = cin_shapes(hp)
             final_len = ws["pooled"].shape[1]
             off = 0
@@ -425,7 +443,9 @@ class XDeepFMEngine(object):
                                       _ptr(self.views["cin_b_out"]), B, final_len,
                                       _ptr(ws["cin_out"]), st)
             )
+            self._done(ev)
         if hp.use_DNN_part:
+            ev = self._mark("dnn_fwd")
             x, K = ws["emb_out"], F * D
             for k, size in enumerate(hp.layer_sizes):
                 _lib.check(
@@ -438,6 +458,8 @@ class XDeepFMEngine(object):
                 lib.xdfm_dense_fwd(_ptr(x), _ptr(self.views["dnn_w_out"]), _ptr(self.views["dnn_b_out"]),
                                    B, K, 1, 0, _ptr(ws["dnn_out"]), st)
             )
+            self._done(ev)
+        ev = self._mark("logit_loss")
         _lib.check(
             lib.xdfm_logit_loss(
                 _ptr(ws["lin_out"]) if use_lin else None, _ptr(ws["fm_out"]) if use_fm else None,
@@ -450,6 +472,7 @@ class XDeepFMEngine(object):
                 _ptr(self.data_loss) if with_loss else None, _ptr(self.loss_scratch), st,
             )
         )
+        self._done(ev)
         return ws["pred"][:B]
 
     # ---------------------------------------------------------------- backward
@@ -469,6 +492,7 @@ class XDeepFMEngine(object):
                                    0, _ptr(ws["dummy"]), _ptr(gv["lin_b"]), _ptr(ws["part"]), st)
             )
         if hp.use_DNN_part:
+            ev = self._mark("dnn_bwd")
             n_layers = len(hp.layer_sizes)
             sizes = [F * D] + [int(s) for s in hp.layer_sizes]
             acts = [ws["emb_out"]] + [ws["h_%d" % k] for k in range(n_layers)]
@@ -487,9 +511,11 @@ class XDeepFMEngine(object):
                                        _ptr(ws["part"]), st)
                 )
             wrote_d_emb = True
+            self._done(ev)
         if not wrote_d_emb:
             d_emb[:B].zero_()
         if hp.use_CIN_part:
+            ev = self._mark("cin_bwd")
             shapes = cin_shapes(hp)
             final_len = ws["pooled"].shape[1]
             _lib.check(
@@ -513,6 +539,7 @@ class XDeepFMEngine(object):
                                      final_len, offs[k], _ptr(d_xk), _ptr(d_emb),
                                      _ptr(gv["cin_f_%d" % k]), _ptr(ws["part"]), st)
                 )
+            self._done(ev)
 
     def _opt_args(self, l2=0.0, l1=0.0, clip=0.0):
         hp = self.hp
@@ -532,6 +559,7 @@ class XDeepFMEngine(object):
         self.plan(batch)
         sparse = self.embedding_update == "sparse_rows"
         opt_sparse = self._opt_args()
+        ev = self._mark("embed_bwd")
         _lib.check(
             lib.xdfm_embed_bwd(
                 0 if sparse else 1, _ptr(self.table), _ptr(self.table_m), _ptr(self.table_v),
@@ -545,6 +573,8 @@ class XDeepFMEngine(object):
                 ctypes.byref(opt_sparse), _ptr(ws["pieces"]), _ptr(ws["long_list"]), st,
             )
         )
+        self._done(ev)
+        ev_upd = self._mark("dense_update")
         first = True  # the first dense_update writes reg_loss, the others accumulate
         if not sparse:
             one = np.asarray([0, self.N * self.D], dtype=np.int64)
@@ -598,6 +628,7 @@ class XDeepFMEngine(object):
                 first = False
         if first:
             self.reg_loss.zero_()
+        self._done(ev_upd)
 
     def train_step(self, batch):
         """One optimisation step; returns (total_loss, data_loss) as 0-dim device tensors."""
