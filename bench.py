@@ -1,0 +1,257 @@
+#!/usr/bin/env python
+"""Benchmark of the xDeepFM training hot path on MI355X (BASELINE.json metric:
+"train samples/sec, xDeepFM Criteo-shape").
+
+    python bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[2], SURVEY.md 8(d) input S3): Criteo-shape synthetic, 39 fields
+(13 numeric with one hot feature id each + 26 categorical, Zipf-like ids in per-field ranges),
+FEATURE_COUNT = 2^25 hashed rows, dim 16, batch 8192 per GPU, linear + FM + CIN[20,10] + DNN[20,20],
+log_loss, Adam with sparse row updates of the embedding table ("sparse_rows").  A step is one full
+training pass over one batch whose arrays are already resident in HBM: CSR build, forward,
+backward, id sort + segment-sum + fused row Adam, dense Adam.  fp32 throughout.
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): the table is row-sharded over the
+ranks (owner = id mod N) with RCCL all-to-all exchanges, dense gradients are all-reduced; each
+rank keeps its own 8192-sample batch (weak scaling).
+
+Prints ONE JSON line on rank 0.  `roofline` is for the kernel with the largest total time in the
+timed region, its duration measured live with HIP events on the launch stream
+(xdfm_prof_enable/collect); `cpu_baseline` is the CPU oracle (oracle/, torch CPU fp32) timed on a
+bounded sample of the same workload on the host cores.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from recommenders_amd import _lib  # noqa: E402
+from recommenders_amd.models.deeprec.deeprec_utils import prepare_hparams  # noqa: E402
+from recommenders_amd.synth import criteo_shape_ids  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+F32_MATRIX_PEAK_TFLOPS = 157.3  # same guide: fp32 MFMA / vector peak
+
+
+def workload_hparams(args):
+    return prepare_hparams(
+        None, model_type="xDeepFM", data_format="ffm", FEATURE_COUNT=args.features, FIELD_COUNT=39,
+        dim=args.dim, layer_sizes=[20, 20], cross_layer_sizes=[20, 10], activation=["relu", "relu"],
+        dropout=[0.0, 0.0], loss="log_loss", method="classification", metrics=["auc", "logloss"],
+        use_Linear_part=True, use_FM_part=True, use_CIN_part=True, use_DNN_part=True,
+        init_method="tnormal", init_value=0.1, learning_rate=0.002, optimizer="adam",
+        embed_l2=0.0, layer_l2=0.0, cross_l2=0.01, batch_size=args.batch, save_model=False,
+        embedding_update="sparse_rows")
+
+
+def synth_batches(hp, n_batches, seed):
+    """S3 batches as host arrays in the iterator's layout (single-hot: one token per field)."""
+    rng = np.random.default_rng(seed)
+    B, F, N = hp.batch_size, hp.FIELD_COUNT, hp.FEATURE_COUNT
+    out = []
+    rows = np.arange(B * F, dtype=np.int64)
+    dnn_idx = np.stack([rows, np.zeros_like(rows)], axis=1)
+    for _ in range(n_batches):
+        ids = criteo_shape_ids(rng, B, N).astype(np.int64).reshape(-1)
+        w = np.ones((B, F), dtype=np.float32)
+        w[:, :13] = rng.random((B, 13), dtype=np.float32)
+        labels = (rng.random(B) < 0.25).astype(np.float32)
+        out.append({"labels": labels.reshape(B, 1), "dnn_feat_indices": dnn_idx, "dnn_feat_values": ids,
+                    "dnn_feat_weights": w.reshape(-1),
+                    "fm_feat_indices": np.stack([rows // F, ids], axis=1), "fm_feat_values": w.reshape(-1)})
+    return out
+
+
+def kernel_model(name, hp, nnz, uniq):
+    """Algorithmic bytes / flops of ONE launch of a library kernel."""
+    B, F, D = hp.batch_size, hp.FIELD_COUNT, hp.dim
+    if name.startswith("embed_fwd_kernel"):
+        return "hbm", nnz * (8 * D + 12)
+    if name.startswith("embed_bwd_kernel"):
+        # per token: grad row + sorted key + weight; per unique row: read+write of p, m, v
+        return "hbm", nnz * (4 * D + 12) + uniq * 6 * 4 * D
+    if name.startswith("cin_"):
+        pairs0 = F * (F - 1) // 2  # layer-0 mask keeps f < h only; masked pairs are never computed
+        layers = [(pairs0, 20), (F * 10, 10)]
+        L = int(name.split("<")[1].split(">")[0].split(",")[0]) if "<" in name else None
+        sel = [(k, l) for (k, l) in layers if L is None or l <= L] if L else layers
+        # the template argument is the padded channel count: 20 -> layer 0, 12 -> layer 1
+        if L is not None:
+            sel = [layers[0]] if L >= 20 else [layers[1]]
+        flops = sum(2.0 * B * D * k * l for (k, l) in sel)
+        if "bwd_dx" in name:
+            flops = sum(2.0 * B * D * k * l + 4.0 * B * D * k for (k, l) in sel)
+        return "mfma", flops
+    return None, None
+
+
+def run_cpu_baseline(hp, batches, budget_s=20.0):
+    """The oracle's train_step (torch CPU fp32, sparse_rows) on the first batch(es)."""
+    from oracle import xdeepfm_oracle as X
+
+    cores = min(16, os.cpu_count() or 1)
+    torch.set_num_threads(cores)
+    shapes = X.param_shapes(hp)
+    gen = torch.Generator().manual_seed(0)
+    params = {}
+    for name, shape in shapes.items():
+        t = torch.empty(shape, dtype=torch.float32)
+        if name.endswith("_b") or "_b_" in name:
+            t.zero_()
+        else:
+            t.uniform_(-0.1, 0.1, generator=gen)
+        params[name] = t
+    st = X.new_opt_state(params, hp)
+    X.train_step(params, st, batches[0], hp, mode="sparse_rows")  # warm-up (allocator, threads)
+    done, t0 = 0, time.perf_counter()
+    while True:
+        X.train_step(params, st, batches[(done + 1) % len(batches)], hp, mode="sparse_rows")
+        done += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or done >= 8:
+            break
+    return {"value": done * hp.batch_size / el, "unit": "samples/s", "cores": cores, "kind": "port",
+            "sample": "%d training steps of the same batch-%d workload (oracle/xdeepfm_oracle.py, "
+                      "torch CPU fp32, sparse_rows) after 1 warm-up step" % (done, hp.batch_size)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=8192)
+    ap.add_argument("--dim", type=int, default=16)
+    ap.add_argument("--features", type=int, default=1 << 25)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group("nccl", device_id=dev)
+
+    hp = workload_hparams(args)
+    n_batches = 8
+    host_batches = synth_batches(hp, n_batches, seed=1234 + rank)
+
+    if world == 1:
+        from recommenders_amd.models.deeprec.models._engine import XDeepFMEngine
+
+        eng = XDeepFMEngine(hp, device=dev, seed=7, embedding_update="sparse_rows")
+    else:
+        from recommenders_amd.models.deeprec.models._sharded import ShardedXDeepFMEngine
+
+        eng = ShardedXDeepFMEngine(hp, device=dev, seed=7)
+
+    resident = []
+    for hb in host_batches:
+        resident.append(tuple(torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in (
+            hb["labels"].reshape(-1), hb["dnn_feat_indices"], hb["dnn_feat_values"], hb["dnn_feat_weights"])))
+    nnz = int(resident[0][2].numel())
+    uniq = float(np.mean([len(np.unique(hb["dnn_feat_values"])) for hb in host_batches]))
+
+    def step(i):
+        labels, idx, ids, w = resident[i % n_batches]
+        batch = eng.make_batch(labels, idx, ids, w)  # CSR offsets built on the device
+        return eng.train_step(batch)
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    fence()
+    eng.check_errors()
+    _lib.check(_lib.lib.xdfm_prof_enable(1))
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss, _ = step(args.warmup + i)
+    fence()
+    elapsed = time.perf_counter() - t0
+    _lib.check(_lib.lib.xdfm_prof_enable(0))
+    buf = ctypes.create_string_buffer(1 << 16)
+    _lib.check(_lib.lib.xdfm_prof_collect(buf, len(buf)))
+    prof = json.loads(buf.value.decode())
+    eng.check_errors()
+    final_loss = float(loss)
+    if not np.isfinite(final_loss):
+        raise SystemExit("training diverged: loss %r" % final_loss)
+
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        total_ms = sum(v["ms"] for v in prof.values())
+        ranked = sorted(prof.items(), key=lambda kv: -kv[1]["ms"])
+        roofline = None
+        for name, v in ranked:
+            bound, work = kernel_model(name, hp, nnz, uniq)
+            if bound is None:
+                continue
+            avg_s = v["ms"] / v["n"] * 1e-3
+            if bound == "hbm":
+                ach, peak, unit = work / avg_s / 1e9, HBM_PEAK_GBS, "GB/s"
+            else:
+                ach, peak, unit = work / avg_s / 1e12, F32_MATRIX_PEAK_TFLOPS, "TFLOP/s"
+            roofline = {"kernel": name, "bound": bound, "achieved": round(ach, 3), "peak": peak, "unit": unit,
+                        "frac": round(ach / peak, 4), "traffic": None, "avg_us": round(avg_s * 1e6, 2),
+                        "share_of_kernel_time": round(v["ms"] / total_ms, 3)}
+            break
+        kernels = {}
+        for name, v in ranked[:12]:
+            entry = {"avg_us": round(v["ms"] / v["n"] * 1e3, 2), "per_step": round(v["n"] / args.steps, 2)}
+            bound, work = kernel_model(name, hp, nnz, uniq)
+            if bound == "hbm":
+                entry["GB/s"] = round(work / (v["ms"] / v["n"] * 1e-3) / 1e9, 1)
+            elif bound == "mfma":
+                entry["TFLOP/s"] = round(work / (v["ms"] / v["n"] * 1e-3) / 1e12, 2)
+            kernels[name] = entry
+        line = {
+            "metric": "train samples/sec, xDeepFM Criteo-shape", "value": round(world * hp.batch_size * args.steps / elapsed, 1),
+            "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[2]: Criteo-shape synthetic, 39 fields, 2^25 rows, dim %d, "
+                                   "batch %d per GPU, linear+FM+CIN[20,10]+DNN[20,20], sparse-row Adam" % (hp.dim, hp.batch_size),
+                       "FEATURE_COUNT": hp.FEATURE_COUNT, "FIELD_COUNT": 39, "dim": hp.dim,
+                       "global_batch": world * hp.batch_size,
+                       "parallelism": "single GPU" if world == 1 else "table row-sharded x%d (all-to-all) + dense all-reduce" % world},
+            "roofline": roofline,
+            "kernel_time_ms_per_step": round(total_ms / args.steps, 4),
+            "kernels": kernels,
+            "final_loss": round(final_loss, 5),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = run_cpu_baseline(hp, host_batches)
+        print(json.dumps(line))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

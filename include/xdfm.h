@@ -66,6 +66,13 @@ extern "C" {
 int xdfm_abi_version(void);
 const char* xdfm_last_error(void);
 
+/* Measurement only (no reference counterpart): when enabled, every kernel launch of the
+ * library is bracketed by two HIP events on its launch stream.  xdfm_prof_collect waits for
+ * the recorded events, writes {"<kernel name>": {"ms": total, "n": launches}, ...} as JSON
+ * text into `json` and forgets them.  bench.py's roofline line is computed from this. */
+int xdfm_prof_enable(int32_t on);
+int xdfm_prof_collect(char* json, size_t cap);
+
 /* ------------------------------------------------------------------------
  * libffm text ingest (host).  Replaces FFMTextIterator.parser_one_line /
  * load_data_from_file / _convert_data  (io/iterator.py:90-219).

@@ -70,6 +70,8 @@ _PSZ = ctypes.POINTER(ctypes.c_size_t)
 # table against the header text, so a declaration cannot drift from its binding.
 SIGNATURES = {
     "xdfm_abi_version": [],
+    "xdfm_prof_enable": [_I32],
+    "xdfm_prof_collect": [ctypes.c_char_p, _SZ],
     "xdfm_ffm_open": [ctypes.c_char_p, _I64, _I64, ctypes.c_char, ctypes.c_char, ctypes.POINTER(_P)],
     "xdfm_ffm_next": [_P, _I64, ctypes.POINTER(BatchInfo)],
     "xdfm_ffm_fill": [_P] * 11,

@@ -357,7 +357,7 @@ extern "C" int xdfm_cin_fwd(const float* x0, const float* xk, const float* w, in
   CinDims c{B, F, H, D, L, n_hidden, masked};
   dim3 grid((unsigned)((B + spb - 1) / spb), (unsigned)((L + nch - 1) / nch));
 #define CALL(N)                                                                                  \
-  hipLaunchKernelGGL(cin_fwd_kernel<N>, grid, dim3(threads), lds_bytes, (hipStream_t)stream, c, x0, \
+  XDFM_LAUNCH("cin_fwd_kernel<" #N ">", stream, cin_fwd_kernel<N>, grid, dim3(threads), lds_bytes, c, x0, \
                      xk, w, xnext, pooled, pool_stride, pool_off, spb)
   DISPATCH_NCH(nch, CALL);
 #undef CALL
@@ -396,7 +396,7 @@ extern "C" int xdfm_cin_bwd(const float* x0, const float* xk, const float* w, in
   float* part = dw_part + (size_t)B * D * L;
   {
     const int64_t total = B * D * L;
-    hipLaunchKernelGGL(cin_dcurr_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, c,
+    XDFM_LAUNCH("cin_dcurr_kernel", st, cin_dcurr_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c,
                        d_xnext, d_pooled, pool_stride, pool_off, dc_mn);
   }
   const int nch = pick_nch(L);
@@ -410,7 +410,7 @@ extern "C" int xdfm_cin_bwd(const float* x0, const float* xk, const float* w, in
     dim3 grid((unsigned)((B + spb - 1) / spb));
     for (int ch = 0; ch < chunks; ++ch) {
 #define CALL(N)                                                                                   \
-  hipLaunchKernelGGL(cin_bwd_dx_kernel<N>, grid, dim3(threads), lds_bytes, st, c, x0, xk, w, dc_mn, \
+  XDFM_LAUNCH("cin_bwd_dx_kernel<" #N ">", st, cin_bwd_dx_kernel<N>, grid, dim3(threads), lds_bytes, c, x0, xk, w, dc_mn, \
                      ch * nch, ch > 0 ? 1 : 0, d_xk, d_x0, spb)
       DISPATCH_NCH(nch, CALL);
 #undef CALL
@@ -428,13 +428,13 @@ extern "C" int xdfm_cin_bwd(const float* x0, const float* xk, const float* w, in
     if (P > 0) {
       dim3 grid((unsigned)((P + kThreads - 1) / kThreads), (unsigned)n_splits, (unsigned)chunks);
 #define CALL(N)                                                                                  \
-  hipLaunchKernelGGL(cin_bwd_dw_kernel<N>, grid, dim3(kThreads), lds_bytes, st, c, x0, xk, dc_mn, P, \
+  XDFM_LAUNCH("cin_bwd_dw_kernel<" #N ">", st, cin_bwd_dw_kernel<N>, grid, dim3(kThreads), lds_bytes, c, x0, xk, dc_mn, P, \
                      samples_per_split, SUB, part)
       DISPATCH_NCH(nch, CALL);
 #undef CALL
     }
     const int64_t total = (int64_t)F * H * L;
-    hipLaunchKernelGGL(cin_dw_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
+    XDFM_LAUNCH("cin_dw_reduce_kernel", st, cin_dw_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
                        c, part, P > 0 ? n_splits : 0, d_w);
   }
   XDFM_LAUNCH_CHECK();

@@ -207,7 +207,7 @@ extern "C" int xdfm_dense_fwd(const float* x, const float* w, const float* b, in
   const int nch = pick_nch(Nout);
   dim3 grid((unsigned)((B + kT - 1) / kT), (unsigned)((Nout + nch - 1) / nch));
 #define CALL(N)                                                                                \
-  hipLaunchKernelGGL(dense_fwd_kernel<N>, grid, dim3(kT), 0, (hipStream_t)stream, x, w, b, B, K, \
+  XDFM_LAUNCH("dense_fwd_kernel<" #N ">", stream, dense_fwd_kernel<N>, grid, dim3(kT), 0, x, w, b, B, K, \
                      Nout, act, y)
   DISPATCH_NCH(nch, CALL);
 #undef CALL
@@ -237,7 +237,7 @@ extern "C" int xdfm_dense_bwd(const float* x, const float* w, const float* y, co
   float* dz = part;
   float* psum = part + (size_t)B * Nout;
   const int64_t total = B * Nout;
-  hipLaunchKernelGGL(dense_dz_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, y, dy,
+  XDFM_LAUNCH("dense_dz_kernel", st, dense_dz_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, y, dy,
                      total, act, dz);
   const int n_splits = splits_for(B);
   const int samples_per_split = (int)((B + n_splits - 1) / n_splits);
@@ -245,19 +245,19 @@ extern "C" int xdfm_dense_bwd(const float* x, const float* w, const float* y, co
   {
     dim3 grid((unsigned)((K + 1 + 255) / 256), (unsigned)n_splits, (unsigned)((Nout + nch - 1) / nch));
 #define CALL(N)                                                                              \
-  hipLaunchKernelGGL(dense_bwd_dw_kernel<N>, grid, dim3(256), 0, st, x, dz, B, K, Nout,       \
+  XDFM_LAUNCH("dense_bwd_dw_kernel<" #N ">", st, dense_bwd_dw_kernel<N>, grid, dim3(256), 0, x, dz, B, K, Nout,       \
                      samples_per_split, psum)
     DISPATCH_NCH(nch, CALL);
 #undef CALL
   }
   {
     const int64_t tot = (int64_t)(K + 1) * Nout;
-    hipLaunchKernelGGL(dense_dw_reduce_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st,
+    XDFM_LAUNCH("dense_dw_reduce_kernel", st, dense_dw_reduce_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0,
                        psum, n_splits, K, Nout, dw, db);
   }
   if (dx) {
     const int64_t tot = B * K;
-    hipLaunchKernelGGL(dense_bwd_dx_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, dz,
+    XDFM_LAUNCH("dense_bwd_dx_kernel", st, dense_bwd_dx_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, dz,
                        w, B, K, Nout, accumulate_dx, dx);
   }
   XDFM_LAUNCH_CHECK();
@@ -269,8 +269,7 @@ extern "C" int xdfm_cin_head_fwd(const float* pooled, const float* w, const floa
   XDFM_REQUIRE(pooled && w && bias && out, "xdfm_cin_head_fwd: null argument");
   XDFM_REQUIRE(B >= 0 && n > 0, "xdfm_cin_head_fwd: bad sizes");
   if (B == 0) return XDFM_OK;
-  hipLaunchKernelGGL(cin_head_fwd_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0,
-                     (hipStream_t)stream, pooled, w, bias, B, n, out);
+  XDFM_LAUNCH("cin_head_fwd_kernel", stream, cin_head_fwd_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, pooled, w, bias, B, n, out);
   XDFM_LAUNCH_CHECK();
   return XDFM_OK;
 }
@@ -283,7 +282,7 @@ extern "C" int xdfm_cin_head_bwd(const float* pooled, const float* w, const floa
   hipStream_t st = (hipStream_t)stream;
   if (B > 0) {
     const int64_t tot = B * n;
-    hipLaunchKernelGGL(cin_head_dpooled_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, w,
+    XDFM_LAUNCH("cin_head_dpooled_kernel", st, cin_head_dpooled_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, w,
                        g, B, n, d_pooled);
   }
   // dw, db: the weight-gradient path of a [n] -> [1] identity layer whose dy is g

@@ -391,7 +391,7 @@ extern "C" int xdfm_build_row_ptr(const int64_t* dnn_feat_indices, int64_t nnz, 
   XDFM_REQUIRE(nnz == 0 || (dnn_feat_indices && tok_row), "xdfm_build_row_ptr: null input");
   const int threads = 256;
   const unsigned blocks = (unsigned)((nnz + 1 + threads - 1) / threads);
-  hipLaunchKernelGGL(build_row_ptr_kernel, dim3(blocks), dim3(threads), 0, (hipStream_t)stream,
+  XDFM_LAUNCH("build_row_ptr_kernel", stream, build_row_ptr_kernel, dim3(blocks), dim3(threads), 0,
                      dnn_feat_indices, nnz, n_rows, row_ptr, tok_row, err_flag);
   XDFM_LAUNCH_CHECK();
   return XDFM_OK;
@@ -410,7 +410,7 @@ extern "C" int xdfm_embed_fwd(const float* table, const float* lin_w, int64_t N,
   if (B == 0) return XDFM_OK;
   const unsigned blocks = (unsigned)((B + 3) / 4);
 #define LAUNCH(V)                                                                               \
-  hipLaunchKernelGGL(embed_fwd_kernel<V>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, table, \
+  XDFM_LAUNCH("embed_fwd_kernel<" #V ">", stream, embed_fwd_kernel<V>, dim3(blocks), dim3(256), 0, table, \
                      lin_out ? lin_w : nullptr, N, D, F, B, row_ptr, ids, weights, emb_out,      \
                      lin_out, fm_out, fm_sum, err_flag)
   if (vec == 4)
@@ -453,12 +453,15 @@ extern "C" int xdfm_embed_plan(const int64_t* ids, int64_t nnz, int64_t N, int32
   void* tmp = base + 2 * seg;
   size_t tmp_bytes = plan_ws_bytes - 2 * seg;
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(plan_keys_kernel, dim3((unsigned)((nnz + 255) / 256)), dim3(256), 0, st, ids,
+  XDFM_LAUNCH("plan_keys_kernel", st, plan_keys_kernel, dim3((unsigned)((nnz + 255) / 256)), dim3(256), 0, ids,
                      nnz, N, keys, vals);
   XDFM_LAUNCH_CHECK();
-  XDFM_HIP(rocprim::radix_sort_pairs(tmp, tmp_bytes, keys, (uint32_t*)sorted_ids, vals,
-                                     (uint32_t*)sorted_tok, (size_t)nnz, 0u, key_bits(N), st,
-                                     false));
+  {
+    xdfm::ProfScope prof_scope_("rocprim::radix_sort_pairs(plan)", (void*)st);
+    XDFM_HIP(rocprim::radix_sort_pairs(tmp, tmp_bytes, keys, (uint32_t*)sorted_ids, vals,
+                                       (uint32_t*)sorted_tok, (size_t)nnz, 0u, key_bits(N), st,
+                                       false));
+  }
   return XDFM_OK;
 }
 
@@ -532,8 +535,8 @@ extern "C" int xdfm_embed_bwd(int32_t mode, float* table, float* slot_m, float* 
   const unsigned blocks_long = (unsigned)((max_long + gpb - 1) / gpb);
 #define LAUNCH(V, M)                                                                          \
   do {                                                                                        \
-    hipLaunchKernelGGL((embed_bwd_kernel<V, M>), dim3(blocks), dim3(256), 0, st, a);          \
-    hipLaunchKernelGGL((embed_bwd_long_kernel<V, M>), dim3(blocks_long), dim3(256), 0, st, a); \
+    XDFM_LAUNCH("embed_bwd_kernel<" #V ", " #M ">", st, (embed_bwd_kernel<V, M>), dim3(blocks), dim3(256), 0, a);          \
+    XDFM_LAUNCH("embed_bwd_long_kernel<" #V ", " #M ">", st, (embed_bwd_long_kernel<V, M>), dim3(blocks_long), dim3(256), 0, a); \
   } while (0)
   if (mode == 0) {
     if (vec == 4) LAUNCH(4, 0); else if (vec == 2) LAUNCH(2, 0); else LAUNCH(1, 0);
@@ -551,8 +554,7 @@ extern "C" int xdfm_embed_clear_rows(float* grad_table, float* grad_lin, int32_t
   if (nnz == 0) return XDFM_OK;
   XDFM_REQUIRE(sorted_ids, "xdfm_embed_clear_rows: null sorted_ids");
   const int64_t total = nnz * D;
-  hipLaunchKernelGGL(clear_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
-                     (hipStream_t)stream, grad_table, grad_lin, D, sorted_ids, nnz);
+  XDFM_LAUNCH("clear_rows_kernel", stream, clear_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, grad_table, grad_lin, D, sorted_ids, nnz);
   XDFM_LAUNCH_CHECK();
   return XDFM_OK;
 }

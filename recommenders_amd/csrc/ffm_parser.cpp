@@ -27,19 +27,6 @@
 
 namespace xdfm {
 
-char* error_buffer() {
-  static thread_local char buf[512] = {0};
-  return buf;
-}
-
-int fail(int code, const char* fmt, ...) {
-  va_list ap;
-  va_start(ap, fmt);
-  vsnprintf(error_buffer(), 512, fmt, ap);
-  va_end(ap);
-  return code;
-}
-
 namespace {
 
 // whitespace of Python's str.strip() restricted to ASCII
@@ -187,9 +174,6 @@ struct xdfm_ffm_reader {
   // per-sample scratch: running count per field (reference: dnn_feat_dic, :178-185)
   std::vector<std::pair<int64_t, int64_t>> field_count;
 };
-
-extern "C" int xdfm_abi_version(void) { return XDFM_ABI_VERSION; }
-extern "C" const char* xdfm_last_error(void) { return xdfm::error_buffer(); }
 
 extern "C" int xdfm_ffm_open(const char* path, int64_t field_count, int64_t feature_count,
                              char col_sep, char id_sep, xdfm_ffm_reader** out) {

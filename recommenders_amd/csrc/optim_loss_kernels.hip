@@ -422,20 +422,20 @@ extern "C" int xdfm_dense_update(float* param, const float* grad, float* slot_m,
   }
   float* partial = stats + (size_t)n_seg * 4;
   if (need_stats) {
-    hipLaunchKernelGGL(dense_stats_kernel, dim3(kStatBlocks, n_seg), dim3(256), 0, st, tab, param, grad,
+    XDFM_LAUNCH("dense_stats_kernel", st, dense_stats_kernel, dim3(kStatBlocks, n_seg), dim3(256), 0, tab, param, grad,
                        stats, 0, partial);
-    hipLaunchKernelGGL(dense_stats_final_kernel, dim3(1), dim3(kStatBlocks), 0, st, tab, partial, 0,
+    XDFM_LAUNCH("dense_stats_final_kernel", st, dense_stats_final_kernel, dim3(1), dim3(kStatBlocks), 0, tab, partial, 0,
                        stats, reg_loss, accumulate_reg_loss);
     if (opt->clip_norm > 0.f) {
-      hipLaunchKernelGGL(dense_stats_kernel, dim3(kStatBlocks, n_seg), dim3(256), 0, st, tab, param,
+      XDFM_LAUNCH("dense_stats_kernel", st, dense_stats_kernel, dim3(kStatBlocks, n_seg), dim3(256), 0, tab, param,
                          grad, stats, 1, partial);
-      hipLaunchKernelGGL(dense_stats_final_kernel, dim3(1), dim3(kStatBlocks), 0, st, tab, partial, 1,
+      XDFM_LAUNCH("dense_stats_final_kernel", st, dense_stats_final_kernel, dim3(1), dim3(kStatBlocks), 0, tab, partial, 1,
                          stats, nullptr, 0);
     }
   }
   long long blocks = (total + 255) / 256;
   if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(dense_update_kernel, dim3((unsigned)blocks), dim3(256), 0, st, tab, o, param, grad,
+  XDFM_LAUNCH("dense_update_kernel", st, dense_update_kernel, dim3((unsigned)blocks), dim3(256), 0, tab, o, param, grad,
                      slot_m, slot_v, stats);
   XDFM_LAUNCH_CHECK();
   return XDFM_OK;
@@ -468,9 +468,9 @@ extern "C" int xdfm_logit_loss(const float* part0, const float* part1, const flo
   hipStream_t st = (hipStream_t)stream;
   long long blocks = (B + 255) / 256;
   if (blocks > 1024) blocks = 1024;
-  hipLaunchKernelGGL(loss_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a, scratch);
+  XDFM_LAUNCH("loss_fwd_kernel", st, loss_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, a, scratch);
   if (labels && (g_logit || loss))
-    hipLaunchKernelGGL(loss_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a, scratch,
+    XDFM_LAUNCH("loss_bwd_kernel", st, loss_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, a, scratch,
                        (int)blocks, loss);
   XDFM_LAUNCH_CHECK();
   return XDFM_OK;
@@ -508,20 +508,20 @@ extern "C" int xdfm_eval_auc_logloss(const float* preds, const float* labels, in
   hipStream_t st = (hipStream_t)stream;
   const unsigned blocks = (unsigned)((n + 255) / 256);
   XDFM_HIP(hipMemsetAsync(u2, 0, sizeof(unsigned long long), st));
-  hipLaunchKernelGGL(eval_keys_kernel, dim3(blocks), dim3(256), 0, st, preds, labels, (long long)n,
+  XDFM_LAUNCH("eval_keys_kernel", st, eval_keys_kernel, dim3(blocks), dim3(256), 0, preds, labels, (long long)n,
                      keys_in, pos_in);
   XDFM_HIP(rocprim::radix_sort_pairs(tmp, tmp_bytes, keys_in, keys_out, pos_in, pos_out, (size_t)n, 0u,
                                      32u, st, false));
-  hipLaunchKernelGGL(eval_negflag_kernel, dim3(blocks), dim3(256), 0, st, pos_out, (long long)n, neg);
+  XDFM_LAUNCH("eval_negflag_kernel", st, eval_negflag_kernel, dim3(blocks), dim3(256), 0, pos_out, (long long)n, neg);
   tmp_bytes = L.tmp_bytes;
   XDFM_HIP(rocprim::exclusive_scan(tmp, tmp_bytes, neg, cneg, 0, (size_t)n, rocprim::plus<int32_t>(), st,
                                    false));
-  hipLaunchKernelGGL(eval_total_kernel, dim3(1), dim3(64), 0, st, cneg, neg, (long long)n, cneg + n);
-  hipLaunchKernelGGL(eval_auc_kernel, dim3(blocks), dim3(256), 0, st, keys_out, cneg, (long long)n, u2);
+  XDFM_LAUNCH("eval_total_kernel", st, eval_total_kernel, dim3(1), dim3(64), 0, cneg, neg, (long long)n, cneg + n);
+  XDFM_LAUNCH("eval_auc_kernel", st, eval_auc_kernel, dim3(blocks), dim3(256), 0, keys_out, cneg, (long long)n, u2);
   unsigned lblocks = blocks > 1024 ? 1024 : blocks;
-  hipLaunchKernelGGL(eval_logloss_kernel, dim3(lblocks), dim3(256), 0, st, preds, labels, (long long)n,
+  XDFM_LAUNCH("eval_logloss_kernel", st, eval_logloss_kernel, dim3(lblocks), dim3(256), 0, preds, labels, (long long)n,
                      partial);
-  hipLaunchKernelGGL(eval_final_kernel, dim3(1), dim3(256), 0, st, partial, (int)lblocks, u2, cneg + n,
+  XDFM_LAUNCH("eval_final_kernel", st, eval_final_kernel, dim3(1), dim3(256), 0, partial, (int)lblocks, u2, cneg + n,
                      (long long)n, out);
   XDFM_LAUNCH_CHECK();
   return XDFM_OK;

@@ -1,0 +1,111 @@
+// Host runtime pieces of libxdfm.so shared by every entry point: the per-thread error
+// message and the optional per-kernel timing (HIP events on the launch stream) that
+// bench.py uses for its roofline line.
+#include <hip/hip_runtime_api.h>
+
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "xdfm_common.h"
+
+namespace xdfm {
+
+char* error_buffer() {
+  static thread_local char buf[512] = {0};
+  return buf;
+}
+
+int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(error_buffer(), 512, fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+namespace {
+struct Record {
+  const char* name;
+  hipEvent_t beg, end;
+};
+std::mutex g_mu;
+bool g_on = false;
+std::vector<Record> g_records;
+constexpr size_t kMaxRecords = 1u << 18;
+}  // namespace
+
+ProfScope::ProfScope(const char* name, void* stream) : slot_(-1), stream_(stream) {
+  if (!g_on) return;
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (!g_on || g_records.size() >= kMaxRecords) return;
+  Record r{name, nullptr, nullptr};
+  if (hipEventCreate(&r.beg) != hipSuccess) return;
+  if (hipEventCreate(&r.end) != hipSuccess) {
+    (void)hipEventDestroy(r.beg);
+    return;
+  }
+  (void)hipEventRecord(r.beg, (hipStream_t)stream);
+  slot_ = (long)g_records.size();
+  g_records.push_back(r);
+}
+
+ProfScope::~ProfScope() {
+  if (slot_ < 0) return;
+  std::lock_guard<std::mutex> lk(g_mu);
+  if ((size_t)slot_ < g_records.size()) (void)hipEventRecord(g_records[slot_].end, (hipStream_t)stream_);
+}
+
+}  // namespace xdfm
+
+extern "C" int xdfm_abi_version(void) { return XDFM_ABI_VERSION; }
+extern "C" const char* xdfm_last_error(void) { return xdfm::error_buffer(); }
+
+extern "C" int xdfm_prof_enable(int32_t on) {
+  std::lock_guard<std::mutex> lk(xdfm::g_mu);
+  xdfm::g_on = on != 0;
+  return XDFM_OK;
+}
+
+extern "C" int xdfm_prof_collect(char* json, size_t cap) {
+  XDFM_REQUIRE(json && cap >= 64, "xdfm_prof_collect: buffer too small");
+  std::vector<xdfm::Record> recs;
+  {
+    std::lock_guard<std::mutex> lk(xdfm::g_mu);
+    recs.swap(xdfm::g_records);
+  }
+  struct Agg {
+    double ms = 0;
+    long n = 0;
+  };
+  std::map<std::string, Agg> agg;
+  int rc = XDFM_OK;
+  for (auto& r : recs) {
+    float ms = 0.f;
+    hipError_t e = hipEventSynchronize(r.end);
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, r.beg, r.end);
+    if (e == hipSuccess) {
+      Agg& a = agg[r.name];
+      a.ms += ms;
+      a.n += 1;
+    } else {
+      rc = xdfm::fail(XDFM_E_HIP, "xdfm_prof_collect: %s", hipGetErrorString(e));
+    }
+    (void)hipEventDestroy(r.beg);
+    (void)hipEventDestroy(r.end);
+  }
+  std::string out = "{";
+  bool first = true;
+  for (auto& kv : agg) {
+    char line[256];
+    snprintf(line, sizeof(line), "%s\"%s\": {\"ms\": %.6f, \"n\": %ld}", first ? "" : ", ",
+             kv.first.c_str(), kv.second.ms, kv.second.n);
+    out += line;
+    first = false;
+  }
+  out += "}";
+  if (out.size() + 1 > cap) return xdfm::fail(XDFM_E_WORKSPACE, "xdfm_prof_collect: need %zu bytes", out.size() + 1);
+  memcpy(json, out.c_str(), out.size() + 1);
+  return rc;
+}

@@ -12,7 +12,28 @@ namespace xdfm {
 char* error_buffer();
 int fail(int code, const char* fmt, ...);
 
+// Times everything enqueued on `stream` during its lifetime when xdfm_prof_enable(1) is on
+// (two HIP events); otherwise a no-op.  The name is the kernel's (as rocprofv3 prints it).
+class ProfScope {
+ public:
+  ProfScope(const char* name, void* stream);
+  ~ProfScope();
+  ProfScope(const ProfScope&) = delete;
+  ProfScope& operator=(const ProfScope&) = delete;
+
+ private:
+  long slot_;
+  void* stream_;
+};
+
 }  // namespace xdfm
+
+// launch `kernel` under a timing scope named after it
+#define XDFM_LAUNCH(name, stream, kernel, grid, block, lds, ...)                            \
+  do {                                                                                      \
+    xdfm::ProfScope prof_scope_(name, (void*)(stream));                                     \
+    hipLaunchKernelGGL(kernel, grid, block, lds, (hipStream_t)(stream), __VA_ARGS__);       \
+  } while (0)
 
 #define XDFM_REQUIRE(cond, ...)                              \
   do {                                                       \
