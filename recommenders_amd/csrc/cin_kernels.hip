@@ -17,18 +17,16 @@
 // Layouts: x0[B][F][D], xk[B][H][D], w[F*H][L], xnext[B][n_hidden][D], pooled[B][stride].
 #include <hip/hip_runtime.h>
 
+#include "cin_common.h"
 #include "xdfm_common.h"
+
+using xdfm_cin::CinDims;
 
 namespace {
 
 constexpr int kThreads = 256;
 constexpr int kPad = 16;  // LDS row = blockDim + kPad floats: staging writes of 2 h-rows hit disjoint banks
 constexpr int kMaxSplits = 256;
-
-struct CinDims {
-  int64_t B;
-  int F, H, D, L, n_hidden, masked;
-};
 
 // stage src[b0 .. b0+nb)[R][D] into lds[r * Tp + bl*D + d]
 __device__ __forceinline__ void stage_tile(const float* __restrict__ src, int64_t b0, int nb, int R,
@@ -349,6 +347,10 @@ extern "C" int xdfm_cin_fwd(const float* x0, const float* xk, const float* w, in
   XDFM_REQUIRE(n_hidden == 0 || xnext, "xdfm_cin_fwd: xnext is null");
   XDFM_REQUIRE(n_hidden == L || pooled, "xdfm_cin_fwd: pooled is null");
   if (B == 0) return XDFM_OK;
+  if (xdfm_cin::mfma_supported(B, F, H, D, L)) {
+    CinDims cm{B, F, H, D, L, n_hidden, masked};
+    return xdfm_cin::fwd_mfma(cm, x0, xk, w, xnext, pooled, pool_stride, pool_off, (hipStream_t)stream);
+  }
   const int nch = pick_nch(L);
   const int rows = (xk == x0) ? H : H + F;
   int threads, spb;
@@ -371,6 +373,10 @@ extern "C" int xdfm_cin_bwd_workspace_floats(int64_t B, int32_t F, int32_t H, in
                "xdfm_cin_bwd_workspace_floats: bad argument");
   const int SUB = (64 / D) > 0 ? (64 / D) : 1;
   *floats = (size_t)B * D * L + (size_t)splits_for(B, SUB) * F * H * L;
+  if (xdfm_cin::mfma_supported(B, F, H, D, L)) {
+    const size_t m = xdfm_cin::bwd_mfma_workspace_floats(B, F, H, D, L, 0);
+    if (m > *floats) *floats = m;
+  }
   return XDFM_OK;
 }
 
@@ -392,6 +398,9 @@ extern "C" int xdfm_cin_bwd(const float* x0, const float* xk, const float* w, in
     XDFM_HIP(hipMemsetAsync(d_w, 0, (size_t)F * H * L * sizeof(float), st));
     return XDFM_OK;
   }
+  if (xdfm_cin::mfma_supported(B, F, H, D, L))
+    return xdfm_cin::bwd_mfma(c, x0, xk, w, d_xnext, d_pooled, pool_stride, pool_off, d_xk, d_x0, d_w,
+                              dw_part, st);
   float* dc_mn = dw_part;
   float* part = dw_part + (size_t)B * D * L;
   {

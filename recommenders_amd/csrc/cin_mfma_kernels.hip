@@ -1,0 +1,650 @@
+// Compressed Interaction Network on the fp32 matrix cores of gfx950
+// (v_mfma_f32_16x16x4_f32: exact fp32, bitwise a k-ordered fmaf chain).
+//
+// Reference: recommenders/models/deeprec/models/xDeepFM.py:191-267.  The reference
+// materialises Z[b,d,f*H+h] = X0[b,f,d]*Xk[b,h,d] (:192-200), masks layer 0 (:208-217) and
+// runs a width-1 conv1d = GEMM over the pair index (:220-222).  Here Z is an MFMA operand
+// that is formed in registers (one v_mul per operand) from LDS-resident X tiles and never
+// stored.  With m = (sample, d) the three contractions are
+//
+//   forward   curr[m,n]   = sum_p  Z[m,p] W[p,n]          M = rows,  N = channels, K = pairs
+//   d-input   T[m,p]      = sum_n  dcurr[m,n] W[p,n]      M = rows,  N = pairs,    K = channels
+//             dXk[m,h]    = sum_f  X0[m,f] T[m,(f,h)] ,  dX0[m,f] = sum_h Xk[m,h] T[m,(f,h)]
+//   d-filter  dW[p,n]     = sum_m  Z[m,p] dcurr[m,n]      M = pairs, N = channels, K = rows
+//
+// Pairs of the masked layer 0 (f >= h) are never computed.  All sums have a fixed
+// association (no float atomics): results are bit-identical from run to run.
+//
+// Layouts: x0[B][F][D], xk[B][H][D], w[F*H][L], xnext[B][n_hidden][D], pooled[B][stride],
+// dc_mn[B*D][L] (upstream gradient of curr in row-major (m, n) order).
+#include <hip/hip_runtime.h>
+
+#include "cin_common.h"
+#include "xdfm_common.h"
+
+namespace xdfm_cin {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int kPad = 16;  // LDS row stride = rows + 16 floats: the four k-groups of a wave hit disjoint banks
+
+__device__ __forceinline__ f32x4 mfma(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// k-th valid pair -> (f, h); the masked layer enumerates f < h only, f-major
+__device__ __forceinline__ void pair_of(int q, int H, int masked, int* f, int* h) {
+  if (!masked) {
+    *f = q / H;
+    *h = q - *f * H;
+    return;
+  }
+  int ff = 0, rem = q;
+  while (rem >= H - 1 - ff) {
+    rem -= H - 1 - ff;
+    ++ff;
+  }
+  *f = ff;
+  *h = ff + 1 + rem;
+}
+
+// stage src[b0 .. b0+nb)[R][D] transposed into lds[r * Tp + bl*D + d]; rows R..Rpad are zero
+__device__ __forceinline__ void stage_cols(const float* __restrict__ src, int64_t b0, int nb, int R,
+                                           int Rpad, int D, float* lds, int Tp) {
+  const int total = nb * R * D;
+  const float* base = src + b0 * R * D;
+  for (int idx = threadIdx.x; idx < total; idx += blockDim.x) {
+    const int bl = idx / (R * D);
+    const int rem = idx - bl * R * D;
+    const int r = rem / D;
+    const int d = rem - r * D;
+    lds[r * Tp + bl * D + d] = base[idx];
+  }
+  // padding rows (feature index >= R) and padding columns (row >= nb*D) must read as zero
+  const int cols = nb * D;
+  for (int idx = threadIdx.x; idx < (Rpad - R) * Tp; idx += blockDim.x) lds[R * Tp + idx] = 0.f;
+  const int padc = Tp - cols;
+  for (int idx = threadIdx.x; idx < R * padc; idx += blockDim.x) {
+    const int r = idx / padc;
+    lds[r * Tp + cols + (idx - r * padc)] = 0.f;
+  }
+}
+
+// ------------------------------------------------------------------------ forward
+// Block = 4 waves; a wave owns RT row tiles of 16 rows; NT channel tiles of 16 per block.
+// A[i=row][k=pair] = x0[f_k][row] * xk[h_k][row]   (lane: i = lane&15, k = lane>>4)
+// B[k=pair][j=ch]  = w[pair_k][c0 + j]             (lane: j = lane&15, k = lane>>4), from L1/L2
+template <int NT, int RT>
+__global__ __launch_bounds__(256) void cin_fwd_mfma_kernel(
+    CinDims c, const float* __restrict__ x0, const float* __restrict__ xk,
+    const float* __restrict__ w, float* __restrict__ xnext, float* __restrict__ pooled,
+    int pool_stride, int pool_off, int SPB, int P, int lds_rows) {
+  extern __shared__ float lds[];
+  constexpr int ROWS = 64 * RT;
+  constexpr int Tp = ROWS + kPad;
+  const bool shared_x = (xk == x0);
+  float* xs = lds;
+  float* as = shared_x ? xs : lds + c.H * Tp;
+  int* ptab = reinterpret_cast<int*>(lds + lds_rows * Tp);
+  const int Ppad = (P + 3) & ~3;
+
+  const int64_t b0 = (int64_t)blockIdx.x * SPB;
+  const int nb = (int)((c.B - b0 < SPB) ? (c.B - b0) : SPB);
+  stage_cols(xk, b0, nb, c.H, c.H, c.D, xs, Tp);
+  if (!shared_x) stage_cols(x0, b0, nb, c.F, c.F, c.D, as, Tp);
+  for (int k = threadIdx.x; k < Ppad; k += blockDim.x) {
+    int f = 0, h = 0;
+    if (k < P) pair_of(k, c.H, c.masked, &f, &h);
+    ptab[k] = (k < P) ? (f | (h << 16)) : -1;
+  }
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = lane & 15, kk = lane >> 4;
+  const int c0 = blockIdx.y * (NT * 16);
+  const int rbase = wave * (16 * RT) + i;  // + 16*rt
+
+  f32x4 acc[RT][NT];
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[rt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // software pipeline: the filter values of step s+1 are in flight while step s multiplies
+  int pt = ptab[kk];
+  float bv[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int ch = c0 + nt * 16 + i;
+    const int f = pt & 0xffff, h = pt >> 16;
+    bv[nt] = (pt >= 0 && ch < c.L) ? w[(int64_t)(f * c.H + h) * c.L + ch] : 0.f;
+  }
+#pragma unroll 2
+  for (int k0 = 0; k0 < Ppad; k0 += 4) {
+    const int f = (pt >= 0) ? (pt & 0xffff) : 0, h = (pt >= 0) ? (pt >> 16) : 0;
+    const int kn = k0 + 4;
+    const int pt_n = (kn < Ppad) ? ptab[kn + kk] : -1;
+    float bn[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int ch = c0 + nt * 16 + i;
+      const int fn = pt_n & 0xffff, hn = pt_n >> 16;
+      bn[nt] = (pt_n >= 0 && ch < c.L) ? w[(int64_t)(fn * c.H + hn) * c.L + ch] : 0.f;
+    }
+    const float* ap = as + f * Tp + rbase;
+    const float* xp = xs + h * Tp + rbase;
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+      const float a = ap[16 * rt] * xp[16 * rt];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[rt][nt] = mfma(a, bv[nt], acc[rt][nt]);
+    }
+    pt = pt_n;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) bv[nt] = bn[nt];
+  }
+
+  // epilogue: transpose through LDS so that the global stores run along d
+  const float scale = c.masked ? 2.f : 1.f;  // exact, so applying it last changes no bit
+  __syncthreads();                           // everyone is done with the X tiles
+  float* out = lds;                          // [NT*16][Tp]
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        out[(nt * 16 + i) * Tp + wave * (16 * RT) + rt * 16 + kk * 4 + r] = acc[rt][nt][r] * scale;
+  __syncthreads();
+  const int cols = nb * c.D;
+  int nch = c.L - c0;
+  if (nch > NT * 16) nch = NT * 16;
+  for (int idx = threadIdx.x; idx < nch * cols; idx += blockDim.x) {
+    const int ch = idx / cols;
+    const int rl = idx - ch * cols;
+    const int g = c0 + ch;
+    if (g < c.n_hidden) {
+      const int bl = rl / c.D, d = rl - bl * c.D;
+      xnext[((b0 + bl) * c.n_hidden + g) * c.D + d] = out[ch * Tp + rl];
+    }
+  }
+  for (int idx = threadIdx.x; idx < nch * nb; idx += blockDim.x) {
+    const int ch = idx / nb;
+    const int bl = idx - ch * nb;
+    const int g = c0 + ch;
+    if (g >= c.n_hidden) {
+      float s = 0.f;
+      for (int d = 0; d < c.D; ++d) s += out[ch * Tp + bl * c.D + d];  // reduce_sum over D (:270)
+      pooled[(b0 + bl) * pool_stride + pool_off + g - c.n_hidden] = s;
+    }
+  }
+}
+
+// ---------------------------------------------------------------- input gradients
+// Block = 4 waves x 16 rows.  Pair tile = 4 f x 4 h (lane&15 = fi*4 + hi).
+// A[i=row][k=ch] = dcurr[row][4s+k]   (registers, SMAX steps)
+// B[k=ch][j=pair] = w[(f,h)][4s+k]    (LDS copy of the four filter rows-of-h of this f tile,
+//                                      invalid pairs staged as zeros)
+// D[row=(lane>>4)*4+r][pair=lane&15] = T
+template <int NHT, int SMAX>
+__global__ __launch_bounds__(256) void cin_bwd_dx_mfma_kernel(
+    CinDims c, const float* __restrict__ x0, const float* __restrict__ xk,
+    const float* __restrict__ w, const float* __restrict__ dc_mn, float* d_xk, float* d_x0,
+    int SPB, int Lp) {
+  extern __shared__ float lds[];
+  constexpr int ROWS = 64;
+  constexpr int Tp = ROWS + kPad;
+  const bool shared_x = (xk == x0);
+  const int Hp = (c.H + 3) & ~3, Fp = (c.F + 3) & ~3;
+  const int nht = Hp >> 2, nft = Fp >> 2;
+  float* xs = lds;                                   // [Hp][Tp]
+  float* as = shared_x ? xs : xs + Hp * Tp;          // [Fp][Tp]
+  float* dxk_s = as + Fp * Tp;                       // [Hp][Tp]
+  float* dx0_s = dxk_s + Hp * Tp;                    // [Fp][Tp]
+  float* wst = dx0_s + Fp * Tp;                      // [4][Hp][Lp]
+
+  const int64_t b0 = (int64_t)blockIdx.x * SPB;
+  const int nb = (int)((c.B - b0 < SPB) ? (c.B - b0) : SPB);
+  const int cols = nb * c.D;
+  stage_cols(xk, b0, nb, c.H, Hp, c.D, xs, Tp);
+  if (!shared_x) stage_cols(x0, b0, nb, c.F, Fp, c.D, as, Tp);
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane & 15, kk = lane >> 4;
+  const int fi = j >> 2, hi = j & 3;
+  const int S = (c.L + 3) >> 2;
+  // A operands: this lane's row (for the A role: row = lane&15) and channels 4s + kk
+  float dcA[SMAX];
+  {
+    const int rl = wave * 16 + j;
+    const int64_t m = b0 * c.D + rl;
+#pragma unroll
+    for (int s = 0; s < SMAX; ++s) {
+      const int ch = 4 * s + kk;
+      dcA[s] = (s < S && rl < cols && ch < c.L) ? dc_mn[m * c.L + ch] : 0.f;
+    }
+  }
+  const int rrow = wave * 16 + kk * 4;  // first of this lane's 4 result rows
+  f32x4 accK[NHT];
+#pragma unroll
+  for (int ht = 0; ht < NHT; ++ht) accK[ht] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  for (int ft = 0; ft < nft; ++ft) {
+    __syncthreads();  // previous tile row is done with wst (and the X tiles are staged)
+    {
+      // stage w[(f, h), n] for f = 4ft .. 4ft+3 -> wst[fi][h][n], zeros where the pair is not valid
+      const int per_f = Hp * Lp;
+      for (int idx = threadIdx.x; idx < 4 * per_f; idx += blockDim.x) {
+        const int ff = idx / per_f;
+        const int rem = idx - ff * per_f;
+        const int h = rem / Lp;
+        const int n = rem - h * Lp;
+        const int f = 4 * ft + ff;
+        const bool ok = f < c.F && h < c.H && n < c.L && (!c.masked || h > f);
+        wst[idx] = ok ? w[(int64_t)(f * c.H + h) * c.L + n] : 0.f;
+      }
+    }
+    __syncthreads();
+    const f32x4 a0 = *reinterpret_cast<const f32x4*>(as + (4 * ft + fi) * Tp + rrow);
+    f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int ht_begin = c.masked ? ft : 0;
+    const float* wl = wst + (fi * Hp + hi) * Lp + kk;
+#pragma unroll
+    for (int ht = 0; ht < NHT; ++ht) {
+      if (ht >= ht_begin && ht < nht) {
+        f32x4 T = f32x4{0.f, 0.f, 0.f, 0.f};
+        const float* wp = wl + 4 * ht * Lp;
+#pragma unroll
+        for (int s = 0; s < SMAX; ++s)
+          if (s < S) T = mfma(dcA[s], wp[4 * s], T);
+        const f32x4 xv = *reinterpret_cast<const f32x4*>(xs + (4 * ht + hi) * Tp + rrow);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          acc0[r] = fmaf(xv[r], T[r], acc0[r]);
+          accK[ht][r] = fmaf(a0[r], T[r], accK[ht][r]);
+        }
+      }
+    }
+    // dX0[rows][4ft+fi] = sum over hi (the 4 lanes of a quad), fixed order
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float v = acc0[r];
+      v += __shfl_xor(v, 1);
+      v += __shfl_xor(v, 2);
+      acc0[r] = v;
+    }
+    if (hi == 0) *reinterpret_cast<f32x4*>(dx0_s + (4 * ft + fi) * Tp + rrow) = acc0;
+  }
+  // dXk[rows][4ht+hi] = sum over fi (lanes j, j+4, j+8, j+12), fixed order
+#pragma unroll
+  for (int ht = 0; ht < NHT; ++ht) {
+    if (ht < nht) {
+      f32x4 v = accK[ht];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float t = v[r];
+        t += __shfl_down(t, 8, 16);
+        t += __shfl_down(t, 4, 16);
+        v[r] = t;
+      }
+      if (fi == 0) *reinterpret_cast<f32x4*>(dxk_s + (4 * ht + hi) * Tp + rrow) = v;
+    }
+  }
+  __syncthreads();
+  const float scale = c.masked ? 2.f : 1.f;
+  // d_x0[b][f][d] += ... ; layer 0 (xk == x0): both roles go to d_x0
+  {
+    const int total = nb * c.F * c.D;
+    float* base = d_x0 + b0 * c.F * c.D;
+    for (int idx = threadIdx.x; idx < total; idx += blockDim.x) {
+      const int bl = idx / (c.F * c.D);
+      const int rem = idx - bl * c.F * c.D;
+      const int f = rem / c.D;
+      const int d = rem - f * c.D;
+      float v = dx0_s[f * Tp + bl * c.D + d];
+      if (shared_x) v += dxk_s[f * Tp + bl * c.D + d];
+      base[idx] += v * scale;
+    }
+  }
+  if (!shared_x) {
+    const int total = nb * c.H * c.D;
+    float* base = d_xk + b0 * c.H * c.D;
+    for (int idx = threadIdx.x; idx < total; idx += blockDim.x) {
+      const int bl = idx / (c.H * c.D);
+      const int rem = idx - bl * c.H * c.D;
+      const int h = rem / c.D;
+      const int d = rem - h * c.D;
+      base[idx] = dxk_s[h * Tp + bl * c.D + d] * scale;
+    }
+  }
+}
+
+// ----------------------------------------------------------------- filter gradient
+// tile t -> (ft, ht); the masked layer enumerates ht >= ft only, ft-major
+__host__ __device__ inline int n_tiles(int nft, int nht, int masked) {
+  return masked ? nft * (nft + 1) / 2 : nft * nht;
+}
+__host__ __device__ inline void tile_of(int t, int nft, int nht, int masked, int* ft, int* ht) {
+  if (!masked) {
+    *ft = t / nht;
+    *ht = t - *ft * nht;
+    return;
+  }
+  int f = 0, rem = t;
+  while (rem >= nft - f) {
+    rem -= nft - f;
+    ++f;
+  }
+  *ft = f;
+  *ht = f + rem;
+}
+__host__ __device__ inline int tile_index(int ft, int ht, int nft, int nht, int masked) {
+  if (!masked) return ft * nht + ht;
+  return ft * nft - ft * (ft - 1) / 2 + (ht - ft);
+}
+
+// Block = 4 waves sharing RC rows at a time; wave w owns PT pair tiles.
+// A[i=pair][k=row] = x0[row][f_i] * xk[row][h_i]   (LDS, [row][feature] layout)
+// B[k=row][j=ch]   = dcurr[row][c0 + j]            (global)
+// D[pair=(lane>>4)*4+r][ch=lane&15]
+template <int PT, int NT>
+__global__ __launch_bounds__(256) void cin_bwd_dw_mfma_kernel(
+    CinDims c, const float* __restrict__ x0, const float* __restrict__ xk,
+    const float* __restrict__ dc_mn, int64_t rows_total, int rows_per_split,
+    float* __restrict__ part) {
+  extern __shared__ float lds[];
+  constexpr int RC = 64;
+  const bool shared_x = (xk == x0);
+  const int Hp = (c.H + 3) & ~3, Fp = (c.F + 3) & ~3;
+  const int nht = Hp >> 2, nft = Fp >> 2;
+  const int Hs = Hp | 1, Fs = Fp | 1;  // odd strides: the 8 addresses of a k-group pair hit 8 banks
+  float* xs = lds;                     // [RC][Hs]
+  float* as = shared_x ? xs : lds + RC * Hs;  // [RC][Fs]
+  const int ntile = n_tiles(nft, nht, c.masked);
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane & 15, kk = lane >> 4;
+  const int fi = j >> 2, hi = j & 3;
+  const int c0 = blockIdx.z * (NT * 16);
+  const int t0 = (blockIdx.y * 4 + wave) * PT;
+  int foff[PT], hoff[PT];
+#pragma unroll
+  for (int p = 0; p < PT; ++p) {
+    int ft = 0, ht = 0;
+    if (t0 + p < ntile) tile_of(t0 + p, nft, nht, c.masked, &ft, &ht);
+    foff[p] = 4 * ft + fi;
+    hoff[p] = 4 * ht + hi;
+  }
+  f32x4 acc[PT][NT];
+#pragma unroll
+  for (int p = 0; p < PT; ++p)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[p][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int64_t r_beg = (int64_t)blockIdx.x * rows_per_split;
+  int64_t r_end = r_beg + rows_per_split;
+  if (r_end > rows_total) r_end = rows_total;
+  const int HD = c.H * c.D, FD = c.F * c.D;
+  for (int64_t r0 = r_beg; r0 < r_end; r0 += RC) {
+    const int nr = (int)((r_end - r0 < RC) ? (r_end - r0) : RC);
+    __syncthreads();
+    // [row][h] <- xk[b][h][d] with row = b*D + d; unused cells are zero
+    for (int idx = threadIdx.x; idx < RC * Hp; idx += blockDim.x) {
+      const int h = idx / RC;  // consecutive threads walk rows (d fastest): coalesced reads
+      const int rl = idx - h * RC;
+      float v = 0.f;
+      if (rl < nr && h < c.H) {
+        const int64_t m = r0 + rl;
+        const int64_t b = m / c.D;
+        const int d = (int)(m - b * c.D);
+        v = xk[b * HD + h * c.D + d];
+      }
+      xs[rl * Hs + h] = v;
+    }
+    if (!shared_x) {
+      for (int idx = threadIdx.x; idx < RC * Fp; idx += blockDim.x) {
+        const int f = idx / RC;
+        const int rl = idx - f * RC;
+        float v = 0.f;
+        if (rl < nr && f < c.F) {
+          const int64_t m = r0 + rl;
+          const int64_t b = m / c.D;
+          const int d = (int)(m - b * c.D);
+          v = x0[b * FD + f * c.D + d];
+        }
+        as[rl * Fs + f] = v;
+      }
+    }
+    __syncthreads();
+    if (t0 < ntile) {
+      float bv[NT];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int ch = c0 + nt * 16 + j;
+        bv[nt] = (kk < nr && ch < c.L) ? dc_mn[(r0 + kk) * c.L + ch] : 0.f;
+      }
+#pragma unroll 2
+      for (int ks = 0; ks < RC; ks += 4) {
+        const int rl = ks + kk;
+        float bn[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          const int ch = c0 + nt * 16 + j;
+          const int rn = rl + 4;
+          bn[nt] = (ks + 4 < RC && rn < nr && ch < c.L) ? dc_mn[(r0 + rn) * c.L + ch] : 0.f;
+        }
+        const float* ar = as + rl * Fs;
+        const float* xr = xs + rl * Hs;
+#pragma unroll
+        for (int p = 0; p < PT; ++p) {
+          const float a = ar[foff[p]] * xr[hoff[p]];
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) acc[p][nt] = mfma(a, bv[nt], acc[p][nt]);
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) bv[nt] = bn[nt];
+      }
+    }
+  }
+  // part[split][tile*16 + pair][L]
+#pragma unroll
+  for (int p = 0; p < PT; ++p) {
+    if (t0 + p < ntile) {
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int ch = c0 + nt * 16 + j;
+        if (ch < c.L) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int64_t slot = (int64_t)blockIdx.x * ntile * 16 + (int64_t)(t0 + p) * 16 + kk * 4 + r;
+            part[slot * c.L + ch] = acc[p][nt][r];
+          }
+        }
+      }
+    }
+  }
+}
+
+// d_w[(f,h), n] = scale * sum over splits, in split order; masked pairs get 0
+__global__ void cin_dw_unpack_kernel(CinDims c, const float* __restrict__ part, int n_splits,
+                                     float* __restrict__ d_w) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t total = (int64_t)c.F * c.H * c.L;
+  if (idx >= total) return;
+  const int p = (int)(idx / c.L);
+  const int n = (int)(idx - (int64_t)p * c.L);
+  const int f = p / c.H, h = p - f * c.H;
+  const int nft = (c.F + 3) >> 2, nht = (c.H + 3) >> 2;
+  float s = 0.f;
+  if (!(c.masked && h <= f)) {
+    const int t = tile_index(f >> 2, h >> 2, nft, nht, c.masked);
+    const int ntile = n_tiles(nft, nht, c.masked);
+    const int64_t slot = (int64_t)t * 16 + (f & 3) * 4 + (h & 3);
+    const int64_t stride = (int64_t)ntile * 16 * c.L;
+    const float* src = part + slot * c.L + n;
+    for (int k = 0; k < n_splits; ++k) s += src[k * stride];
+  }
+  d_w[idx] = s * (c.masked ? 2.f : 1.f);
+}
+
+// upstream gradient of curr in [m][L] order (m = b*D+d)
+__global__ void cin_dcurr_kernel(CinDims c, const float* __restrict__ d_xnext,
+                                 const float* __restrict__ d_pooled, int pool_stride, int pool_off,
+                                 float* __restrict__ dc_mn) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t total = c.B * c.D * c.L;
+  if (idx >= total) return;
+  const int64_t m = idx / c.L;
+  const int n = (int)(idx - m * c.L);
+  const int64_t b = m / c.D;
+  const int d = (int)(m - b * c.D);
+  dc_mn[idx] = (n < c.n_hidden) ? d_xnext[(b * c.n_hidden + n) * c.D + d]
+                                : d_pooled[b * pool_stride + pool_off + n - c.n_hidden];
+}
+
+constexpr size_t kLdsLimit = 160 * 1024;
+
+template <typename K>
+int allow_lds(K kernel, size_t bytes) {
+  if (bytes > 64 * 1024)
+    XDFM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+  return XDFM_OK;
+}
+
+int dw_splits(int64_t rows) {
+  int64_t s = (rows + 511) / 512;
+  return (int)(s < 1 ? 1 : (s > 256 ? 256 : s));
+}
+
+}  // namespace
+
+bool mfma_supported(int64_t B, int F, int H, int D, int L) {
+  if (D > 64 || F > 128 || H > 128 || F < 1 || H < 1) return false;
+  const int Hp = (H + 3) & ~3, Fp = (F + 3) & ~3;
+  const int S = (L + 3) / 4;
+  if (S > 64) return false;
+  const int Lp = 4 * S + 1;
+  const size_t dx_lds = ((size_t)(2 * Hp + 2 * Fp) * (64 + kPad) + (size_t)4 * Hp * Lp) * sizeof(float);
+  if (dx_lds > kLdsLimit) return false;
+  (void)B;
+  return true;
+}
+
+int fwd_mfma(const CinDims& c, const float* x0, const float* xk, const float* w, float* xnext,
+             float* pooled, int pool_stride, int pool_off, hipStream_t st) {
+  constexpr int RT = 4;
+  constexpr int ROWS = 64 * RT;
+  const int SPB = ROWS / c.D;
+  const int P = c.masked ? c.F * (c.F - 1) / 2 : c.F * c.H;
+  const int Ppad = (P + 3) & ~3;
+  const int nt_total = (c.L + 15) / 16;
+  const int NT = nt_total >= 4 ? 4 : (nt_total >= 2 ? 2 : 1);
+  int lds_rows = (xk == x0) ? c.H : c.H + c.F;
+  if (lds_rows < NT * 16) lds_rows = NT * 16;
+  const size_t lds_bytes = (size_t)lds_rows * (ROWS + kPad) * sizeof(float) + (size_t)(Ppad + 4) * sizeof(int);
+  XDFM_REQUIRE(lds_bytes <= kLdsLimit, "xdfm_cin_fwd: tile does not fit the LDS");
+  dim3 grid((unsigned)((c.B + SPB - 1) / SPB), (unsigned)((nt_total + NT - 1) / NT));
+#define CALL(N)                                                                                   \
+  do {                                                                                            \
+    int rc = allow_lds(cin_fwd_mfma_kernel<N, RT>, lds_bytes);                                    \
+    if (rc) return rc;                                                                            \
+    XDFM_LAUNCH("cin_fwd_mfma_kernel<" #N ", 4>", st, (cin_fwd_mfma_kernel<N, RT>), grid, dim3(256), \
+                lds_bytes, c, x0, xk, w, xnext, pooled, pool_stride, pool_off, SPB, P, lds_rows); \
+  } while (0)
+  if (NT == 4)
+    CALL(4);
+  else if (NT == 2)
+    CALL(2);
+  else
+    CALL(1);
+#undef CALL
+  XDFM_LAUNCH_CHECK();
+  return XDFM_OK;
+}
+
+size_t bwd_mfma_workspace_floats(int64_t B, int F, int H, int D, int L, int masked) {
+  const int nft = (F + 3) / 4, nht = (H + 3) / 4;
+  const int ntile = n_tiles(nft, nht, masked);
+  return (size_t)B * D * L + (size_t)dw_splits(B * D) * ntile * 16 * L;
+}
+
+int bwd_mfma(const CinDims& c, const float* x0, const float* xk, const float* w,
+             const float* d_xnext, const float* d_pooled, int pool_stride, int pool_off, float* d_xk,
+             float* d_x0, float* d_w, float* ws, hipStream_t st) {
+  float* dc_mn = ws;
+  float* part = ws + (size_t)c.B * c.D * c.L;
+  {
+    const int64_t total = c.B * c.D * c.L;
+    XDFM_LAUNCH("cin_dcurr_kernel", st, cin_dcurr_kernel, dim3((unsigned)((total + 255) / 256)),
+                dim3(256), 0, c, d_xnext, d_pooled, pool_stride, pool_off, dc_mn);
+  }
+  const int Hp = (c.H + 3) & ~3, Fp = (c.F + 3) & ~3;
+  const int nht = Hp / 4, nft = Fp / 4;
+  const int S = (c.L + 3) / 4;
+  const bool shared_x = (xk == x0);
+  // ---- input gradients
+  {
+    const int SPB = 64 / c.D;
+    const int Lp = 4 * S + 1;
+    const size_t lds_bytes =
+        ((size_t)((shared_x ? 2 : 2) * Hp + (shared_x ? 1 : 2) * Fp) * (64 + kPad) + (size_t)4 * Hp * Lp) *
+        sizeof(float);
+    dim3 grid((unsigned)((c.B + SPB - 1) / SPB));
+#define CALL(NH, SM)                                                                               \
+  do {                                                                                             \
+    int rc = allow_lds(cin_bwd_dx_mfma_kernel<NH, SM>, lds_bytes);                                 \
+    if (rc) return rc;                                                                             \
+    XDFM_LAUNCH("cin_bwd_dx_mfma_kernel<" #NH ", " #SM ">", st, (cin_bwd_dx_mfma_kernel<NH, SM>),  \
+                grid, dim3(256), lds_bytes, c, x0, xk, w, dc_mn, d_xk, d_x0, SPB, Lp);             \
+  } while (0)
+#define BY_S(NH)        \
+  do {                  \
+    if (S <= 3)         \
+      CALL(NH, 3);      \
+    else if (S <= 5)    \
+      CALL(NH, 5);      \
+    else if (S <= 16)   \
+      CALL(NH, 16);     \
+    else                \
+      CALL(NH, 64);     \
+  } while (0)
+    if (nht <= 3)
+      BY_S(3);
+    else if (nht <= 10)
+      BY_S(10);
+    else
+      BY_S(32);
+#undef BY_S
+#undef CALL
+  }
+  // ---- filter gradient
+  {
+    const int64_t rows = c.B * c.D;
+    const int n_splits = dw_splits(rows);
+    const int rows_per_split = (int)((rows + n_splits - 1) / n_splits);
+    const int ntile = n_tiles(nft, nht, c.masked);
+    const int nt_total = (c.L + 15) / 16;
+    const int NT = nt_total >= 2 ? 2 : 1;
+    constexpr int PT = 8;
+    const size_t lds_bytes = (size_t)64 * ((Hp | 1) + (shared_x ? 0 : (Fp | 1))) * sizeof(float);
+    dim3 grid((unsigned)n_splits, (unsigned)((ntile + 4 * PT - 1) / (4 * PT)),
+              (unsigned)((nt_total + NT - 1) / NT));
+    if (NT == 2) {
+      XDFM_LAUNCH("cin_bwd_dw_mfma_kernel<8, 2>", st, (cin_bwd_dw_mfma_kernel<PT, 2>), grid, dim3(256),
+                  lds_bytes, c, x0, xk, dc_mn, rows, rows_per_split, part);
+    } else {
+      XDFM_LAUNCH("cin_bwd_dw_mfma_kernel<8, 1>", st, (cin_bwd_dw_mfma_kernel<PT, 1>), grid, dim3(256),
+                  lds_bytes, c, x0, xk, dc_mn, rows, rows_per_split, part);
+    }
+    const int64_t total = (int64_t)c.F * c.H * c.L;
+    XDFM_LAUNCH("cin_dw_unpack_kernel", st, cin_dw_unpack_kernel, dim3((unsigned)((total + 255) / 256)),
+                dim3(256), 0, c, part, n_splits, d_w);
+  }
+  XDFM_LAUNCH_CHECK();
+  return XDFM_OK;
+}
+
+}  // namespace xdfm_cin
