@@ -50,23 +50,63 @@ __device__ __forceinline__ void pair_of(int q, int H, int masked, int* f, int* h
   *h = ff + 1 + rem;
 }
 
-// stage src[b0 .. b0+nb)[R][D] transposed into lds[r * Tp + bl*D + d]; rows R..Rpad are zero
+// stage src[b0 .. b0+nb)[R][D] transposed into lds[r * Tp + bl*D + d]; rows R..Rpad are zero.
+// Four loads per thread are in flight before the first LDS write (the tile is read once, so
+// this loop runs at memory latency unless it keeps several requests outstanding).
 __device__ __forceinline__ void stage_cols(const float* __restrict__ src, int64_t b0, int nb, int R,
                                            int Rpad, int D, float* lds, int Tp) {
-  const int total = nb * R * D;
   const float* base = src + b0 * R * D;
-  for (int idx = threadIdx.x; idx < total; idx += blockDim.x) {
-    const int bl = idx / (R * D);
-    const int rem = idx - bl * R * D;
-    const int r = rem / D;
-    const int d = rem - r * D;
-    lds[r * Tp + bl * D + d] = base[idx];
+  const int nt = blockDim.x;
+  if ((D & 3) == 0) {
+    const int D4 = D >> 2;
+    const int total4 = nb * R * D4;
+    const float4* base4 = reinterpret_cast<const float4*>(base);
+    for (int q0 = threadIdx.x; q0 < total4; q0 += 4 * nt) {
+      float4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int q = q0 + u * nt;
+        v[u] = base4[q < total4 ? q : total4 - 1];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int q = q0 + u * nt;
+        if (q < total4) {
+          const int row = q / D4;
+          const int d4 = q - row * D4;
+          const int bl = row / R;
+          const int r = row - bl * R;
+          *reinterpret_cast<float4*>(lds + r * Tp + bl * D + 4 * d4) = v[u];
+        }
+      }
+    }
+  } else {
+    const int total = nb * R * D;
+    for (int q0 = threadIdx.x; q0 < total; q0 += 4 * nt) {
+      float v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int q = q0 + u * nt;
+        v[u] = base[q < total ? q : total - 1];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int q = q0 + u * nt;
+        if (q < total) {
+          const int row = q / D;
+          const int d = q - row * D;
+          const int bl = row / R;
+          const int r = row - bl * R;
+          lds[r * Tp + bl * D + d] = v[u];
+        }
+      }
+    }
   }
   // padding rows (feature index >= R) and padding columns (row >= nb*D) must read as zero
   const int cols = nb * D;
-  for (int idx = threadIdx.x; idx < (Rpad - R) * Tp; idx += blockDim.x) lds[R * Tp + idx] = 0.f;
+  for (int idx = threadIdx.x; idx < (Rpad - R) * Tp; idx += nt) lds[R * Tp + idx] = 0.f;
   const int padc = Tp - cols;
-  for (int idx = threadIdx.x; idx < R * padc; idx += blockDim.x) {
+  for (int idx = threadIdx.x; idx < R * padc; idx += nt) {
     const int r = idx / padc;
     lds[r * Tp + cols + (idx - r * padc)] = 0.f;
   }
@@ -94,10 +134,12 @@ __global__ __launch_bounds__(256) void cin_fwd_mfma_kernel(
   const int nb = (int)((c.B - b0 < SPB) ? (c.B - b0) : SPB);
   stage_cols(xk, b0, nb, c.H, c.H, c.D, xs, Tp);
   if (!shared_x) stage_cols(x0, b0, nb, c.F, c.F, c.D, as, Tp);
-  for (int k = threadIdx.x; k < Ppad; k += blockDim.x) {
+  // pair table, padded by two steps so that the prefetches below never leave it;
+  // entry = f | h << 8, sign bit set for a padding slot (f = h = 0, operand forced to zero)
+  for (int k = threadIdx.x; k < Ppad + 8; k += blockDim.x) {
     int f = 0, h = 0;
     if (k < P) pair_of(k, c.H, c.masked, &f, &h);
-    ptab[k] = (k < P) ? (f | (h << 16)) : -1;
+    ptab[k] = (k < P) ? (f | (h << 8)) : (int)0x80000000;
   }
   __syncthreads();
 
@@ -112,38 +154,59 @@ __global__ __launch_bounds__(256) void cin_fwd_mfma_kernel(
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) acc[rt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // software pipeline: the filter values of step s+1 are in flight while step s multiplies
-  int pt = ptab[kk];
-  float bv[NT];
+  // channel offsets, clamped: columns >= L compute garbage that is never stored
+  int choff[NT];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
     const int ch = c0 + nt * 16 + i;
-    const int f = pt & 0xffff, h = pt >> 16;
-    bv[nt] = (pt >= 0 && ch < c.L) ? w[(int64_t)(f * c.H + h) * c.L + ch] : 0.f;
+    choff[nt] = ch < c.L ? ch : c.L - 1;
   }
-#pragma unroll 2
-  for (int k0 = 0; k0 < Ppad; k0 += 4) {
-    const int f = (pt >= 0) ? (pt & 0xffff) : 0, h = (pt >= 0) ? (pt >> 16) : 0;
-    const int kn = k0 + 4;
-    const int pt_n = (kn < Ppad) ? ptab[kn + kk] : -1;
-    float bn[NT];
+  // Software pipeline, two steps per trip, no predicated loads: while step s multiplies,
+  // the filter values and X values of step s+1 are in flight and the pair of step s+2 is read.
+  struct Stage {
+    float b[NT];
+    float a[RT], x[RT];
+    int pt;
+  };
+  auto issue = [&](Stage& st, int pt) {
+    const int f = pt & 0xff, h = (pt >> 8) & 0xff;
+    const unsigned wrow = (unsigned)((f * c.H + h) * c.L);  // F*H*L < 2^31 (checked on the host)
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      const int ch = c0 + nt * 16 + i;
-      const int fn = pt_n & 0xffff, hn = pt_n >> 16;
-      bn[nt] = (pt_n >= 0 && ch < c.L) ? w[(int64_t)(fn * c.H + hn) * c.L + ch] : 0.f;
-    }
+    for (int nt = 0; nt < NT; ++nt) st.b[nt] = w[wrow + (unsigned)choff[nt]];
     const float* ap = as + f * Tp + rbase;
     const float* xp = xs + h * Tp + rbase;
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
-      const float a = ap[16 * rt] * xp[16 * rt];
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) acc[rt][nt] = mfma(a, bv[nt], acc[rt][nt]);
+      st.a[rt] = ap[16 * rt];
+      st.x[rt] = xp[16 * rt];
     }
-    pt = pt_n;
+    st.pt = pt;
+  };
+  auto compute = [&](const Stage& st) {
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) bv[nt] = bn[nt];
+    for (int rt = 0; rt < RT; ++rt) {
+      float a = st.a[rt] * st.x[rt];
+      a = st.pt < 0 ? 0.f : a;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[rt][nt] = mfma(a, st.b[nt], acc[rt][nt]);
+    }
+  };
+  Stage s0, s1;
+  issue(s0, ptab[kk]);
+  int pt_next = ptab[4 + kk];
+  for (int k0 = 0; k0 < Ppad; k0 += 8) {
+    // sched_barrier(0): keep the compiler from sinking the loads of the next step to their uses
+    const int pt_a = ptab[k0 + 8 + kk];
+    issue(s1, pt_next);
+    __builtin_amdgcn_sched_barrier(0);
+    compute(s0);
+    __builtin_amdgcn_sched_barrier(0);
+    const int pt_b = ptab[k0 + 12 + kk];
+    issue(s0, pt_a);
+    __builtin_amdgcn_sched_barrier(0);
+    compute(s1);  // a padding step when Ppad is not a multiple of 8: operands are zero
+    __builtin_amdgcn_sched_barrier(0);
+    pt_next = pt_b;
   }
 
   // epilogue: transpose through LDS so that the global stores run along d
@@ -183,15 +246,29 @@ __global__ __launch_bounds__(256) void cin_fwd_mfma_kernel(
 }
 
 // ---------------------------------------------------------------- input gradients
+// LDS image of the filter for one f tile, built once per call: wpk[ft][fi][Hp][Lp] with
+// zeros where the pair (4ft+fi, h) is not part of the layer (padding, or h <= f when masked)
+__global__ void cin_pack_w_kernel(CinDims c, const float* __restrict__ w, int Hp, int Lp, int nft,
+                                  float* __restrict__ wpk) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t total = (int64_t)nft * 4 * Hp * Lp;
+  if (idx >= total) return;
+  const int n = (int)(idx % Lp);
+  const int64_t t = idx / Lp;
+  const int h = (int)(t % Hp);
+  const int f = (int)(t / Hp);  // = 4*ft + fi
+  const bool ok = f < c.F && h < c.H && n < c.L && (!c.masked || h > f);
+  wpk[idx] = ok ? w[(int64_t)(f * c.H + h) * c.L + n] : 0.f;
+}
+
 // Block = 4 waves x 16 rows.  Pair tile = 4 f x 4 h (lane&15 = fi*4 + hi).
 // A[i=row][k=ch] = dcurr[row][4s+k]   (registers, SMAX steps)
-// B[k=ch][j=pair] = w[(f,h)][4s+k]    (LDS copy of the four filter rows-of-h of this f tile,
-//                                      invalid pairs staged as zeros)
+// B[k=ch][j=pair] = w[(f,h)][4s+k]    (LDS copy of wpk[ft])
 // D[row=(lane>>4)*4+r][pair=lane&15] = T
 template <int NHT, int SMAX>
 __global__ __launch_bounds__(256) void cin_bwd_dx_mfma_kernel(
     CinDims c, const float* __restrict__ x0, const float* __restrict__ xk,
-    const float* __restrict__ w, const float* __restrict__ dc_mn, float* d_xk, float* d_x0,
+    const float* __restrict__ wpk, const float* __restrict__ dc_mn, float* d_xk, float* d_x0,
     int SPB, int Lp) {
   extern __shared__ float lds[];
   constexpr int ROWS = 64;
@@ -231,19 +308,22 @@ __global__ __launch_bounds__(256) void cin_bwd_dx_mfma_kernel(
 #pragma unroll
   for (int ht = 0; ht < NHT; ++ht) accK[ht] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  const int per_ft4 = Hp * Lp;  // float4 count of one wpk[ft] image (4*Hp*Lp floats)
   for (int ft = 0; ft < nft; ++ft) {
     __syncthreads();  // previous tile row is done with wst (and the X tiles are staged)
     {
-      // stage w[(f, h), n] for f = 4ft .. 4ft+3 -> wst[fi][h][n], zeros where the pair is not valid
-      const int per_f = Hp * Lp;
-      for (int idx = threadIdx.x; idx < 4 * per_f; idx += blockDim.x) {
-        const int ff = idx / per_f;
-        const int rem = idx - ff * per_f;
-        const int h = rem / Lp;
-        const int n = rem - h * Lp;
-        const int f = 4 * ft + ff;
-        const bool ok = f < c.F && h < c.H && n < c.L && (!c.masked || h > f);
-        wst[idx] = ok ? w[(int64_t)(f * c.H + h) * c.L + n] : 0.f;
+      const float4* src = reinterpret_cast<const float4*>(wpk) + (size_t)ft * per_ft4;
+      float4* dst = reinterpret_cast<float4*>(wst);
+      for (int q0 = threadIdx.x; q0 < per_ft4; q0 += 4 * 256) {
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int q = q0 + u * 256;
+          v[u] = src[q < per_ft4 ? q : per_ft4 - 1];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (q0 + u * 256 < per_ft4) dst[q0 + u * 256] = v[u];
       }
     }
     __syncthreads();
@@ -251,19 +331,57 @@ __global__ __launch_bounds__(256) void cin_bwd_dx_mfma_kernel(
     f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f};
     const int ht_begin = c.masked ? ft : 0;
     const float* wl = wst + (fi * Hp + hi) * Lp + kk;
+    const float* xl = xs + hi * Tp + rrow;
+    // two h tiles per trip: two independent accumulate chains keep the matrix pipe busy
 #pragma unroll
-    for (int ht = 0; ht < NHT; ++ht) {
-      if (ht >= ht_begin && ht < nht) {
+    for (int hp = 0; hp < (NHT + 1) / 2; ++hp) {
+      const int h0 = 2 * hp, h1 = 2 * hp + 1;
+      const bool on0 = h0 >= ht_begin && h0 < nht;
+      const bool on1 = h1 < NHT && h1 >= ht_begin && h1 < nht;
+      if (on0 && on1) {
+        f32x4 T0 = f32x4{0.f, 0.f, 0.f, 0.f}, T1 = T0;
+        float w0[SMAX], w1[SMAX];
+#pragma unroll
+        for (int s = 0; s < SMAX; ++s) {  // Lp = 4*SMAX + 1: steps beyond L read staged zeros
+          w0[s] = wl[4 * h0 * Lp + 4 * s];
+          w1[s] = wl[4 * h1 * Lp + 4 * s];
+        }
+        const f32x4 x0v = *reinterpret_cast<const f32x4*>(xl + 4 * h0 * Tp);
+        const f32x4 x1v = *reinterpret_cast<const f32x4*>(xl + 4 * h1 * Tp);
+#pragma unroll
+        for (int s = 0; s < SMAX; ++s) {
+          T0 = mfma(dcA[s], w0[s], T0);
+          T1 = mfma(dcA[s], w1[s], T1);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          acc0[r] = fmaf(x0v[r], T0[r], acc0[r]);
+          accK[h0][r] = fmaf(a0[r], T0[r], accK[h0][r]);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          acc0[r] = fmaf(x1v[r], T1[r], acc0[r]);
+          accK[h1 < NHT ? h1 : 0][r] = fmaf(a0[r], T1[r], accK[h1 < NHT ? h1 : 0][r]);
+        }
+      } else if (on0 || on1) {
+        const int ht = on0 ? h0 : (h1 < NHT ? h1 : 0);
         f32x4 T = f32x4{0.f, 0.f, 0.f, 0.f};
         const float* wp = wl + 4 * ht * Lp;
 #pragma unroll
-        for (int s = 0; s < SMAX; ++s)
-          if (s < S) T = mfma(dcA[s], wp[4 * s], T);
-        const f32x4 xv = *reinterpret_cast<const f32x4*>(xs + (4 * ht + hi) * Tp + rrow);
+        for (int s = 0; s < SMAX; ++s) T = mfma(dcA[s], wp[4 * s], T);
+        const f32x4 xv = *reinterpret_cast<const f32x4*>(xl + 4 * ht * Tp);
+        if (on0) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          acc0[r] = fmaf(xv[r], T[r], acc0[r]);
-          accK[ht][r] = fmaf(a0[r], T[r], accK[ht][r]);
+          for (int r = 0; r < 4; ++r) {
+            acc0[r] = fmaf(xv[r], T[r], acc0[r]);
+            accK[h0][r] = fmaf(a0[r], T[r], accK[h0][r]);
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            acc0[r] = fmaf(xv[r], T[r], acc0[r]);
+            accK[h1 < NHT ? h1 : 0][r] = fmaf(a0[r], T[r], accK[h1 < NHT ? h1 : 0][r]);
+          }
         }
       }
     }
@@ -390,31 +508,44 @@ __global__ __launch_bounds__(256) void cin_bwd_dw_mfma_kernel(
   for (int64_t r0 = r_beg; r0 < r_end; r0 += RC) {
     const int nr = (int)((r_end - r0 < RC) ? (r_end - r0) : RC);
     __syncthreads();
-    // [row][h] <- xk[b][h][d] with row = b*D + d; unused cells are zero
-    for (int idx = threadIdx.x; idx < RC * Hp; idx += blockDim.x) {
-      const int h = idx / RC;  // consecutive threads walk rows (d fastest): coalesced reads
-      const int rl = idx - h * RC;
-      float v = 0.f;
-      if (rl < nr && h < c.H) {
-        const int64_t m = r0 + rl;
-        const int64_t b = m / c.D;
-        const int d = (int)(m - b * c.D);
-        v = xk[b * HD + h * c.D + d];
-      }
-      xs[rl * Hs + h] = v;
-    }
-    if (!shared_x) {
-      for (int idx = threadIdx.x; idx < RC * Fp; idx += blockDim.x) {
-        const int f = idx / RC;
-        const int rl = idx - f * RC;
-        float v = 0.f;
-        if (rl < nr && f < c.F) {
-          const int64_t m = r0 + rl;
-          const int64_t b = m / c.D;
-          const int d = (int)(m - b * c.D);
-          v = x0[b * FD + f * c.D + d];
+    // [row][h] <- xk[b][h][d] with row = b*D + d; unused cells are zero.  Thread t always
+    // serves row t & 63, so the sample / d split is done once per chunk.
+    {
+      const int rl = threadIdx.x & 63;
+      const int hq = threadIdx.x >> 6;  // 0..3
+      const int64_t m = r0 + rl;
+      const int64_t b = m / c.D;
+      const int d = (int)(m - b * c.D);
+      const bool row_ok = rl < nr;
+      const float* xrow = xk + b * HD + d;
+      for (int h0 = 0; h0 < Hp; h0 += 16) {
+        float v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int h = h0 + 4 * u + hq;
+          v[u] = (row_ok && h < c.H) ? xrow[h * c.D] : 0.f;
         }
-        as[rl * Fs + f] = v;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int h = h0 + 4 * u + hq;
+          if (h < Hp) xs[rl * Hs + h] = v[u];
+        }
+      }
+      if (!shared_x) {
+        const float* arow = x0 + b * FD + d;
+        for (int f0 = 0; f0 < Fp; f0 += 16) {
+          float v[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int f = f0 + 4 * u + hq;
+            v[u] = (row_ok && f < c.F) ? arow[f * c.D] : 0.f;
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int f = f0 + 4 * u + hq;
+            if (f < Fp) as[rl * Fs + f] = v[u];
+          }
+        }
       }
     }
     __syncthreads();
@@ -467,26 +598,42 @@ __global__ __launch_bounds__(256) void cin_bwd_dw_mfma_kernel(
   }
 }
 
-// d_w[(f,h), n] = scale * sum over splits, in split order; masked pairs get 0
-__global__ void cin_dw_unpack_kernel(CinDims c, const float* __restrict__ part, int n_splits,
-                                     float* __restrict__ d_w) {
-  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+// d_w[(f,h), n] = scale * sum over splits; masked pairs get 0.  A block sums 32 elements:
+// 8 lanes-groups each add every 8th split in order, then the 8 partial sums are added in
+// group order (fixed association, bit-identical from run to run).
+__global__ __launch_bounds__(256) void cin_dw_unpack_kernel(CinDims c, const float* __restrict__ part,
+                                                            int n_splits, float* __restrict__ d_w) {
+  __shared__ float red[8][33];
+  const int e = threadIdx.x & 31, g = threadIdx.x >> 5;
+  const int64_t idx = (int64_t)blockIdx.x * 32 + e;
   const int64_t total = (int64_t)c.F * c.H * c.L;
-  if (idx >= total) return;
-  const int p = (int)(idx / c.L);
-  const int n = (int)(idx - (int64_t)p * c.L);
-  const int f = p / c.H, h = p - f * c.H;
-  const int nft = (c.F + 3) >> 2, nht = (c.H + 3) >> 2;
   float s = 0.f;
-  if (!(c.masked && h <= f)) {
-    const int t = tile_index(f >> 2, h >> 2, nft, nht, c.masked);
-    const int ntile = n_tiles(nft, nht, c.masked);
-    const int64_t slot = (int64_t)t * 16 + (f & 3) * 4 + (h & 3);
-    const int64_t stride = (int64_t)ntile * 16 * c.L;
-    const float* src = part + slot * c.L + n;
-    for (int k = 0; k < n_splits; ++k) s += src[k * stride];
+  bool live = false;
+  if (idx < total) {
+    const int p = (int)(idx / c.L);
+    const int n = (int)(idx - (int64_t)p * c.L);
+    const int f = p / c.H, h = p - f * c.H;
+    const int nft = (c.F + 3) >> 2, nht = (c.H + 3) >> 2;
+    if (!(c.masked && h <= f)) {
+      live = true;
+      const int t = tile_index(f >> 2, h >> 2, nft, nht, c.masked);
+      const int ntile = n_tiles(nft, nht, c.masked);
+      const int64_t slot = (int64_t)t * 16 + (f & 3) * 4 + (h & 3);
+      const int64_t stride = (int64_t)ntile * 16 * c.L;
+      const float* src = part + slot * c.L + n;
+      for (int k = g; k < n_splits; k += 8) s += src[k * stride];
+    }
   }
-  d_w[idx] = s * (c.masked ? 2.f : 1.f);
+  red[g][e] = s;
+  __syncthreads();
+  if (g == 0 && idx < total) {
+    float t = 0.f;
+    if (live) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) t += red[q][e];
+    }
+    d_w[idx] = t * (c.masked ? 2.f : 1.f);
+  }
 }
 
 // upstream gradient of curr in [m][L] order (m = b*D+d)
@@ -514,6 +661,9 @@ int allow_lds(K kernel, size_t bytes) {
   return XDFM_OK;
 }
 
+// SMAX instantiation of the input-gradient kernel that serves S = ceil(L/4) channel steps
+int smax_for(int S) { return S <= 3 ? 3 : (S <= 5 ? 5 : (S <= 16 ? 16 : 64)); }
+
 int dw_splits(int64_t rows) {
   int64_t s = (rows + 511) / 512;
   return (int)(s < 1 ? 1 : (s > 256 ? 256 : s));
@@ -526,7 +676,7 @@ bool mfma_supported(int64_t B, int F, int H, int D, int L) {
   const int Hp = (H + 3) & ~3, Fp = (F + 3) & ~3;
   const int S = (L + 3) / 4;
   if (S > 64) return false;
-  const int Lp = 4 * S + 1;
+  const int Lp = 4 * smax_for(S) + 1;
   const size_t dx_lds = ((size_t)(2 * Hp + 2 * Fp) * (64 + kPad) + (size_t)4 * Hp * Lp) * sizeof(float);
   if (dx_lds > kLdsLimit) return false;
   (void)B;
@@ -544,7 +694,7 @@ int fwd_mfma(const CinDims& c, const float* x0, const float* xk, const float* w,
   const int NT = nt_total >= 4 ? 4 : (nt_total >= 2 ? 2 : 1);
   int lds_rows = (xk == x0) ? c.H : c.H + c.F;
   if (lds_rows < NT * 16) lds_rows = NT * 16;
-  const size_t lds_bytes = (size_t)lds_rows * (ROWS + kPad) * sizeof(float) + (size_t)(Ppad + 4) * sizeof(int);
+  const size_t lds_bytes = (size_t)lds_rows * (ROWS + kPad) * sizeof(float) + (size_t)(Ppad + 16) * sizeof(int);
   XDFM_REQUIRE(lds_bytes <= kLdsLimit, "xdfm_cin_fwd: tile does not fit the LDS");
   dim3 grid((unsigned)((c.B + SPB - 1) / SPB), (unsigned)((nt_total + NT - 1) / NT));
 #define CALL(N)                                                                                   \
@@ -568,14 +718,18 @@ int fwd_mfma(const CinDims& c, const float* x0, const float* xk, const float* w,
 size_t bwd_mfma_workspace_floats(int64_t B, int F, int H, int D, int L, int masked) {
   const int nft = (F + 3) / 4, nht = (H + 3) / 4;
   const int ntile = n_tiles(nft, nht, masked);
-  return (size_t)B * D * L + (size_t)dw_splits(B * D) * ntile * 16 * L;
+  const int Hp = (H + 3) & ~3, S = (L + 3) / 4;
+  const size_t wpk = (size_t)nft * 4 * Hp * (4 * smax_for(S) + 1);
+  return (((size_t)B * D * L + 3) & ~(size_t)3) + wpk + (size_t)dw_splits(B * D) * ntile * 16 * L;
 }
 
 int bwd_mfma(const CinDims& c, const float* x0, const float* xk, const float* w,
              const float* d_xnext, const float* d_pooled, int pool_stride, int pool_off, float* d_xk,
              float* d_x0, float* d_w, float* ws, hipStream_t st) {
   float* dc_mn = ws;
-  float* part = ws + (size_t)c.B * c.D * c.L;
+  float* wpk = ws + (((size_t)c.B * c.D * c.L + 3) & ~(size_t)3);  // 16-byte aligned: staged as float4
+  const size_t wpk_floats = (size_t)((c.F + 3) / 4) * 4 * ((c.H + 3) & ~3) * (4 * smax_for((c.L + 3) / 4) + 1);
+  float* part = wpk + wpk_floats;
   {
     const int64_t total = c.B * c.D * c.L;
     XDFM_LAUNCH("cin_dcurr_kernel", st, cin_dcurr_kernel, dim3((unsigned)((total + 255) / 256)),
@@ -588,17 +742,19 @@ int bwd_mfma(const CinDims& c, const float* x0, const float* xk, const float* w,
   // ---- input gradients
   {
     const int SPB = 64 / c.D;
-    const int Lp = 4 * S + 1;
+    const int Lp = 4 * smax_for(S) + 1;
     const size_t lds_bytes =
         ((size_t)((shared_x ? 2 : 2) * Hp + (shared_x ? 1 : 2) * Fp) * (64 + kPad) + (size_t)4 * Hp * Lp) *
         sizeof(float);
     dim3 grid((unsigned)((c.B + SPB - 1) / SPB));
+    XDFM_LAUNCH("cin_pack_w_kernel", st, cin_pack_w_kernel, dim3((unsigned)((wpk_floats + 255) / 256)),
+                dim3(256), 0, c, w, Hp, Lp, nft, wpk);
 #define CALL(NH, SM)                                                                               \
   do {                                                                                             \
     int rc = allow_lds(cin_bwd_dx_mfma_kernel<NH, SM>, lds_bytes);                                 \
     if (rc) return rc;                                                                             \
     XDFM_LAUNCH("cin_bwd_dx_mfma_kernel<" #NH ", " #SM ">", st, (cin_bwd_dx_mfma_kernel<NH, SM>),  \
-                grid, dim3(256), lds_bytes, c, x0, xk, w, dc_mn, d_xk, d_x0, SPB, Lp);             \
+                grid, dim3(256), lds_bytes, c, x0, xk, wpk, dc_mn, d_xk, d_x0, SPB, Lp);             \
   } while (0)
 #define BY_S(NH)        \
   do {                  \
@@ -640,7 +796,7 @@ int bwd_mfma(const CinDims& c, const float* x0, const float* xk, const float* w,
                   lds_bytes, c, x0, xk, dc_mn, rows, rows_per_split, part);
     }
     const int64_t total = (int64_t)c.F * c.H * c.L;
-    XDFM_LAUNCH("cin_dw_unpack_kernel", st, cin_dw_unpack_kernel, dim3((unsigned)((total + 255) / 256)),
+    XDFM_LAUNCH("cin_dw_unpack_kernel", st, cin_dw_unpack_kernel, dim3((unsigned)((total + 31) / 32)),
                 dim3(256), 0, c, part, n_splits, d_w);
   }
   XDFM_LAUNCH_CHECK();
