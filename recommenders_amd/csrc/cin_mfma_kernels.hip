@@ -487,6 +487,12 @@ __global__ __launch_bounds__(256) void cin_bwd_dw_mfma_kernel(
   const int fi = j >> 2, hi = j & 3;
   const int c0 = blockIdx.z * (NT * 16);
   const int t0 = (blockIdx.y * 4 + wave) * PT;
+  int choff[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int ch = c0 + nt * 16 + j;
+    choff[nt] = ch < c.L ? ch : c.L - 1;
+  }
   int foff[PT], hoff[PT];
 #pragma unroll
   for (int p = 0; p < PT; ++p) {
@@ -550,32 +556,46 @@ __global__ __launch_bounds__(256) void cin_bwd_dw_mfma_kernel(
     }
     __syncthreads();
     if (t0 < ntile) {
-      float bv[NT];
+      // two k-steps (8 rows) per trip; operands of the next step are in flight while this one
+      // multiplies.  No predicated loads: rows past the chunk read zeros from LDS (so the
+      // clamped dcurr value they meet does not matter), channels past L are never stored.
+      struct Stage {
+        float b[NT];
+        float a[PT], x[PT];
+      };
+      auto issue = [&](Stage& st, int rl) {
+        int64_t row = r0 + rl;
+        row = row < rows_total ? row : rows_total - 1;
+        const float* dr = dc_mn + row * c.L;
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-        const int ch = c0 + nt * 16 + j;
-        bv[nt] = (kk < nr && ch < c.L) ? dc_mn[(r0 + kk) * c.L + ch] : 0.f;
-      }
-#pragma unroll 2
-      for (int ks = 0; ks < RC; ks += 4) {
-        const int rl = ks + kk;
-        float bn[NT];
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-          const int ch = c0 + nt * 16 + j;
-          const int rn = rl + 4;
-          bn[nt] = (ks + 4 < RC && rn < nr && ch < c.L) ? dc_mn[(r0 + rn) * c.L + ch] : 0.f;
-        }
+        for (int nt = 0; nt < NT; ++nt) st.b[nt] = dr[choff[nt]];
         const float* ar = as + rl * Fs;
         const float* xr = xs + rl * Hs;
 #pragma unroll
         for (int p = 0; p < PT; ++p) {
-          const float a = ar[foff[p]] * xr[hoff[p]];
-#pragma unroll
-          for (int nt = 0; nt < NT; ++nt) acc[p][nt] = mfma(a, bv[nt], acc[p][nt]);
+          st.a[p] = ar[foff[p]];
+          st.x[p] = xr[hoff[p]];
         }
+      };
+      auto compute = [&](const Stage& st) {
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) bv[nt] = bn[nt];
+        for (int p = 0; p < PT; ++p) {
+          const float a = st.a[p] * st.x[p];
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) acc[p][nt] = mfma(a, st.b[nt], acc[p][nt]);
+        }
+      };
+      Stage s0, s1;
+      issue(s0, kk);
+      for (int ks = 0; ks < RC; ks += 8) {
+        issue(s1, ks + 4 + kk);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(s0);
+        __builtin_amdgcn_sched_barrier(0);
+        issue(s0, (ks + 8 < RC ? ks + 8 : 0) + kk);  // last trip: a harmless re-read of row kk
+        __builtin_amdgcn_sched_barrier(0);
+        compute(s1);
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
   }
