@@ -1,10 +1,16 @@
-// Dense layers of the DNN tower and the two output heads, fp32, gfx950.
+// Dense layers of the DNN tower and the two output heads on the fp32 matrix cores of gfx950
+// (v_mfma_f32_16x16x4_f32, exact fp32).
 //
 // Reference: xDeepFM.py:473-533 (`xw_plus_b` + `_active_layer`, base_model.py:324-353) and
-// the CIN head xDeepFM.py:279-293.  The notebook/Criteo-shape towers are tiny (390x20,
-// 20x20, 20x1): memory/launch bound, so the fp32 form is VALU with the weight row held in
-// SGPRs (one lane per sample, x staged through LDS so that the global read is coalesced).
-// Weight gradients are reduced over the batch in a fixed split order (no float atomics).
+// the CIN head xDeepFM.py:279-293.
+//
+//   forward   y[b,n]  = act(sum_k x[b,k] w[k,n] + bias[n])     M = rows, N = out,  K = in
+//   d-input   dx[b,k] = sum_n dz[b,n] w[k,n]                    M = rows, N = in,   K = out
+//   d-weight  dw[k,n] = sum_b x[b,k] dz[b,n], db[n] = sum_b dz  M = in,   N = out,  K = rows
+// with dz = dy * act'(y) formed on the fly from the saved output.  The tower is tiny next to
+// its input (x = the [B, F*D] embedding block): the kernels are HBM-bound on x, so the work of
+// one row tile is split over the 4 waves of a block to keep enough loads in flight.
+// Reductions over the batch run in a fixed split order (no float atomics).
 //
 // Layouts: x[B][K], w[K][Nout], b[Nout], y[B][Nout].
 #include <hip/hip_runtime.h>
@@ -13,9 +19,11 @@
 
 namespace {
 
-constexpr int kT = 128;   // samples per block in the forward
-constexpr int kKT = 32;   // k-tile staged per step
-constexpr int kMaxSplits = 128;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f32x4 mfma(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
 
 __device__ __forceinline__ float activate(float v, int act) {
   switch (act) {
@@ -38,116 +46,270 @@ __device__ __forceinline__ float act_grad(float y, int act) {
   }
 }
 
-template <int NCH>
-__global__ __launch_bounds__(kT) void dense_fwd_kernel(const float* __restrict__ x,
-                                                        const float* __restrict__ w,
-                                                        const float* __restrict__ bias, int64_t B,
-                                                        int K, int Nout, int act,
-                                                        float* __restrict__ y) {
-  __shared__ float xs[kKT][kT + 1];
-  const int tid = threadIdx.x;
-  const int64_t b0 = (int64_t)blockIdx.x * kT;
-  const int64_t b = b0 + tid;
-  const int c0 = blockIdx.y * NCH;
-  const bool full = (c0 + NCH <= Nout);
-  float acc[NCH];
+// ------------------------------------------------------------------------ forward
+// Block = 4 waves on the same 16 rows; wave w takes the 16-wide k steps w, w+4, ...;
+// lane (i = lane&15, kk = lane>>4) loads x[row i][k0 + 4kk .. +3] as one 16-byte load and
+// feeds it to 4 MFMAs whose k slot kk stands for k = k0 + 4kk + s (s = 0..3).
+template <int NT>
+__global__ __launch_bounds__(256) void dense_fwd_mfma_kernel(
+    const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+    int64_t B, int K, int Nout, int act, float* __restrict__ y) {
+  __shared__ float red[3][NT][64][4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = lane & 15, kk = lane >> 4;
+  const int64_t row0 = (int64_t)blockIdx.x * 16;
+  const int c0 = blockIdx.y * (NT * 16);
+  int64_t arow = row0 + i;
+  if (arow >= B) arow = B - 1;  // clamped rows compute garbage that is never stored
+  const float* xr = x + arow * K;
+  const bool vec = ((K & 3) == 0);
+  int choff[NT];
 #pragma unroll
-  for (int n = 0; n < NCH; ++n) acc[n] = 0.f;
-  for (int k0 = 0; k0 < K; k0 += kKT) {
-    __syncthreads();
-    for (int idx = tid; idx < kT * kKT; idx += kT) {
-      const int bl = idx / kKT;
-      const int kk = idx - bl * kKT;
-      const int64_t bb = b0 + bl;
-      const int k = k0 + kk;
-      xs[kk][bl] = (bb < B && k < K) ? x[bb * K + k] : 0.f;
+  for (int nt = 0; nt < NT; ++nt) {
+    const int ch = c0 + nt * 16 + i;
+    choff[nt] = ch < Nout ? ch : Nout - 1;
+  }
+  f32x4 acc[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  struct Stage {
+    float a[4];
+    float b[4][NT];
+  };
+  auto issue = [&](Stage& st, int k0) {
+    const int k = k0 + 4 * kk;
+    if (vec && k + 3 < K) {
+      const float4 v = *reinterpret_cast<const float4*>(xr + k);
+      st.a[0] = v.x;
+      st.a[1] = v.y;
+      st.a[2] = v.z;
+      st.a[3] = v.w;
+    } else {
+#pragma unroll
+      for (int s = 0; s < 4; ++s) st.a[s] = (k + s < K) ? xr[k + s] : 0.f;
     }
-    __syncthreads();
-    const int kn = (K - k0 < kKT) ? (K - k0) : kKT;
-    for (int kk = 0; kk < kn; ++kk) {
-      const float xv = xs[kk][tid];
-      const float* __restrict__ wrow = w + (int64_t)(k0 + kk) * Nout + c0;
-      if (full) {
 #pragma unroll
-        for (int n = 0; n < NCH; ++n) acc[n] = fmaf(xv, wrow[n], acc[n]);
-      } else {
+    for (int s = 0; s < 4; ++s) {
+      const int kc = (k + s < K) ? k + s : K - 1;  // a is zero there
 #pragma unroll
-        for (int n = 0; n < NCH; ++n)
-          if (c0 + n < Nout) acc[n] = fmaf(xv, wrow[n], acc[n]);
+      for (int nt = 0; nt < NT; ++nt) st.b[s][nt] = w[(unsigned)(kc * Nout + choff[nt])];
+    }
+  };
+  auto compute = [&](const Stage& st) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[nt] = mfma(st.a[s], st.b[s][nt], acc[nt]);
+  };
+  // this wave's steps: k0 = 16*wave, 16*(wave+4), ...; two stages in flight
+  const int nsteps = (K + 15) / 16;
+  Stage s0, s1;
+  int st_i = wave;
+  if (st_i < nsteps) issue(s0, 16 * st_i);
+  while (st_i < nsteps) {
+    const int n1 = st_i + 4, n2 = st_i + 8;
+    if (n1 < nsteps) issue(s1, 16 * n1);
+    __builtin_amdgcn_sched_barrier(0);
+    compute(s0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (n1 >= nsteps) break;
+    if (n2 < nsteps) issue(s0, 16 * n2);
+    __builtin_amdgcn_sched_barrier(0);
+    compute(s1);
+    __builtin_amdgcn_sched_barrier(0);
+    st_i = n2;
+  }
+  // sum the 4 waves' partial tiles in wave order, then bias + activation + store (wave 0)
+  if (wave > 0) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[wave - 1][nt][lane][r] = acc[nt][r];
+  }
+  __syncthreads();
+  if (wave == 0) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int ch = c0 + nt * 16 + i;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float v = acc[nt][r];
+        v += red[0][nt][lane][r];
+        v += red[1][nt][lane][r];
+        v += red[2][nt][lane][r];
+        const int64_t row = row0 + kk * 4 + r;
+        if (row < B && ch < Nout) y[row * Nout + ch] = activate(v + bias[ch], act);
       }
     }
   }
-  if (b >= B) return;
-#pragma unroll
-  for (int n = 0; n < NCH; ++n)
-    if (c0 + n < Nout) y[b * Nout + c0 + n] = activate(acc[n] + bias[c0 + n], act);
 }
 
-__global__ void dense_dz_kernel(const float* __restrict__ y, const float* __restrict__ dy,
-                                int64_t total, int act, float* __restrict__ dz) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < total) dz[i] = dy[i] * act_grad(y[i], act);
-}
-
-// lane per k (k == K is the bias row, x = 1); registers hold dW[k, c0..c0+NCH)
-template <int NCH>
-__global__ __launch_bounds__(256) void dense_bwd_dw_kernel(const float* __restrict__ x,
-                                                           const float* __restrict__ dz, int64_t B,
-                                                           int K, int Nout, int samples_per_split,
-                                                           float* __restrict__ part) {
-  const int k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k > K) return;
-  const int c0 = blockIdx.z * NCH;
-  const bool full = (c0 + NCH <= Nout);
-  float acc[NCH];
+// ---------------------------------------------------------------- input gradient
+// Block = 4 waves on the same 16 rows; wave w takes the 16-wide column tiles w, w+4, ...
+// A[i=row][k=n] = dz[row][4s+kk] (registers), B[k=n][j=col] = w[c0+j][4s+kk].
+template <int SMAX>
+__global__ __launch_bounds__(256) void dense_bwd_dx_mfma_kernel(
+    const float* __restrict__ w, const float* __restrict__ y, const float* __restrict__ dy,
+    int64_t B, int K, int Nout, int act, int accumulate, float* __restrict__ dx) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = lane & 15, kk = lane >> 4;
+  const int64_t row0 = (int64_t)blockIdx.x * 16;
+  const int S = (Nout + 3) >> 2;
+  float dzA[SMAX];
+  {
+    int64_t arow = row0 + i;
+    const bool ok = arow < B;
+    if (!ok) arow = B - 1;
 #pragma unroll
-  for (int n = 0; n < NCH; ++n) acc[n] = 0.f;
-  const int64_t s_beg = (int64_t)blockIdx.y * samples_per_split;
-  int64_t s_end = s_beg + samples_per_split;
-  if (s_end > B) s_end = B;
-  for (int64_t b = s_beg; b < s_end; ++b) {
-    const float xv = (k < K) ? x[b * K + k] : 1.f;
-    const float* __restrict__ dzrow = dz + b * Nout + c0;
-    if (full) {
-#pragma unroll
-      for (int n = 0; n < NCH; ++n) acc[n] = fmaf(xv, dzrow[n], acc[n]);
-    } else {
-#pragma unroll
-      for (int n = 0; n < NCH; ++n)
-        if (c0 + n < Nout) acc[n] = fmaf(xv, dzrow[n], acc[n]);
+    for (int s = 0; s < SMAX; ++s) {
+      const int n = 4 * s + kk;
+      const int nc = n < Nout ? n : Nout - 1;
+      const float g = dy[arow * Nout + nc] * act_grad(y[arow * Nout + nc], act);
+      dzA[s] = (ok && s < S && n < Nout) ? g : 0.f;
     }
   }
-  float* dst = part + ((int64_t)blockIdx.y * (K + 1) + k) * Nout + c0;
+  const int ntile = (K + 15) / 16;
+  for (int t = wave; t < ntile; t += 4) {
+    const int col = 16 * t + i;
+    const int colc = col < K ? col : K - 1;
+    float bv[SMAX];
 #pragma unroll
-  for (int n = 0; n < NCH; ++n)
-    if (c0 + n < Nout) dst[n] = acc[n];
+    for (int s = 0; s < SMAX; ++s) {
+      const int n = 4 * s + kk;
+      bv[s] = w[(unsigned)(colc * Nout + (n < Nout ? n : Nout - 1))];  // dzA is zero past Nout
+    }
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < SMAX; ++s) acc = mfma(dzA[s], bv[s], acc);
+    if (col < K) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int64_t row = row0 + kk * 4 + r;
+        if (row < B) {
+          float* p = dx + row * K + col;
+          *p = accumulate ? *p + acc[r] : acc[r];
+        }
+      }
+    }
+  }
 }
 
-__global__ void dense_dw_reduce_kernel(const float* __restrict__ part, int n_splits, int K, int Nout,
-                                       float* __restrict__ dw, float* __restrict__ db) {
-  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+// --------------------------------------------------------------- weight gradient
+// Wave = PT k tiles (16 input columns each; column K is the bias row, x = 1) x NT channel
+// tiles, over the rows of one split.  A[i=k][slot=row] = x[row][k0+i], B[slot=row][j] = dz[row][c0+j].
+template <int PT, int NT>
+__global__ __launch_bounds__(256) void dense_bwd_dw_mfma_kernel(
+    const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ dy,
+    int64_t B, int K, int Nout, int act, int rows_per_split, float* __restrict__ part) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = lane & 15, kk = lane >> 4;
+  const int ktiles = (K + 1 + 15) / 16;
+  const int t0 = (blockIdx.y * 4 + wave) * PT;
+  if (t0 >= ktiles) return;  // no barrier in this kernel
+  const int c0 = blockIdx.z * (NT * 16);
+  int kcol[PT];
+#pragma unroll
+  for (int p = 0; p < PT; ++p) kcol[p] = 16 * (t0 + p) + i;
+  int choff[NT];
+  bool chok[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int ch = c0 + nt * 16 + i;
+    chok[nt] = ch < Nout;
+    choff[nt] = chok[nt] ? ch : Nout - 1;
+  }
+  f32x4 acc[PT][NT];
+#pragma unroll
+  for (int p = 0; p < PT; ++p)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[p][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int64_t r_beg = (int64_t)blockIdx.x * rows_per_split;
+  int64_t r_end = r_beg + rows_per_split;
+  if (r_end > B) r_end = B;
+  if (r_beg >= r_end) r_end = r_beg;  // an empty split still writes its zero partials
+  struct Stage {
+    float a[PT];
+    float b[NT];
+  };
+  auto issue = [&](Stage& st, int64_t r) {
+    const bool ok = r < r_end;
+    int64_t rc = ok ? r : r_end - 1;
+    if (rc < 0) rc = 0;
+    const float* xr = x + rc * K;
+#pragma unroll
+    for (int p = 0; p < PT; ++p) {
+      const int k = kcol[p];
+      float v = xr[k < K ? k : K - 1];
+      v = (k < K) ? v : (k == K ? 1.f : 0.f);
+      st.a[p] = ok ? v : 0.f;  // rows past the split contribute nothing
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const float g = dy[rc * Nout + choff[nt]] * act_grad(y[rc * Nout + choff[nt]], act);
+      st.b[nt] = chok[nt] ? g : 0.f;
+    }
+  };
+  auto compute = [&](const Stage& st) {
+#pragma unroll
+    for (int p = 0; p < PT; ++p)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[p][nt] = mfma(st.a[p], st.b[nt], acc[p][nt]);
+  };
+  Stage s0, s1;
+  int64_t r = r_beg + kk;
+  issue(s0, r);
+  for (int64_t rb = r_beg; rb < r_end; rb += 8) {
+    issue(s1, r + 4);
+    __builtin_amdgcn_sched_barrier(0);
+    compute(s0);
+    __builtin_amdgcn_sched_barrier(0);
+    issue(s0, r + 8);
+    __builtin_amdgcn_sched_barrier(0);
+    compute(s1);
+    __builtin_amdgcn_sched_barrier(0);
+    r += 8;
+  }
+  // part[split][k][n], k in [0, K] (row K = bias)
+#pragma unroll
+  for (int p = 0; p < PT; ++p)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int ch = c0 + nt * 16 + i;
+      if (ch < Nout) {
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          const int k = 16 * (t0 + p) + kk * 4 + rr;
+          if (k <= K) part[((int64_t)blockIdx.x * (K + 1) + k) * Nout + ch] = acc[p][nt][rr];
+        }
+      }
+    }
+}
+
+// dw / db = sum over splits: 8 thread groups add every 8th split in order, then the 8 partial
+// sums are added in group order (fixed association)
+__global__ __launch_bounds__(256) void dense_dw_reduce_kernel(const float* __restrict__ part, int n_splits,
+                                                              int K, int Nout, float* __restrict__ dw,
+                                                              float* __restrict__ db) {
+  __shared__ float red[8][33];
+  const int e = threadIdx.x & 31, g = threadIdx.x >> 5;
+  const int64_t idx = (int64_t)blockIdx.x * 32 + e;
   const int64_t total = (int64_t)(K + 1) * Nout;
-  if (idx >= total) return;
   float s = 0.f;
-  for (int k = 0; k < n_splits; ++k) s += part[(int64_t)k * total + idx];
-  if (idx < (int64_t)K * Nout)
-    dw[idx] = s;
-  else
-    db[idx - (int64_t)K * Nout] = s;
-}
-
-__global__ void dense_bwd_dx_kernel(const float* __restrict__ dz, const float* __restrict__ w,
-                                    int64_t B, int K, int Nout, int accumulate,
-                                    float* __restrict__ dx) {
-  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= B * K) return;
-  const int64_t b = idx / K;
-  const int k = (int)(idx - b * K);
-  const float* __restrict__ dzrow = dz + b * Nout;
-  const float* __restrict__ wrow = w + (int64_t)k * Nout;
-  float s = 0.f;
-  for (int n = 0; n < Nout; ++n) s = fmaf(dzrow[n], wrow[n], s);
-  dx[idx] = accumulate ? dx[idx] + s : s;
+  if (idx < total)
+    for (int k = g; k < n_splits; k += 8) s += part[(int64_t)k * total + idx];
+  red[g][e] = s;
+  __syncthreads();
+  if (g == 0 && idx < total) {
+    float t = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) t += red[q][e];
+    if (idx < (int64_t)K * Nout)
+      dw[idx] = t;
+    else
+      db[idx - (int64_t)K * Nout] = t;
+  }
 }
 
 // exFM_out = base_score + xw_plus_b(result)   (xDeepFM.py:272-292)
@@ -174,50 +336,40 @@ __global__ void cin_head_dpooled_kernel(const float* __restrict__ w, const float
   d_pooled[idx] = g[b] + g[b] * w[k];
 }
 
-int pick_nch(int Nout) {
-  if (Nout <= 1) return 1;
-  if (Nout <= 2) return 2;
-  if (Nout <= 4) return 4;
-  return 8;
-}
-
 int splits_for(int64_t B) {
-  int64_t s = (B + 31) / 32;
-  return (int)(s < 1 ? 1 : (s > kMaxSplits ? kMaxSplits : s));
+  int64_t s = (B + 127) / 128;
+  return (int)(s < 1 ? 1 : (s > 128 ? 128 : s));
 }
 
 bool act_ok(int act) { return act >= XDFM_ACT_IDENTITY && act <= XDFM_ACT_ELU; }
 
 }  // namespace
 
-#define DISPATCH_NCH(nch, CALL) \
-  switch (nch) {                \
-    case 1: { CALL(1); } break; \
-    case 2: { CALL(2); } break; \
-    case 4: { CALL(4); } break; \
-    default: { CALL(8); } break; \
-  }
-
 extern "C" int xdfm_dense_fwd(const float* x, const float* w, const float* b, int64_t B, int32_t K,
                               int32_t Nout, int32_t act, float* y, void* stream) {
   XDFM_REQUIRE(x && w && b && y, "xdfm_dense_fwd: null argument");
   XDFM_REQUIRE(B >= 0 && K > 0 && Nout > 0, "xdfm_dense_fwd: bad sizes");
+  XDFM_REQUIRE((int64_t)K * Nout < ((int64_t)1 << 31), "xdfm_dense_fwd: weight too large");
   XDFM_REQUIRE(act_ok(act), "xdfm_dense_fwd: unknown activation %d", act);
   if (B == 0) return XDFM_OK;
-  const int nch = pick_nch(Nout);
-  dim3 grid((unsigned)((B + kT - 1) / kT), (unsigned)((Nout + nch - 1) / nch));
-#define CALL(N)                                                                                \
-  XDFM_LAUNCH("dense_fwd_kernel<" #N ">", stream, dense_fwd_kernel<N>, grid, dim3(kT), 0, x, w, b, B, K, \
-                     Nout, act, y)
-  DISPATCH_NCH(nch, CALL);
-#undef CALL
+  const int nt_total = (Nout + 15) / 16;
+  const unsigned rows = (unsigned)((B + 15) / 16);
+  if (nt_total >= 2) {
+    dim3 grid(rows, (unsigned)((nt_total + 1) / 2));
+    XDFM_LAUNCH("dense_fwd_mfma_kernel<2>", stream, dense_fwd_mfma_kernel<2>, grid, dim3(256), 0, x, w, b, B,
+                K, Nout, act, y);
+  } else {
+    dim3 grid(rows, 1);
+    XDFM_LAUNCH("dense_fwd_mfma_kernel<1>", stream, dense_fwd_mfma_kernel<1>, grid, dim3(256), 0, x, w, b, B,
+                K, Nout, act, y);
+  }
   XDFM_LAUNCH_CHECK();
   return XDFM_OK;
 }
 
 extern "C" int xdfm_dense_bwd_workspace_floats(int64_t B, int32_t K, int32_t Nout, size_t* floats) {
   XDFM_REQUIRE(floats && B >= 0 && K > 0 && Nout > 0, "xdfm_dense_bwd_workspace_floats: bad argument");
-  *floats = (size_t)B * Nout + (size_t)splits_for(B) * (K + 1) * Nout;
+  *floats = (size_t)splits_for(B) * (K + 1) * Nout;
   return XDFM_OK;
 }
 
@@ -227,6 +379,7 @@ extern "C" int xdfm_dense_bwd(const float* x, const float* w, const float* y, co
                               void* stream) {
   XDFM_REQUIRE(x && w && y && dy && dw && db && part, "xdfm_dense_bwd: null argument");
   XDFM_REQUIRE(B >= 0 && K > 0 && Nout > 0, "xdfm_dense_bwd: bad sizes");
+  XDFM_REQUIRE((int64_t)K * Nout < ((int64_t)1 << 31), "xdfm_dense_bwd: weight too large");
   XDFM_REQUIRE(act_ok(act), "xdfm_dense_bwd: unknown activation %d", act);
   hipStream_t st = (hipStream_t)stream;
   if (B == 0) {
@@ -234,31 +387,42 @@ extern "C" int xdfm_dense_bwd(const float* x, const float* w, const float* y, co
     XDFM_HIP(hipMemsetAsync(db, 0, (size_t)Nout * sizeof(float), st));
     return XDFM_OK;
   }
-  float* dz = part;
-  float* psum = part + (size_t)B * Nout;
-  const int64_t total = B * Nout;
-  XDFM_LAUNCH("dense_dz_kernel", st, dense_dz_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, y, dy,
-                     total, act, dz);
   const int n_splits = splits_for(B);
-  const int samples_per_split = (int)((B + n_splits - 1) / n_splits);
-  const int nch = Nout <= 4 ? pick_nch(Nout) : (Nout <= 8 ? 8 : 8);
+  const int rows_per_split = (int)((B + n_splits - 1) / n_splits);
+  const int nt_total = (Nout + 15) / 16;
+  const int ktiles = (K + 1 + 15) / 16;
   {
-    dim3 grid((unsigned)((K + 1 + 255) / 256), (unsigned)n_splits, (unsigned)((Nout + nch - 1) / nch));
-#define CALL(N)                                                                              \
-  XDFM_LAUNCH("dense_bwd_dw_kernel<" #N ">", st, dense_bwd_dw_kernel<N>, grid, dim3(256), 0, x, dz, B, K, Nout,       \
-                     samples_per_split, psum)
-    DISPATCH_NCH(nch, CALL);
-#undef CALL
-  }
-  {
+    constexpr int PT = 4;
+    if (nt_total >= 2) {
+      dim3 grid((unsigned)n_splits, (unsigned)((ktiles + 4 * PT - 1) / (4 * PT)), (unsigned)((nt_total + 1) / 2));
+      XDFM_LAUNCH("dense_bwd_dw_mfma_kernel<4, 2>", st, (dense_bwd_dw_mfma_kernel<PT, 2>), grid, dim3(256), 0,
+                  x, y, dy, B, K, Nout, act, rows_per_split, part);
+    } else {
+      dim3 grid((unsigned)n_splits, (unsigned)((ktiles + 4 * PT - 1) / (4 * PT)), 1);
+      XDFM_LAUNCH("dense_bwd_dw_mfma_kernel<4, 1>", st, (dense_bwd_dw_mfma_kernel<PT, 1>), grid, dim3(256), 0,
+                  x, y, dy, B, K, Nout, act, rows_per_split, part);
+    }
     const int64_t tot = (int64_t)(K + 1) * Nout;
-    XDFM_LAUNCH("dense_dw_reduce_kernel", st, dense_dw_reduce_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0,
-                       psum, n_splits, K, Nout, dw, db);
+    XDFM_LAUNCH("dense_dw_reduce_kernel", st, dense_dw_reduce_kernel, dim3((unsigned)((tot + 31) / 32)),
+                dim3(256), 0, part, n_splits, K, Nout, dw, db);
   }
   if (dx) {
-    const int64_t tot = B * K;
-    XDFM_LAUNCH("dense_bwd_dx_kernel", st, dense_bwd_dx_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, dz,
-                       w, B, K, Nout, accumulate_dx, dx);
+    const int S = (Nout + 3) / 4;
+    dim3 grid((unsigned)((B + 15) / 16));
+#define CALL(SM)                                                                                       \
+  XDFM_LAUNCH("dense_bwd_dx_mfma_kernel<" #SM ">", st, dense_bwd_dx_mfma_kernel<SM>, grid, dim3(256), 0, w, \
+              y, dy, B, K, Nout, act, accumulate_dx, dx)
+    if (S <= 1)
+      CALL(1);
+    else if (S <= 5)
+      CALL(5);
+    else if (S <= 16)
+      CALL(16);
+    else if (S <= 64)
+      CALL(64);
+    else
+      return xdfm::fail(XDFM_E_INVALID, "xdfm_dense_bwd: layer width %d not supported (max 256)", Nout);
+#undef CALL
   }
   XDFM_LAUNCH_CHECK();
   return XDFM_OK;
@@ -269,7 +433,8 @@ extern "C" int xdfm_cin_head_fwd(const float* pooled, const float* w, const floa
   XDFM_REQUIRE(pooled && w && bias && out, "xdfm_cin_head_fwd: null argument");
   XDFM_REQUIRE(B >= 0 && n > 0, "xdfm_cin_head_fwd: bad sizes");
   if (B == 0) return XDFM_OK;
-  XDFM_LAUNCH("cin_head_fwd_kernel", stream, cin_head_fwd_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, pooled, w, bias, B, n, out);
+  XDFM_LAUNCH("cin_head_fwd_kernel", stream, cin_head_fwd_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0,
+              pooled, w, bias, B, n, out);
   XDFM_LAUNCH_CHECK();
   return XDFM_OK;
 }
@@ -282,8 +447,8 @@ extern "C" int xdfm_cin_head_bwd(const float* pooled, const float* w, const floa
   hipStream_t st = (hipStream_t)stream;
   if (B > 0) {
     const int64_t tot = B * n;
-    XDFM_LAUNCH("cin_head_dpooled_kernel", st, cin_head_dpooled_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, w,
-                       g, B, n, d_pooled);
+    XDFM_LAUNCH("cin_head_dpooled_kernel", st, cin_head_dpooled_kernel, dim3((unsigned)((tot + 255) / 256)),
+                dim3(256), 0, w, g, B, n, d_pooled);
   }
   // dw, db: the weight-gradient path of a [n] -> [1] identity layer whose dy is g
   return xdfm_dense_bwd(pooled, w, g /* y unused for identity */, g, B, n, 1, XDFM_ACT_IDENTITY,
