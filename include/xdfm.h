@@ -174,7 +174,8 @@ typedef struct xdfm_opt_args {
  *   mode 0 (sparse_rows): apply `opt` to the touched rows of table (+slots) and lin_w in place;
  *   mode 1 (scatter)    : store the sums into grad_table[N,D] / grad_lin[N] (rows of untouched
  *                         ids are left as they are: the caller keeps them zero).
- *   pieces[nnz*D (+nnz)] float scratch, long_list[nnz+1] int32 scratch (count in [0]).
+ *   pieces: float scratch of 2*(nnz/64 + 1)*(D + 1) elements (partial sums of the segments that
+ *   cross a 64-token chunk boundary); long_list: unused, may be NULL.
  *   d_emb[B,F,D]; g_logit[B] and fm_sum[B,D] only when the FM / linear parts are on. */
 int xdfm_embed_bwd(int32_t mode, float* table, float* slot_m, float* slot_v, float* lin_w,
                    float* lin_m, float* lin_v, float* grad_table, float* grad_lin, int64_t N,

@@ -20,7 +20,6 @@
 namespace {
 
 constexpr int kWave = 64;
-constexpr int kPieceLen = 64;  // sorted positions per piece boundary in the backward
 
 template <int VEC>
 struct Vec;
@@ -240,9 +239,7 @@ struct BwdArgs {
   const float *weights, *d_emb, *g_logit, *fm_sum;
   int use_fm;
   OptDev opt;
-  float* pieces;      // [nnz][D]
-  float* pieces_lin;  // [nnz]
-  int32_t* long_list; // [0]=count, [1..] head positions of segments cut by a piece boundary
+  float* pieces;      // head[nchunks][D], tail[nchunks][D], head_lin[nchunks], tail_lin[nchunks]
 };
 
 template <int VEC, int MODE>
@@ -261,91 +258,206 @@ __device__ __forceinline__ void finish_row(const BwdArgs& a, int id, int c, cons
   }
 }
 
-// One lane group (LPR lanes) per sorted position i.  Position i starts a "piece" when it
-// is the head of its id segment or a multiple of kPieceLen; the group sums the piece's
-// token contributions in sorted order.  A segment that is a single piece is finished on
-// the spot (optimizer fused); otherwise the piece sum is parked in `pieces` and the head
-// is queued for the second kernel, which adds the pieces in position order.  The sum of
-// a row therefore has one fixed association, whatever the scheduling.
+// Segment sum over the id-sorted token list, one wave per chunk of 64 sorted positions.
+//  * lane = position: loads key / token / row / weight once, and runs a 6-step segmented
+//    scan of the linear-part scalar g*w.
+//  * the D-wide contributions are handled R = 64/LPR positions per pass (LPR = D/VEC lanes
+//    own one row, VEC floats each): gather, then a log2(R)-step segmented inclusive scan
+//    across the lane groups with cross-lane shuffles; a carry links the passes.
+//  * a segment that lies inside the chunk is finished on the spot (optimizer fused).  The
+//    partial sum of a segment that comes in from the previous chunk goes to head[chunk], of
+//    one that starts here and runs on into the next chunk to tail[chunk]; the second kernel
+//    adds tail[c0] + head[c0+1] + ... in chunk order for each such segment.
+// Every sum has one fixed association: bit-identical from run to run, no float atomics.
+constexpr int kChunk = 64;
+
+template <int VEC>
+__device__ __forceinline__ void shfl_vec(const float (&v)[VEC], int src, float (&o)[VEC]) {
+#pragma unroll
+  for (int k = 0; k < VEC; ++k) o[k] = __shfl(v[k], src);
+}
+
 template <int VEC, int MODE>
 __global__ __launch_bounds__(256) void embed_bwd_kernel(BwdArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int64_t chunk = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t p0 = chunk * kChunk;
+  if (p0 >= a.nnz) return;  // wave-uniform; the kernel has no barrier
   const int LPR = a.D / VEC;
-  const int GPB = 256 / LPR;
-  const int grp = threadIdx.x / LPR;
-  const int c = threadIdx.x - grp * LPR;
-  const int64_t i = (int64_t)blockIdx.x * GPB + grp;
-  if (grp >= GPB || i >= a.nnz) return;
-  const int id = a.sorted_ids[i];
-  const bool head = (i == 0) || (a.sorted_ids[i - 1] != id);
-  if (!head && (i % kPieceLen) != 0) return;
-
-  float acc[VEC];
-#pragma unroll
-  for (int v = 0; v < VEC; ++v) acc[v] = 0.f;
-  float lacc = 0.f;
-  float e[VEC];
-  if (a.use_fm) load_vec<VEC>(a.table + (int64_t)id * a.D + c * VEC, e);
+  const int R = 64 / LPR;
+  const int g = lane / LPR;
+  const int c = lane - g * LPR;
+  const int nvalid = (int)((a.nnz - p0 < kChunk) ? (a.nnz - p0) : kChunk);
   const bool need_g = a.use_fm || a.lin_w != nullptr;
-  int64_t j = i;
-  do {
-    const int t = a.sorted_tok[j];
-    const int r = a.tok_row[t];
-    const float w = a.weights[t];
-    float de[VEC];
-    load_vec<VEC>(a.d_emb + (int64_t)r * a.D + c * VEC, de);
-#pragma unroll
-    for (int v = 0; v < VEC; ++v) acc[v] = fmaf(w, de[v], acc[v]);
-    if (need_g) {
-      const int b = r / a.F;
-      const float gw = a.g_logit[b] * w;
-      if (a.use_fm) {
-        float s[VEC];
-        load_vec<VEC>(a.fm_sum + (int64_t)b * a.D + c * VEC, s);
-#pragma unroll
-        for (int v = 0; v < VEC; ++v) acc[v] = fmaf(gw, s[v] - w * e[v], acc[v]);
-      }
-      lacc += gw;
-    }
-    ++j;
-  } while (j < a.nnz && a.sorted_ids[j] == id && (j % kPieceLen) != 0);
 
-  const bool complete = head && (j >= a.nnz || a.sorted_ids[j] != id);
-  if (complete) {
-    finish_row<VEC, MODE>(a, id, c, acc, lacc);
-  } else {
-    store_vec<VEC>(a.pieces + i * a.D + c * VEC, acc);
-    if (c == 0) {
-      a.pieces_lin[i] = lacc;
-      if (head) {
-        const int slot = atomicAdd(a.long_list, 1);
-        a.long_list[1 + slot] = (int32_t)i;
+  // ---- per-position metadata
+  const bool pv = lane < nvalid;
+  const int64_t p = p0 + (pv ? lane : 0);
+  const int key = pv ? a.sorted_ids[p] : -1;
+  const int tok = a.sorted_tok[p];
+  const int row = a.tok_row[tok];
+  const float w = pv ? a.weights[tok] : 0.f;
+  float gw = 0.f;
+  if (need_g) gw = pv ? a.g_logit[row / a.F] * w : 0.f;
+  const int prev_key = (p0 > 0) ? a.sorted_ids[p0 - 1] : -1;
+  const int next_key = (p0 + kChunk < a.nnz) ? a.sorted_ids[p0 + kChunk] : -2;
+  const int first_key = __shfl(key, 0);
+  const int last_key = __shfl(key, nvalid - 1);
+  const bool cont_prev = prev_key == first_key;
+  const bool cont_next = next_key == last_key;
+  const int key_after = __shfl_down(key, 1);  // key of position lane+1 (garbage for lane 63)
+
+  // ---- linear part: segmented inclusive scan of g*w over the 64 positions
+  float lsum = gw;
+  if (a.lin_w != nullptr) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const float o = __shfl_up(lsum, d);
+      const int ko = __shfl_up(key, d);
+      if (lane >= d && ko == key) lsum += o;
+    }
+  }
+
+  float* head_vec = a.pieces;
+  const int64_t nchunks = (a.nnz + kChunk - 1) / kChunk;
+  float* tail_vec = head_vec + nchunks * a.D;
+  float* head_lin = tail_vec + nchunks * a.D;
+  float* tail_lin = head_lin + nchunks;
+
+  float carry[VEC];
+#pragma unroll
+  for (int k = 0; k < VEC; ++k) carry[k] = 0.f;
+  int carry_key = -3;
+  const int npass = (nvalid + R - 1) / R;
+  for (int t = 0; t < npass; ++t) {
+    const int q = t * R + g;                 // position of this lane group
+    const bool on = g < R && q < nvalid;
+    const int qs = on ? q : 0;
+    const int key_raw = __shfl(key, qs);  // every lane takes part in the shuffle
+    const int key_q = on ? key_raw : -1;
+    const int row_q = __shfl(row, qs);
+    const float w_q = __shfl(w, qs);
+    const float gw_q = __shfl(gw, qs);
+    const int keyn_q = __shfl(key_after, qs);
+    const float lsum_q = __shfl(lsum, qs);
+    float v[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) v[k] = 0.f;
+    if (on) {
+      float de[VEC];
+      load_vec<VEC>(a.d_emb + (int64_t)row_q * a.D + c * VEC, de);
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) v[k] = w_q * de[k];
+      if (a.use_fm) {
+        float e[VEC], sfm[VEC];
+        load_vec<VEC>(a.table + (int64_t)key_q * a.D + c * VEC, e);
+        load_vec<VEC>(a.fm_sum + (int64_t)(row_q / a.F) * a.D + c * VEC, sfm);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) v[k] = fmaf(gw_q, sfm[k] - w_q * e[k], v[k]);
+      }
+      if (g == 0 && carry_key == key_q) {
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) v[k] += carry[k];
+      }
+    }
+    // segmented inclusive scan across the lane groups
+    for (int d = 1; d < R; d <<= 1) {
+      float o[VEC];
+      const int src = lane - d * LPR;
+      shfl_vec<VEC>(v, src < 0 ? lane : src, o);
+      const int ko = __shfl(key_q, src < 0 ? lane : src);
+      if (on && g >= d && ko == key_q) {
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) v[k] += o[k];
+      }
+    }
+    // carry for the next pass = the last group's running sum
+    {
+      const int src = (R - 1) * LPR + c;
+      shfl_vec<VEC>(v, src < 64 ? src : lane, carry);
+      carry_key = __shfl(key_q, (R - 1) * LPR);
+    }
+    if (on) {
+      const bool chunk_end = q == nvalid - 1;
+      const bool seg_end = chunk_end || keyn_q != key_q;
+      if (seg_end) {
+        if (cont_prev && key_q == first_key) {
+          store_vec<VEC>(head_vec + chunk * a.D + c * VEC, v);
+          if (c == 0) head_lin[chunk] = lsum_q;
+        } else if (chunk_end && cont_next) {
+          store_vec<VEC>(tail_vec + chunk * a.D + c * VEC, v);
+          if (c == 0) tail_lin[chunk] = lsum_q;
+        } else {
+          finish_row<VEC, MODE>(a, key_q, c, v, lsum_q);
+        }
       }
     }
   }
 }
 
+// One wave per chunk boundary.  The wave whose boundary is the first one a segment crosses
+// adds the segment's pieces in chunk order and finishes the row.
 template <int VEC, int MODE>
 __global__ __launch_bounds__(256) void embed_bwd_long_kernel(BwdArgs a) {
-  const int LPR = a.D / VEC;
-  const int GPB = 256 / LPR;
-  const int grp = threadIdx.x / LPR;
-  const int c = threadIdx.x - grp * LPR;
-  const int64_t e = (int64_t)blockIdx.x * GPB + grp;
-  if (grp >= GPB || e >= a.long_list[0]) return;
-  const int64_t i = a.long_list[1 + e];
-  const int id = a.sorted_ids[i];
-  float acc[VEC];
-  load_vec<VEC>(a.pieces + i * a.D + c * VEC, acc);
-  float lacc = a.pieces_lin[i];
-  for (int64_t k = (i / kPieceLen + 1) * kPieceLen; k < a.nnz && a.sorted_ids[k] == id;
-       k += kPieceLen) {
-    float p[VEC];
-    load_vec<VEC>(a.pieces + k * a.D + c * VEC, p);
-#pragma unroll
-    for (int v = 0; v < VEC; ++v) acc[v] += p[v];
-    lacc += a.pieces_lin[k];
+  const int lane = threadIdx.x & 63;
+  const int64_t c1 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6) + 1;  // boundary between c1-1 and c1
+  const int64_t nchunks = (a.nnz + kChunk - 1) / kChunk;
+  if (c1 >= nchunks) return;
+  const int key = a.sorted_ids[c1 * kChunk];
+  if (a.sorted_ids[c1 * kChunk - 1] != key) return;                           // no segment crosses here
+  if (c1 >= 2 && a.sorted_ids[(c1 - 1) * kChunk - 1] == key) return;          // an earlier boundary owns it
+  // last chunk of the segment: first chunk ce >= c1 whose successor does not start with key
+  int64_t ce = c1;
+  for (;;) {
+    const int64_t cc = ce + lane;
+    const bool cont = (cc + 1 < nchunks) && a.sorted_ids[(cc + 1) * kChunk] == key;
+    const unsigned long long m = __ballot(!cont);
+    if (m) {
+      ce += __ffsll((long long)m) - 1;
+      break;
+    }
+    ce += 64;
   }
-  finish_row<VEC, MODE>(a, id, c, acc, lacc);
+  const float* head_vec = a.pieces;
+  const float* tail_vec = head_vec + nchunks * a.D;
+  const float* head_lin = tail_vec + nchunks * a.D;
+  const float* tail_lin = head_lin + nchunks;
+  const int LPR = a.D / VEC;
+  const int R = 64 / LPR;
+  const int g = lane / LPR;
+  const int c = lane - g * LPR;
+  // group g adds pieces g, g+R, ... (piece 0 = tail[c1-1], piece k = head[c1+k-1]) in order
+  const int64_t npieces = ce - c1 + 2;
+  float v[VEC];
+#pragma unroll
+  for (int k = 0; k < VEC; ++k) v[k] = 0.f;
+  if (g < R) {
+    for (int64_t k = g; k < npieces; k += R) {
+      float pv[VEC];
+      const float* src = (k == 0) ? tail_vec + (c1 - 1) * a.D : head_vec + (c1 + k - 1) * a.D;
+      load_vec<VEC>(src + c * VEC, pv);
+#pragma unroll
+      for (int kx = 0; kx < VEC; ++kx) v[kx] += pv[kx];
+    }
+  }
+  // add the groups in a fixed tree
+  for (int d = 1; d < R; d <<= 1) {
+    float o[VEC];
+    const int src = lane + d * LPR;
+    shfl_vec<VEC>(v, src < 64 ? src : lane, o);
+    if (g + d < R && (g & (2 * d - 1)) == 0) {
+#pragma unroll
+      for (int kx = 0; kx < VEC; ++kx) v[kx] += o[kx];
+    }
+  }
+  float lsum = 0.f;
+  if (a.lin_w != nullptr) {
+    for (int64_t k = lane; k < npieces; k += 64) lsum += (k == 0) ? tail_lin[c1 - 1] : head_lin[c1 + k - 1];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) lsum += __shfl_down(lsum, d);
+    lsum = __shfl(lsum, 0);
+  }
+  if (g == 0) finish_row<VEC, MODE>(a, key, c, v, lsum);
 }
 
 __global__ void clear_rows_kernel(float* __restrict__ grad_table, float* __restrict__ grad_lin,
@@ -476,7 +588,8 @@ extern "C" int xdfm_embed_bwd(int32_t mode, float* table, float* slot_m, float* 
   XDFM_REQUIRE(mode == 0 || mode == 1, "xdfm_embed_bwd: mode must be 0 or 1");
   XDFM_REQUIRE(N > 0 && D > 0 && F > 0 && B >= 0 && nnz >= 0, "xdfm_embed_bwd: bad sizes");
   if (nnz == 0) return XDFM_OK;
-  XDFM_REQUIRE(sorted_ids && sorted_tok && tok_row && weights && d_emb && pieces && long_list,
+  (void)long_list;  // kept in the signature; the chunked scheme needs no queue
+  XDFM_REQUIRE(sorted_ids && sorted_tok && tok_row && weights && d_emb && pieces,
                "xdfm_embed_bwd: null argument");
   XDFM_REQUIRE(!use_fm || (g_logit && fm_sum && table), "xdfm_embed_bwd: FM needs g_logit, fm_sum, table");
   BwdArgs a;
@@ -521,18 +634,14 @@ extern "C" int xdfm_embed_bwd(int32_t mode, float* table, float* slot_m, float* 
   a.fm_sum = fm_sum;
   a.use_fm = use_fm;
   a.pieces = pieces;
-  a.pieces_lin = pieces + (size_t)nnz * D;
-  a.long_list = long_list;
 
   const int vec = pick_vec(D);
   const int lpr = D / vec;
-  XDFM_REQUIRE(lpr <= 256, "xdfm_embed_bwd: dim %d not supported", D);
-  const int gpb = 256 / lpr;
+  XDFM_REQUIRE(lpr <= 64, "xdfm_embed_bwd: dim %d not supported (needs D/%d <= 64)", D, vec);
   hipStream_t st = (hipStream_t)stream;
-  XDFM_HIP(hipMemsetAsync(long_list, 0, sizeof(int32_t), st));
-  const unsigned blocks = (unsigned)((nnz + gpb - 1) / gpb);
-  const int64_t max_long = nnz / kPieceLen + 1;
-  const unsigned blocks_long = (unsigned)((max_long + gpb - 1) / gpb);
+  const int64_t nchunks = (nnz + kChunk - 1) / kChunk;
+  const unsigned blocks = (unsigned)((nchunks + 3) / 4);
+  const unsigned blocks_long = (unsigned)((nchunks + 3) / 4);  // boundaries 1 .. nchunks-1
 #define LAUNCH(V, M)                                                                          \
   do {                                                                                        \
     XDFM_LAUNCH("embed_bwd_kernel<" #V ", " #M ">", st, (embed_bwd_kernel<V, M>), dim3(blocks), dim3(256), 0, a);          \

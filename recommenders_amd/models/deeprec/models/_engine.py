@@ -67,7 +67,7 @@ class DeviceBatch(object):
     """One mini-batch resident in HBM (the dnn view of the iterator as CSR)."""
 
     __slots__ = ("B", "nnz", "labels", "ids", "weights", "row_ptr", "tok_row", "sorted_ids",
-                 "sorted_tok", "planned")
+                 "sorted_tok", "planned", "plan_event")
 
 
 class XDeepFMEngine(object):
@@ -172,6 +172,7 @@ class XDeepFMEngine(object):
         self._eval_ws = None
         # name -> [(start_event, end_event)]: filled when bench.py asks for in-situ kernel times
         self.kernel_events = None
+        self._side_stream = None
         self.init_parameters(seed)
 
     # ------------------------------------------------------------------ params
@@ -339,7 +340,7 @@ class XDeepFMEngine(object):
             _lib.check(self.lib.xdfm_dense_bwd_workspace_floats(B, last, 1, ctypes.byref(sz)))
             part_floats = max(part_floats, sz.value)
         buf("part", max(part_floats, 1))
-        buf("pieces", nnz * (D + 1) + 1)
+        buf("pieces", 2 * (nnz // 64 + 1) * (D + 1))
         buf("long_list", nnz + 2, dtype=torch.int32)
         _lib.check(self.lib.xdfm_embed_plan_workspace_bytes(nnz, self.N, ctypes.byref(sz)))
         buf("plan_ws", sz.value, dtype=torch.uint8)
@@ -377,15 +378,37 @@ class XDeepFMEngine(object):
         )
         b.sorted_ids = b.sorted_tok = None
         b.planned = False
+        b.plan_event = None
         return b
+
+    def plan_async(self, batch):
+        """Start the id sort of `batch` on a side stream so that it runs beside the forward
+        pass (it depends on the ids only); update() waits for it."""
+        if batch.planned:
+            return
+        self._ensure_ws(batch.B, batch.nnz)
+        main = torch.cuda.current_stream(self.device)
+        if self._side_stream is None:
+            self._side_stream = torch.cuda.Stream(device=self.device)
+        # allocated under the main stream, which is also where they are consumed and freed
+        batch.sorted_ids = torch.empty((max(batch.nnz, 1),), dtype=torch.int32, device=self.device)
+        batch.sorted_tok = torch.empty((max(batch.nnz, 1),), dtype=torch.int32, device=self.device)
+        ready = torch.cuda.Event()
+        ready.record(main)
+        self._side_stream.wait_event(ready)
+        with torch.cuda.stream(self._side_stream):
+            self.plan(batch)
+            batch.plan_event = torch.cuda.Event()
+            batch.plan_event.record(self._side_stream)
 
     def plan(self, batch):
         """Sort the batch's tokens by feature id (needed by the backward only)."""
         if batch.planned:
             return
         self._ensure_ws(batch.B, batch.nnz)
-        batch.sorted_ids = torch.empty((max(batch.nnz, 1),), dtype=torch.int32, device=self.device)
-        batch.sorted_tok = torch.empty((max(batch.nnz, 1),), dtype=torch.int32, device=self.device)
+        if batch.sorted_ids is None:
+            batch.sorted_ids = torch.empty((max(batch.nnz, 1),), dtype=torch.int32, device=self.device)
+            batch.sorted_tok = torch.empty((max(batch.nnz, 1),), dtype=torch.int32, device=self.device)
         ws = self.ws["plan_ws"]
         ev = self._mark("embed_plan")
         _lib.check(
@@ -557,6 +580,9 @@ class XDeepFMEngine(object):
         clip = float(hp.max_grad_norm) if hp.is_clip_norm else 0.0
         use_lin, use_fm = bool(hp.use_Linear_part), bool(hp.use_FM_part)
         self.plan(batch)
+        if batch.plan_event is not None:
+            torch.cuda.current_stream(self.device).wait_event(batch.plan_event)
+            batch.plan_event = None
         sparse = self.embedding_update == "sparse_rows"
         opt_sparse = self._opt_args()
         ev = self._mark("embed_bwd")
@@ -632,6 +658,7 @@ class XDeepFMEngine(object):
 
     def train_step(self, batch):
         """One optimisation step; returns (total_loss, data_loss) as 0-dim device tensors."""
+        self.plan_async(batch)
         self.forward(batch, with_loss=True, with_grad=True)
         self.backward(batch)
         self.update(batch)
