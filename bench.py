@@ -171,7 +171,7 @@ def main():
     def step(i):
         labels, idx, ids, w = resident[i % n_batches]
         batch = eng.make_batch(labels, idx, ids, w)  # CSR offsets built on the device
-        return eng.train_step(batch)
+        return eng.train_step(batch)  # N > 1: includes the all-to-all exchanges and the all-reduce
 
     def fence():
         torch.cuda.synchronize()
@@ -222,7 +222,7 @@ def main():
                         "share_of_kernel_time": round(v["ms"] / total_ms, 3)}
             break
         kernels = {}
-        for name, v in ranked[:12]:
+        for name, v in ranked[:40]:
             entry = {"avg_us": round(v["ms"] / v["n"] * 1e3, 2), "per_step": round(v["n"] / args.steps, 2)}
             bound, work = kernel_model(name, hp, nnz, uniq)
             if bound == "hbm":

@@ -269,11 +269,14 @@ int xdfm_cin_head_bwd(const float* pooled, const float* w, const float* g, int64
  *   classification != 0: pred = sigmoid(logit) else pred = logit.
  *   labels[B]; outputs logit[B], pred[B], g_logit[B] (NULL: forward only),
  *   loss: device float (mean data loss; NULL: skip), scratch[1024] floats.
+ *   mean_count: number of samples the mean runs over: 0 or B on one GPU; the global batch
+ *   size when the batch is split over ranks (then `loss` is this rank's share of the mean
+ *   and g_logit is scaled accordingly; build extra for the sharded path).
  * ---------------------------------------------------------------------- */
 int xdfm_logit_loss(const float* part0, const float* part1, const float* part2,
                     const float* part3, const float* bias, const float* labels, int64_t B,
-                    int32_t classification, int32_t loss_kind, float* logit, float* pred,
-                    float* g_logit, float* loss, float* scratch, void* stream);
+                    int64_t mean_count, int32_t classification, int32_t loss_kind, float* logit,
+                    float* pred, float* g_logit, float* loss, float* scratch, void* stream);
 
 /* ------------------------------------------------------------------------
  * Fused evaluation: AUC (ties grouped, == sklearn.roc_auc_score) and logloss

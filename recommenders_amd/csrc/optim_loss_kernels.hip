@@ -159,6 +159,7 @@ __global__ __launch_bounds__(256) void dense_update_kernel(SegTable tab, OptDev 
 struct LossArgs {
   const float *part[4], *bias, *labels;
   long long B;
+  long long mean_count;  // samples the mean runs over (B, or the global batch under data parallelism)
   int classification, loss_kind;
   float *logit, *pred, *g_logit;
 };
@@ -224,14 +225,14 @@ __global__ __launch_bounds__(256) void loss_bwd_kernel(LossArgs a, const float* 
   s = block_sum<float, 256>(s, sh);
   __shared__ float loss_sh;
   if (threadIdx.x == 0) {
-    float mean = s / (float)a.B;
+    float mean = s / (float)a.mean_count;
     loss_sh = (a.loss_kind == XDFM_LOSS_SQUARE) ? sqrtf(mean) : mean;
     if (loss_out && blockIdx.x == 0) *loss_out = loss_sh;
   }
   __syncthreads();
   if (!a.g_logit) return;
   const float loss = loss_sh;
-  const float invB = 1.f / (float)a.B;
+  const float invB = 1.f / (float)a.mean_count;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < a.B;
        i += (long long)gridDim.x * 256) {
     const float z = a.logit[i], p = a.pred[i], y = a.labels[i];
@@ -443,11 +444,15 @@ extern "C" int xdfm_dense_update(float* param, const float* grad, float* slot_m,
 
 extern "C" int xdfm_logit_loss(const float* part0, const float* part1, const float* part2,
                                const float* part3, const float* bias, const float* labels, int64_t B,
-                               int32_t classification, int32_t loss_kind, float* logit, float* pred,
-                               float* g_logit, float* loss, float* scratch, void* stream) {
+                               int64_t mean_count, int32_t classification, int32_t loss_kind,
+                               float* logit, float* pred, float* g_logit, float* loss, float* scratch,
+                               void* stream) {
   XDFM_REQUIRE(logit && pred && scratch, "xdfm_logit_loss: null output");
   XDFM_REQUIRE(part0 || part1 || part2 || part3, "xdfm_logit_loss: no logit part given");
   XDFM_REQUIRE(B > 0, "xdfm_logit_loss: empty batch");
+  XDFM_REQUIRE(mean_count == 0 || mean_count >= B, "xdfm_logit_loss: mean_count must be 0 or >= B");
+  XDFM_REQUIRE(mean_count == 0 || mean_count == B || loss_kind != XDFM_LOSS_SQUARE,
+               "xdfm_logit_loss: square_loss (a root of a mean) cannot be split over ranks");
   XDFM_REQUIRE(loss_kind >= XDFM_LOSS_LOG && loss_kind <= XDFM_LOSS_SQUARE,
                "xdfm_logit_loss: unknown loss %d", loss_kind);
   XDFM_REQUIRE(labels || (!g_logit && !loss), "xdfm_logit_loss: loss/gradient need labels");
@@ -460,6 +465,7 @@ extern "C" int xdfm_logit_loss(const float* part0, const float* part1, const flo
   a.bias = bias;
   a.labels = labels;
   a.B = B;
+  a.mean_count = mean_count > 0 ? mean_count : B;
   a.classification = classification;
   a.loss_kind = loss_kind;
   a.logit = logit;

@@ -67,11 +67,12 @@ class DeviceBatch(object):
     """One mini-batch resident in HBM (the dnn view of the iterator as CSR)."""
 
     __slots__ = ("B", "nnz", "labels", "ids", "weights", "row_ptr", "tok_row", "sorted_ids",
-                 "sorted_tok", "planned", "plan_event")
+                 "sorted_tok", "planned", "plan_event", "src_table", "src_lin", "src_ids", "src_N", "route", "owner_sorted_ids", "owner_sorted_tok",
+                 "owner_event")
 
 
 class XDeepFMEngine(object):
-    def __init__(self, hp, device=None, seed=None, embedding_update="dense_exact"):
+    def __init__(self, hp, device=None, seed=None, embedding_update="dense_exact", table_rows=None):
         if not torch.cuda.is_available():
             raise RuntimeError(
                 "recommenders_amd needs a ROCm GPU: the xDeepFM path runs in HIP kernels "
@@ -82,7 +83,9 @@ class XDeepFMEngine(object):
             "cuda", torch.cuda.current_device()
         )
         self.lib = _lib.lib
-        self.N, self.F, self.D = int(hp.FEATURE_COUNT), int(hp.FIELD_COUNT), int(hp.dim)
+        # table_rows: rows held by this process (the sharded engine keeps FEATURE_COUNT / world)
+        self.N = int(hp.FEATURE_COUNT) if table_rows is None else int(table_rows)
+        self.F, self.D = int(hp.FIELD_COUNT), int(hp.dim)
         if hp.fast_CIN_d > 0:
             raise NotImplementedError("fast_CIN_d > 0 (xDeepFM.py:295-451) is not built yet")
         if hp.enable_BN is True:
@@ -173,6 +176,7 @@ class XDeepFMEngine(object):
         # name -> [(start_event, end_event)]: filled when bench.py asks for in-situ kernel times
         self.kernel_events = None
         self._side_stream = None
+        self.mean_count = 0  # set by the sharded engine: global batch size of the step
         self.init_parameters(seed)
 
     # ------------------------------------------------------------------ params
@@ -379,6 +383,9 @@ class XDeepFMEngine(object):
         b.sorted_ids = b.sorted_tok = None
         b.planned = False
         b.plan_event = None
+        # the sharded engine points these at the rows it fetched from their owners
+        b.src_table = b.src_lin = b.src_ids = None
+        b.src_N = 0
         return b
 
     def plan_async(self, batch):
@@ -437,8 +444,11 @@ class XDeepFMEngine(object):
         ev = self._mark("embed_fwd")
         _lib.check(
             lib.xdfm_embed_fwd(
-                _ptr(self.table), _ptr(self.lin_w) if use_lin else None, self.N, D, F, B,
-                _ptr(batch.row_ptr), _ptr(batch.ids), _ptr(batch.weights), batch.nnz,
+                _ptr(batch.src_table if batch.src_table is not None else self.table),
+                _ptr(batch.src_lin if batch.src_table is not None else self.lin_w) if use_lin else None,
+                batch.src_N if batch.src_table is not None else self.N, D, F, B,
+                _ptr(batch.row_ptr), _ptr(batch.src_ids if batch.src_table is not None else batch.ids),
+                _ptr(batch.weights), batch.nnz,
                 _ptr(ws["emb_out"]), _ptr(ws["lin_out"]) if use_lin else None,
                 _ptr(ws["fm_out"]) if use_fm else None, _ptr(ws["fm_sum"]) if use_fm else None,
                 _ptr(self.err_flag), st,
@@ -489,7 +499,7 @@ class XDeepFMEngine(object):
                 _ptr(ws["cin_out"]) if hp.use_CIN_part else None,
                 _ptr(ws["dnn_out"]) if hp.use_DNN_part else None,
                 _ptr(self.views["lin_b"]) if use_lin else None,
-                _ptr(batch.labels) if with_loss else None, B,
+                _ptr(batch.labels) if with_loss else None, B, int(self.mean_count or 0),
                 1 if hp.method == "classification" else 0, _LOSS[hp.loss], _ptr(ws["logit"]),
                 _ptr(ws["pred"]), _ptr(ws["g_logit"]) if with_grad else None,
                 _ptr(self.data_loss) if with_loss else None, _ptr(self.loss_scratch), st,
@@ -569,14 +579,23 @@ class XDeepFMEngine(object):
         return _lib.OptArgs(self.opt_kind, float(hp.learning_rate), 0.9, 0.999, 1e-8,
                             float(self.b1p), float(self.b2p), float(l2), float(l1), float(clip))
 
-    def update(self, batch):
-        """apply_gradients (base_model.py:305-322) for every variable + regular_loss
-        (base_model.py:264-272, value before the update) into self.reg_loss."""
-        hp, lib, ws, st = self.hp, self.lib, self.ws, self._stream()
+    def _advance_step(self):
         self.step += 1
         if self.opt_kind == 1:
             self.b1p = np.float32(self.b1p * np.float32(0.9))
             self.b2p = np.float32(self.b2p * np.float32(0.999))
+
+    def update(self, batch):
+        """apply_gradients (base_model.py:305-322) for every variable + regular_loss
+        (base_model.py:264-272, value before the update) into self.reg_loss."""
+        self._advance_step()
+        first = self._update_embedding(batch)
+        self._update_dense(first)
+
+    def _update_embedding(self, batch):
+        """Table / lin_w step from the sorted-key segment sum.  Returns True when reg_loss has
+        not been written yet (the dense update then writes instead of accumulating)."""
+        hp, lib, ws, st = self.hp, self.lib, self.ws, self._stream()
         clip = float(hp.max_grad_norm) if hp.is_clip_norm else 0.0
         use_lin, use_fm = bool(hp.use_Linear_part), bool(hp.use_FM_part)
         self.plan(batch)
@@ -600,7 +619,6 @@ class XDeepFMEngine(object):
             )
         )
         self._done(ev)
-        ev_upd = self._mark("dense_update")
         first = True  # the first dense_update writes reg_loss, the others accumulate
         if not sparse:
             one = np.asarray([0, self.N * self.D], dtype=np.int64)
@@ -630,6 +648,13 @@ class XDeepFMEngine(object):
                 lib.xdfm_embed_clear_rows(_ptr(self.grad_table), _ptr(self.grad_lin) if use_lin else None,
                                           self.D, _ptr(batch.sorted_ids), batch.nnz, st)
             )
+        return first
+
+    def _update_dense(self, first=True):
+        """Optimizer step of the dense (replicated) parameters from self.dense_grad."""
+        hp, lib, st = self.hp, self.lib, self._stream()
+        clip = float(hp.max_grad_norm) if hp.is_clip_norm else 0.0
+        ev_upd = self._mark("dense_update")
         n_seg = len(self.dense_shapes)
         if n_seg:
             seg = self._seg
