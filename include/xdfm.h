@@ -165,7 +165,16 @@ typedef struct xdfm_opt_args {
   float l2;           /* coefficient of sum(p^2)/2, gradient l2*p */
   float l1;           /* coefficient of sum|p|, gradient l1*sign(p) */
   float clip_norm;    /* >0: per-tensor tf.clip_by_norm(g, clip_norm); 0: off */
+  int32_t reserved;   /* keeps the pointer below 8-byte aligned; set to 0 */
+  /* Optional device scalars (NULL: use beta1_power / beta2_power above).  opt_state[2] is the
+   * Adam step size lr*sqrt(1-beta2^t)/(1-beta1^t) kept up to date by xdfm_opt_advance; with it
+   * no host value changes from step to step, so a step can be captured in a HIP graph. */
+  const float* opt_state;
 } xdfm_opt_args;
+
+/* opt_state[4] = {beta1^t, beta2^t, step size, t}: advance t by one (one tiny kernel).
+ * Initialise the buffer to {1, 1, 0, 0} before the first step.  Build extra. */
+int xdfm_opt_advance(float* opt_state, float lr, float beta1, float beta2, void* stream);
 
 /* Segment sum of the per-token gradient contributions
  *     c_j = w_j*d_emb[row_j,:] + g[b_j]*w_j*(fm_sum[b_j,:] - w_j*table[id_j,:])   (FM term optional)

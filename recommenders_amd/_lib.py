@@ -45,6 +45,8 @@ class OptArgs(ctypes.Structure):
         ("l2", ctypes.c_float),
         ("l1", ctypes.c_float),
         ("clip_norm", ctypes.c_float),
+        ("reserved", ctypes.c_int32),
+        ("opt_state", ctypes.c_void_p),
     ]
 
 
@@ -83,6 +85,7 @@ SIGNATURES = {
     "xdfm_embed_bwd": [_I32, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I32, _I32, _I64, _P, _P, _P,
                        _P, _I64, _P, _P, _P, _I32, ctypes.POINTER(OptArgs), _P, _P, _P],
     "xdfm_embed_clear_rows": [_P, _P, _I32, _P, _I64, _P],
+    "xdfm_opt_advance": [_P, ctypes.c_float, ctypes.c_float, ctypes.c_float, _P],
     "xdfm_dense_update": [_P, _P, _P, _P, _I32, _P, _P, _P, _P, ctypes.POINTER(OptArgs), _P, _P,
                           _I32, _P],
     "xdfm_cin_fwd": [_P, _P, _P, _I64, _I32, _I32, _I32, _I32, _I32, _I32, _P, _P, _I32, _I32, _P],

@@ -196,6 +196,7 @@ inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 struct OptDev {
   int kind;
   float lr, alpha, one_minus_b1, one_minus_b2, eps;
+  const float* state;  // device {b1^t, b2^t, step size, t} or null
 };
 
 template <int VEC>
@@ -204,6 +205,7 @@ __device__ __forceinline__ void apply_row(const OptDev& o, float* p, float* m, f
   float pv[VEC];
   load_vec<VEC>(p, pv);
   if (o.kind == XDFM_OPT_ADAM) {
+    const float alpha = o.state ? o.state[2] : o.alpha;
     float mv[VEC], vv[VEC];
     load_vec<VEC>(m, mv);
     load_vec<VEC>(v, vv);
@@ -211,7 +213,7 @@ __device__ __forceinline__ void apply_row(const OptDev& o, float* p, float* m, f
     for (int i = 0; i < VEC; ++i) {
       mv[i] = mv[i] + (g[i] - mv[i]) * o.one_minus_b1;
       vv[i] = vv[i] + (g[i] * g[i] - vv[i]) * o.one_minus_b2;
-      pv[i] = pv[i] - (mv[i] * o.alpha) / (sqrtf(vv[i]) + o.eps);
+      pv[i] = pv[i] - (mv[i] * alpha) / (sqrtf(vv[i]) + o.eps);
     }
     store_vec<VEC>(m, mv);
     store_vec<VEC>(v, vv);
@@ -485,6 +487,7 @@ int make_opt(const xdfm_opt_args* opt, OptDev* o) {
   o->one_minus_b1 = 1.f - opt->beta1;
   o->one_minus_b2 = 1.f - opt->beta2;
   // TF ApplyAdam: alpha = lr * sqrt(1 - beta2^t) / (1 - beta1^t), all in fp32
+  o->state = opt->opt_state;
   o->alpha = (opt->kind == XDFM_OPT_ADAM)
                  ? opt->lr * sqrtf(1.f - opt->beta2_power) / (1.f - opt->beta1_power)
                  : 0.f;

@@ -30,6 +30,7 @@ struct SegTable {
 struct OptDev {
   int kind;
   float lr, alpha, one_minus_b1, one_minus_b2, eps, clip;
+  const float* state;  // device {b1^t, b2^t, step size, t} or null
 };
 
 // block-wide sum, result valid in thread 0; fixed tree => deterministic
@@ -120,6 +121,7 @@ __global__ __launch_bounds__(256) void dense_update_kernel(SegTable tab, OptDev 
                                                            float* __restrict__ slot_v,
                                                            const float* __restrict__ stats) {
   const long long total = tab.off[tab.n];
+  const float alpha = o.state ? o.state[2] : o.alpha;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total;
        i += (long long)gridDim.x * 256) {
     int s = 0;
@@ -140,7 +142,7 @@ __global__ __launch_bounds__(256) void dense_update_kernel(SegTable tab, OptDev 
       float m = slot_m[i], v = slot_v[i];
       m = m + (g - m) * o.one_minus_b1;
       v = v + (g * g - v) * o.one_minus_b2;
-      p = p - (m * o.alpha) / (sqrtf(v) + o.eps);
+      p = p - (m * alpha) / (sqrtf(v) + o.eps);
       slot_m[i] = m;
       slot_v[i] = v;
     } else if (o.kind == XDFM_OPT_ADAGRAD) {
@@ -152,6 +154,17 @@ __global__ __launch_bounds__(256) void dense_update_kernel(SegTable tab, OptDev 
       p = p - g * o.lr;
     }
     param[i] = p;
+  }
+}
+
+// TF keeps beta1_power / beta2_power as fp32 variables multiplied up every step; same here
+__global__ void opt_advance_kernel(float* st, float lr, float beta1, float beta2) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    const float b1p = st[0] * beta1, b2p = st[1] * beta2;
+    st[0] = b1p;
+    st[1] = b2p;
+    st[2] = lr * sqrtf(1.f - b2p) / (1.f - b1p);
+    st[3] = st[3] + 1.f;
   }
 }
 
@@ -412,6 +425,7 @@ extern "C" int xdfm_dense_update(float* param, const float* grad, float* slot_m,
   o.one_minus_b1 = 1.f - opt->beta1;
   o.one_minus_b2 = 1.f - opt->beta2;
   o.clip = opt->clip_norm;
+  o.state = opt->opt_state;
   o.alpha = (opt->kind == XDFM_OPT_ADAM)
                 ? opt->lr * sqrtf(1.f - opt->beta2_power) / (1.f - opt->beta1_power)
                 : 0.f;
@@ -438,6 +452,14 @@ extern "C" int xdfm_dense_update(float* param, const float* grad, float* slot_m,
   if (blocks > 4096) blocks = 4096;
   XDFM_LAUNCH("dense_update_kernel", st, dense_update_kernel, dim3((unsigned)blocks), dim3(256), 0, tab, o, param, grad,
                      slot_m, slot_v, stats);
+  XDFM_LAUNCH_CHECK();
+  return XDFM_OK;
+}
+
+extern "C" int xdfm_opt_advance(float* opt_state, float lr, float beta1, float beta2, void* stream) {
+  XDFM_REQUIRE(opt_state, "xdfm_opt_advance: null state");
+  XDFM_LAUNCH("opt_advance_kernel", stream, opt_advance_kernel, dim3(1), dim3(64), 0, opt_state, lr, beta1,
+              beta2);
   XDFM_LAUNCH_CHECK();
   return XDFM_OK;
 }

@@ -157,6 +157,9 @@ class XDeepFMEngine(object):
         self.step = 0
         self.b1p = np.float32(1.0)
         self.b2p = np.float32(1.0)
+        # device copy {b1^t, b2^t, Adam step size, t}: what the kernels read, so that no host
+        # scalar changes between steps (a step can be replayed from a HIP graph)
+        self.opt_state = torch.tensor([1.0, 1.0, 0.0, 0.0], dtype=f32, device=dev)
         # dense_exact keeps a dense gradient image of the table, all zero between steps
         if embedding_update == "dense_exact":
             self.grad_table = torch.zeros_like(self.table)
@@ -218,6 +221,9 @@ class XDeepFMEngine(object):
                 draw(self.views[name], shape)
 
     def state_dict(self):
+        if self.opt_kind == 1:  # the device copy is authoritative (graph replays do not run Python)
+            b1p, b2p, _, t = self.opt_state.tolist()
+            self.b1p, self.b2p, self.step = np.float32(b1p), np.float32(b2p), int(round(t))
         sd = {"embedding": self.table, "step": self.step, "b1p": float(self.b1p), "b2p": float(self.b2p)}
         if self.lin_w is not None:
             sd["lin_w"] = self.lin_w.view(-1, 1)
@@ -258,6 +264,7 @@ class XDeepFMEngine(object):
             self.step = int(sd["step"])
             self.b1p = np.float32(sd.get("b1p", 0.9 ** self.step))
             self.b2p = np.float32(sd.get("b2p", 0.999 ** self.step))
+            self.opt_state.copy_(torch.tensor([float(self.b1p), float(self.b2p), 0.0, float(self.step)]))
 
     def _segment_tables(self):
         hp = self.hp
@@ -577,13 +584,16 @@ class XDeepFMEngine(object):
     def _opt_args(self, l2=0.0, l1=0.0, clip=0.0):
         hp = self.hp
         return _lib.OptArgs(self.opt_kind, float(hp.learning_rate), 0.9, 0.999, 1e-8,
-                            float(self.b1p), float(self.b2p), float(l2), float(l1), float(clip))
+                            float(self.b1p), float(self.b2p), float(l2), float(l1), float(clip), 0,
+                            self.opt_state.data_ptr() if self.opt_kind == 1 else None)
 
     def _advance_step(self):
         self.step += 1
         if self.opt_kind == 1:
-            self.b1p = np.float32(self.b1p * np.float32(0.9))
+            self.b1p = np.float32(self.b1p * np.float32(0.9))  # host mirror (checkpoints)
             self.b2p = np.float32(self.b2p * np.float32(0.999))
+            _lib.check(self.lib.xdfm_opt_advance(_ptr(self.opt_state), float(self.hp.learning_rate), 0.9, 0.999,
+                                                 self._stream()))
 
     def update(self, batch):
         """apply_gradients (base_model.py:305-322) for every variable + regular_loss
@@ -689,6 +699,13 @@ class XDeepFMEngine(object):
         self.update(batch)
         return (self.data_loss + self.reg_loss)[0], self.data_loss[0].clone()
 
+    def capture_step(self, labels, dnn_idx, ids, weights):
+        """Capture CSR build + train_step for batches of exactly this shape into a HIP graph
+        (launch-bound loop: ~50 kernel launches per step become one graph launch).  Returns a
+        GraphedStep; its run(labels, dnn_idx, ids, weights) copies the arrays into the graph's
+        static inputs and replays."""
+        return GraphedStep(self, labels, dnn_idx, ids, weights)
+
     # -------------------------------------------------------------------- eval
     def eval_metrics(self, preds, labels):
         """Fused AUC + logloss of device vectors -> (auc, logloss) python floats."""
@@ -704,3 +721,30 @@ class XDeepFMEngine(object):
         )
         auc, logloss, n_pos, _ = out.tolist()
         return auc, logloss, n_pos
+
+
+class GraphedStep(object):
+    def __init__(self, engine, labels, dnn_idx, ids, weights):
+        self.engine = engine
+        self.inputs = [t.clone() for t in (labels, dnn_idx, ids, weights)]
+        if engine.kernel_events is not None:
+            raise RuntimeError("kernel event hooks cannot be captured")
+        # warm up on a side stream (allocations, lazy module loads), as torch asks before a capture
+        s = torch.cuda.Stream(device=engine.device)
+        s.wait_stream(torch.cuda.current_stream(engine.device))
+        with torch.cuda.stream(s):
+            engine.train_step(engine.make_batch(*self.inputs))
+        torch.cuda.current_stream(engine.device).wait_stream(s)
+        torch.cuda.synchronize(engine.device)
+        engine.check_errors()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.batch = engine.make_batch(*self.inputs)
+            self.loss, self.data_loss = engine.train_step(self.batch)
+
+    def run(self, labels, dnn_idx, ids, weights):
+        for dst, src in zip(self.inputs, (labels, dnn_idx, ids, weights)):
+            dst.copy_(src, non_blocking=True)
+        self.graph.replay()
+        self.engine.step += 1
+        return self.loss, self.data_loss

@@ -47,7 +47,7 @@ def test_abi_version_and_error_channel():
 
 
 def test_struct_layouts_match_header():
-    assert ctypes.sizeof(_lib.OptArgs) == 40
+    assert ctypes.sizeof(_lib.OptArgs) == 56 and _lib.OptArgs.opt_state.offset == 48
     assert ctypes.sizeof(_lib.BatchInfo) == 40
 
 

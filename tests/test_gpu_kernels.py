@@ -243,3 +243,35 @@ def test_eval_auc_logloss_matches_cal_metric(golden):
         # unrounded: the AUC is an exact integer ratio
         exact = U._binary_auc(labels, preds)
         assert abs(auc - exact) < 1e-15
+
+
+def test_graph_replay_equals_eager_steps():
+    """A step captured into a HIP graph (device-side Adam scalars, side-stream sort joined
+    inside the capture) must reproduce the eager launches bit for bit."""
+    hp = make_hp(optimizer="adam", learning_rate=0.01, FEATURE_COUNT=400, cross_l2=0.01)
+    rng = np.random.default_rng(12)
+    p32 = X.init_params(hp, seed=4)
+    from oracle import ffm_iterator_oracle as O
+
+    def fixed_shape_batch():
+        B, F, N = 64, hp.FIELD_COUNT, hp.FEATURE_COUNT
+        feats = [[[f, int(rng.integers(0, N)), float(np.float32(rng.random()))] for f in range(F)] for _ in range(B)]
+        return O.convert(list(rng.integers(0, 2, B).astype(float)), feats, F, N)
+
+    batches = [fixed_shape_batch() for _ in range(3)]
+    eager = load_engine(hp, p32, "sparse_rows")
+    graph = load_engine(hp, p32, "sparse_rows")
+
+    def dev(b):
+        return [torch.from_numpy(np.ascontiguousarray(a)).cuda() for a in (
+            b["labels"].reshape(-1), b["dnn_feat_indices"], b["dnn_feat_values"], b["dnn_feat_weights"])]
+
+    losses_e = [float(eager.train_step(eager.make_batch(*dev(b)))[0]) for b in batches]
+    gs = graph.capture_step(*dev(batches[0]))          # runs batch 0 once while warming up
+    losses_g = [float(gs.run(*dev(b))[0]) for b in batches[1:]]
+    torch.cuda.synchronize()
+    graph.check_errors()
+    assert losses_g == losses_e[1:]
+    assert torch.equal(eager.table, graph.table) and torch.equal(eager.dense, graph.dense)
+    assert torch.equal(eager.table_m, graph.table_m) and torch.equal(eager.lin_w, graph.lin_w)
+    assert graph.state_dict()["step"] == 3 and abs(graph.state_dict()["b1p"] - 0.9 ** 3) < 1e-6
