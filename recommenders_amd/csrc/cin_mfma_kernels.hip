@@ -265,7 +265,7 @@ __global__ void cin_pack_w_kernel(CinDims c, const float* __restrict__ w, int Hp
 // A[i=row][k=ch] = dcurr[row][4s+k]   (registers, SMAX steps)
 // B[k=ch][j=pair] = w[(f,h)][4s+k]    (LDS copy of wpk[ft])
 // D[row=(lane>>4)*4+r][pair=lane&15] = T
-template <int NHT, int SMAX>
+template <int NHT, int SMAX, bool PREFETCH>
 __global__ __launch_bounds__(256) void cin_bwd_dx_mfma_kernel(
     CinDims c, const float* __restrict__ x0, const float* __restrict__ xk,
     const float* __restrict__ wpk, const float* __restrict__ dc_mn, float* d_xk, float* d_x0,
@@ -309,24 +309,48 @@ __global__ __launch_bounds__(256) void cin_bwd_dx_mfma_kernel(
   for (int ht = 0; ht < NHT; ++ht) accK[ht] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int per_ft4 = Hp * Lp;  // float4 count of one wpk[ft] image (4*Hp*Lp floats)
+  // When the image fits 4 float4 per thread, the next f tile's image is fetched into registers
+  // while this one multiplies, so the global latency is off the critical path.
+  constexpr bool prefetch = PREFETCH;  // host guarantees per_ft4 <= 4*256 when set
+  // four named registers (an indexed array ends up in scratch here)
+  float4 wn0 = {0, 0, 0, 0}, wn1 = wn0, wn2 = wn0, wn3 = wn0;
+  const int pq0 = threadIdx.x, pq1 = threadIdx.x + 256, pq2 = threadIdx.x + 512, pq3 = threadIdx.x + 768;
+  const int last4 = per_ft4 - 1;
+#define XDFM_FETCH_W(FT)                                                                     \
+  do {                                                                                       \
+    const float4* src_ = reinterpret_cast<const float4*>(wpk) + (size_t)(FT) * per_ft4;      \
+    wn0 = src_[pq0 < per_ft4 ? pq0 : last4];                                                 \
+    wn1 = src_[pq1 < per_ft4 ? pq1 : last4];                                                 \
+    wn2 = src_[pq2 < per_ft4 ? pq2 : last4];                                                 \
+    wn3 = src_[pq3 < per_ft4 ? pq3 : last4];                                                 \
+  } while (0)
+  if constexpr (prefetch) XDFM_FETCH_W(0);
   for (int ft = 0; ft < nft; ++ft) {
     __syncthreads();  // previous tile row is done with wst (and the X tiles are staged)
     {
       const float4* src = reinterpret_cast<const float4*>(wpk) + (size_t)ft * per_ft4;
       float4* dst = reinterpret_cast<float4*>(wst);
-      for (int q0 = threadIdx.x; q0 < per_ft4; q0 += 4 * 256) {
-        float4 v[4];
+      if constexpr (prefetch) {
+        if (pq0 < per_ft4) dst[pq0] = wn0;
+        if (pq1 < per_ft4) dst[pq1] = wn1;
+        if (pq2 < per_ft4) dst[pq2] = wn2;
+        if (pq3 < per_ft4) dst[pq3] = wn3;
+      } else {
+        for (int q0 = threadIdx.x; q0 < per_ft4; q0 += 4 * 256) {
+          float4 v[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int q = q0 + u * 256;
-          v[u] = src[q < per_ft4 ? q : per_ft4 - 1];
+          for (int u = 0; u < 4; ++u) {
+            const int q = q0 + u * 256;
+            v[u] = src[q < per_ft4 ? q : per_ft4 - 1];
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+            if (q0 + u * 256 < per_ft4) dst[q0 + u * 256] = v[u];
         }
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-          if (q0 + u * 256 < per_ft4) dst[q0 + u * 256] = v[u];
       }
     }
     __syncthreads();
+    if constexpr (prefetch) XDFM_FETCH_W(ft + 1 < nft ? ft + 1 : ft);
     const f32x4 a0 = *reinterpret_cast<const f32x4*>(as + (4 * ft + fi) * Tp + rrow);
     f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f};
     const int ht_begin = c.masked ? ft : 0;
@@ -395,6 +419,7 @@ __global__ __launch_bounds__(256) void cin_bwd_dx_mfma_kernel(
     }
     if (hi == 0) *reinterpret_cast<f32x4*>(dx0_s + (4 * ft + fi) * Tp + rrow) = acc0;
   }
+#undef XDFM_FETCH_W
   // dXk[rows][4ht+hi] = sum over fi (lanes j, j+4, j+8, j+12), fixed order
 #pragma unroll
   for (int ht = 0; ht < NHT; ++ht) {
@@ -769,23 +794,31 @@ int bwd_mfma(const CinDims& c, const float* x0, const float* xk, const float* w,
     dim3 grid((unsigned)((c.B + SPB - 1) / SPB));
     XDFM_LAUNCH("cin_pack_w_kernel", st, cin_pack_w_kernel, dim3((unsigned)((wpk_floats + 255) / 256)),
                 dim3(256), 0, c, w, Hp, Lp, nft, wpk);
-#define CALL(NH, SM)                                                                               \
-  do {                                                                                             \
-    int rc = allow_lds(cin_bwd_dx_mfma_kernel<NH, SM>, lds_bytes);                                 \
-    if (rc) return rc;                                                                             \
-    XDFM_LAUNCH("cin_bwd_dx_mfma_kernel<" #NH ", " #SM ">", st, (cin_bwd_dx_mfma_kernel<NH, SM>),  \
-                grid, dim3(256), lds_bytes, c, x0, xk, wpk, dc_mn, d_xk, d_x0, SPB, Lp);             \
+    const bool pre = (size_t)Hp * Lp <= 4 * 256;  // the f-tile filter image fits 4 float4 per thread
+#define CALL_P(NH, SM, PF)                                                                             \
+  do {                                                                                                 \
+    int rc = allow_lds(cin_bwd_dx_mfma_kernel<NH, SM, PF>, lds_bytes);                                 \
+    if (rc) return rc;                                                                                 \
+    XDFM_LAUNCH("cin_bwd_dx_mfma_kernel<" #NH ", " #SM ">", st, (cin_bwd_dx_mfma_kernel<NH, SM, PF>),  \
+                grid, dim3(256), lds_bytes, c, x0, xk, wpk, dc_mn, d_xk, d_x0, SPB, Lp);               \
   } while (0)
-#define BY_S(NH)        \
-  do {                  \
-    if (S <= 3)         \
-      CALL(NH, 3);      \
-    else if (S <= 5)    \
-      CALL(NH, 5);      \
-    else if (S <= 16)   \
-      CALL(NH, 16);     \
-    else                \
-      CALL(NH, 64);     \
+#define CALL_S(NH, SM)          \
+  do {                          \
+    if (pre)                    \
+      CALL_P(NH, SM, true);     \
+    else                        \
+      CALL_P(NH, SM, false);    \
+  } while (0)
+#define BY_S(NH)               \
+  do {                         \
+    if (S <= 3)                \
+      CALL_S(NH, 3);           \
+    else if (S <= 5)           \
+      CALL_S(NH, 5);           \
+    else if (S <= 16)          \
+      CALL_P(NH, 16, false);   \
+    else                       \
+      CALL_P(NH, 64, false);   \
   } while (0)
     if (nht <= 3)
       BY_S(3);
@@ -794,7 +827,8 @@ int bwd_mfma(const CinDims& c, const float* x0, const float* xk, const float* w,
     else
       BY_S(32);
 #undef BY_S
-#undef CALL
+#undef CALL_S
+#undef CALL_P
   }
   // ---- filter gradient
   {
