@@ -221,11 +221,15 @@ int xdfm_dense_update(float* param, const float* grad, float* slot_m, float* slo
  *   curr[b,n,d] = sum_{f,h} s*M[f,h]*x0[b,f,d]*xk[b,h,d]*w[f*H+h,n]
  *   n <  n_hidden : xnext[b,n,d]            = curr   ([B,n_hidden,D], the next layer's input)
  *   n >= n_hidden : pooled[b,pool_off+n-n_hidden] = sum_d curr   (pooled is [B,pool_stride])
+ *   workspace: device float scratch of xdfm_cin_fwd_workspace_floats(...) elements (the
+ *   filter re-packed in matrix-core operand order; may be NULL when that size is 0)
  * ---------------------------------------------------------------------- */
+int xdfm_cin_fwd_workspace_floats(int64_t B, int32_t F, int32_t H, int32_t D, int32_t L,
+                                  size_t* floats);
 int xdfm_cin_fwd(const float* x0, const float* xk, const float* w, int64_t B, int32_t F,
                  int32_t H, int32_t D, int32_t L, int32_t n_hidden, int32_t masked,
                  float* xnext, float* pooled, int32_t pool_stride, int32_t pool_off,
-                 void* stream);
+                 float* workspace, void* stream);
 /* Backward of one layer.  Upstream gradient of curr[b,n,d]:
  *   n <  n_hidden : d_xnext[b,n,d]
  *   n >= n_hidden : d_pooled[b,pool_off+n-n_hidden]        (same for every d)

@@ -14,8 +14,9 @@ struct CinDims {
 
 // shapes the MFMA path handles (else the generic VALU kernels run)
 bool mfma_supported(int64_t B, int F, int H, int D, int L);
+size_t fwd_mfma_workspace_floats(int64_t B, int F, int H, int D, int L);
 int fwd_mfma(const CinDims& c, const float* x0, const float* xk, const float* w, float* xnext,
-             float* pooled, int pool_stride, int pool_off, hipStream_t st);
+             float* pooled, int pool_stride, int pool_off, float* ws, hipStream_t st);
 size_t bwd_mfma_workspace_floats(int64_t B, int F, int H, int D, int L, int masked);
 int bwd_mfma(const CinDims& c, const float* x0, const float* xk, const float* w,
              const float* d_xnext, const float* d_pooled, int pool_stride, int pool_off, float* d_xk,

@@ -337,10 +337,18 @@ int splits_for(int64_t B, int SUB) {
     default: { CALL(32); } break; \
   }
 
+extern "C" int xdfm_cin_fwd_workspace_floats(int64_t B, int32_t F, int32_t H, int32_t D, int32_t L,
+                                             size_t* floats) {
+  XDFM_REQUIRE(floats && B >= 0 && F > 0 && H > 0 && D > 0 && L > 0,
+               "xdfm_cin_fwd_workspace_floats: bad argument");
+  *floats = xdfm_cin::mfma_supported(B, F, H, D, L) ? xdfm_cin::fwd_mfma_workspace_floats(B, F, H, D, L) : 0;
+  return XDFM_OK;
+}
+
 extern "C" int xdfm_cin_fwd(const float* x0, const float* xk, const float* w, int64_t B, int32_t F,
                             int32_t H, int32_t D, int32_t L, int32_t n_hidden, int32_t masked,
                             float* xnext, float* pooled, int32_t pool_stride, int32_t pool_off,
-                            void* stream) {
+                            float* workspace, void* stream) {
   int rc = check_dims("xdfm_cin_fwd", B, F, H, D, L, n_hidden, masked);
   if (rc) return rc;
   XDFM_REQUIRE(x0 && xk && w, "xdfm_cin_fwd: null input");
@@ -349,7 +357,9 @@ extern "C" int xdfm_cin_fwd(const float* x0, const float* xk, const float* w, in
   if (B == 0) return XDFM_OK;
   if (xdfm_cin::mfma_supported(B, F, H, D, L)) {
     CinDims cm{B, F, H, D, L, n_hidden, masked};
-    return xdfm_cin::fwd_mfma(cm, x0, xk, w, xnext, pooled, pool_stride, pool_off, (hipStream_t)stream);
+    XDFM_REQUIRE(workspace, "xdfm_cin_fwd: workspace is null (size it with xdfm_cin_fwd_workspace_floats)");
+    return xdfm_cin::fwd_mfma(cm, x0, xk, w, xnext, pooled, pool_stride, pool_off, workspace,
+                              (hipStream_t)stream);
   }
   const int nch = pick_nch(L);
   const int rows = (xk == x0) ? H : H + F;

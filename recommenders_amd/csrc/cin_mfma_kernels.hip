@@ -19,6 +19,8 @@
 // dc_mn[B*D][L] (upstream gradient of curr in row-major (m, n) order).
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "cin_common.h"
 #include "xdfm_common.h"
 
@@ -241,6 +243,228 @@ __global__ __launch_bounds__(256) void cin_fwd_mfma_kernel(
       float s = 0.f;
       for (int d = 0; d < c.D; ++d) s += out[ch * Tp + bl * c.D + d];  // reduce_sum over D (:270)
       pooled[(b0 + bl) * pool_stride + pool_off + g - c.n_hidden] = s;
+    }
+  }
+}
+
+// ------------------------------------------------------------ forward, factorised
+//   curr[m,n] = scale * sum_o xo[m,o] * U[m,(o,n)],    U[m,(o,n)] = sum_i xi[m,i] * W'[i,(o,n)]
+// (xi, xo) = (xk, x0) or, when F > H, (x0, xk): the longer feature axis is the K of the matrix
+// product, the shorter one is folded in with 4 FMAs per tile.  On gfx950 fp32 MFMAs and VALU
+// ops share the SIMD's fp32 lanes (tools/ub_mfma_mix.hip: every extra VALU op per MFMA costs
+// ~3 cycles on top of the MFMA's 32), so the loop is built to issue almost nothing else:
+//   A[i][k] = W'[4ks+k][(4oq + i>>2, 4nq + i&3)]   packed image wq, one float4 per 4 steps
+//   B[k][j] = xi[row][4ks + k]                     LDS [feature][row]; lane j owns rows 4j..4j+3
+//                                                  of its wave (4 row tiles), one ds_read_b128
+//   D[i = 4*oi + r][j]: lane (oi = lane>>4, j) holds channels 4nq..4nq+3 of its 4 rows for
+//   outer feature 4oq+oi and folds them into its accumulator with xo[row][4oq+oi]; the 4 oi
+//   groups are added once per nq.
+// Steps (oq, ks) of one nq form a flat list (descriptors in global memory, read through the
+// scalar cache); the masked layer skips ks < oq (h <= f there).
+__host__ __device__ inline int fwd2_steps(int noq, int nks, int masked) {
+  return masked ? noq * nks - noq * (noq - 1) / 2 : noq * nks;
+}
+constexpr int kFwdLast = 1 << 16, kFwdFirst = 1 << 17, kFwdValid = 1 << 24;
+// step s -> ks | oq << 8 | flags (0 for a padding step)
+__device__ inline int fwd2_step_desc(int s, int noq, int nks, int masked) {
+  int oq = 0, rem = s;
+  while (oq < noq) {
+    const int cnt = masked ? nks - oq : nks;
+    if (rem < cnt) break;
+    rem -= cnt;
+    ++oq;
+  }
+  if (oq >= noq) return 0;
+  const int ks0 = masked ? oq : 0;
+  const int ks = ks0 + rem;
+  return ks | (oq << 8) | ((ks == nks - 1) ? kFwdLast : 0) | ((ks == ks0) ? kFwdFirst : 0) | kFwdValid;
+}
+
+// image wq[nq][group][lane][4 steps] followed by the step descriptors stab[nsteps_img]
+__global__ void cin_pack_fwd_kernel(CinDims c, const float* __restrict__ w, int noq, int nks,
+                                    int nsteps_img, int NQ, int swap, float* __restrict__ wq) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t total = (int64_t)NQ * nsteps_img * 64;
+  if (idx < nsteps_img)
+    reinterpret_cast<int*>(wq + total)[idx] = fwd2_step_desc((int)idx, noq, nks, c.masked);
+  if (idx >= total) return;
+  const int lane = (int)(idx & 63);
+  const int s = (int)((idx >> 6) % nsteps_img);
+  const int nq = (int)((idx >> 6) / nsteps_img);
+  const int desc = fwd2_step_desc(s, noq, nks, c.masked);
+  const int ks = desc & 0xff, oq = (desc >> 8) & 0xff;
+  const int i = lane & 15, k = lane >> 4;
+  const int o = 4 * oq + (i >> 2), n = 4 * nq + (i & 3), in = 4 * ks + k;
+  const int f = swap ? in : o, h = swap ? o : in;
+  const bool ok = (desc & kFwdValid) && f < c.F && h < c.H && n < c.L && (!c.masked || h > f);
+  const float v = ok ? w[(int64_t)(f * c.H + h) * c.L + n] : 0.f;
+  wq[(((int64_t)nq * (nsteps_img >> 2) + (s >> 2)) * 64 + lane) * 4 + (s & 3)] = v;
+}
+
+// xi: K-side input [B][Ki][D], xo: folded input [B][Ko][D] (xi == xo for the masked layer)
+__global__ __launch_bounds__(256) void cin_fwd2_mfma_kernel(
+    CinDims c, const float* __restrict__ xi, const float* __restrict__ xo, int Ki, int Ko,
+    const float* __restrict__ wq, const int* __restrict__ stab, float* __restrict__ xnext,
+    float* __restrict__ pooled, int pool_stride, int pool_off, int SPB, int ngrp, int NQ) {
+  extern __shared__ float lds[];
+  constexpr int RT = 4;
+  constexpr int ROWS = 64 * RT;
+  constexpr int Tp = ROWS + kPad;
+  const bool shared_x = (xi == xo);
+  const int Kip = (Ki + 3) & ~3, Kop = (Ko + 3) & ~3;
+  const int npool = c.L - c.n_hidden;
+  float* xs = lds;                             // [Kip][Tp]
+  float* as = shared_x ? xs : xs + Kip * Tp;   // [Kop][Tp]
+  float* outs = as + Kop * Tp;                 // [npool][Tp]  pooled channels only
+
+  const int64_t b0 = (int64_t)blockIdx.x * SPB;
+  const int nb = (int)((c.B - b0 < SPB) ? (c.B - b0) : SPB);
+  stage_cols(xi, b0, nb, Ki, Kip, c.D, xs, Tp);
+  if (!shared_x) stage_cols(xo, b0, nb, Ko, Kop, c.D, as, Tp);
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane & 15, g = lane >> 4;
+  const int cols = nb * c.D;
+  const int m0 = wave * 64 + 4 * j;  // this lane's 4 rows: m0 .. m0+3
+  const float* xlane = xs + g * Tp + m0;
+  const float* alane = as + g * Tp + m0;
+  const float scale = c.masked ? 2.f : 1.f;  // exact, so applying it last changes no bit
+  const int4* stab4 = reinterpret_cast<const int4*>(stab);
+  const bool vec_store = (c.D & 3) == 0 && (reinterpret_cast<uintptr_t>(xnext) & 15) == 0;
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+
+  struct Grp {
+    f32x4 b[4];
+    f32x4 xv[4];  // xo values of the steps that close a tile (stale otherwise, never used)
+    int d[4];
+  };
+  auto issue = [&](Grp& G, int4 dd) {
+    G.d[0] = dd.x;
+    G.d[1] = dd.y;
+    G.d[2] = dd.z;
+    G.d[3] = dd.w;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      G.b[s] = *reinterpret_cast<const f32x4*>(xlane + (G.d[s] & 0xff) * (4 * Tp));
+      if (G.d[s] & kFwdLast)
+        G.xv[s] = *reinterpret_cast<const f32x4*>(alane + ((G.d[s] >> 8) & 0xff) * (4 * Tp));
+    }
+  };
+
+  float* xn = xnext + b0 * c.n_hidden * c.D;
+  // The filter image is one stream over (nq, group): a ring of four float4 registers keeps
+  // the loads three groups (48 MFMAs) ahead of their use, across nq boundaries as well.
+  const int ngrp4 = (ngrp + 3) & ~3;  // groups per nq in the image (padding groups are zero)
+  const f32x4* img = reinterpret_cast<const f32x4*>(wq) + lane;
+  const int glast = NQ * ngrp4 - 1;
+  auto aload = [&](int gidx) { return img[(size_t)(gidx < glast ? gidx : glast) * 64]; };
+  f32x4 A0 = aload(0), A1 = aload(1), A2 = aload(2), A3;
+  for (int nq = 0; nq < NQ; ++nq) {
+    f32x4 oacc[RT], U[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+      oacc[rt] = zero4;
+      U[rt] = zero4;
+    }
+    auto compute = [&](const Grp& G, const f32x4& A) {
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const int d = G.d[s];  // wave-uniform (scalar loads)
+        if (d & kFwdFirst) {  // a new (oq, nq) tile: start from zero without clearing registers
+#pragma unroll
+          for (int rt = 0; rt < RT; ++rt) U[rt] = mfma(A[s], G.b[s][rt], zero4);
+        } else {
+#pragma unroll
+          for (int rt = 0; rt < RT; ++rt) U[rt] = mfma(A[s], G.b[s][rt], U[rt]);
+        }
+        if (d & kFwdLast) {  // the tile is complete: fold it in with this lane's xo values
+#pragma unroll
+          for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) oacc[rt][r] = fmaf(G.xv[s][rt], U[rt][r], oacc[rt][r]);
+        }
+      }
+    };
+    const int gbase = nq * ngrp4;
+    auto desc = [&](int q) { return stab4[q < ngrp ? q : ngrp - 1]; };
+    Grp g0, g1;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) g0.xv[s] = g1.xv[s] = zero4;
+    issue(g0, desc(0));
+    int4 d_next = desc(1);
+    for (int q = 0; q < ngrp4; q += 4) {
+      // groups past ngrp exist only in the image (zeros); they are loaded, never multiplied
+      const int4 d_a = desc(q + 2);
+      A3 = aload(gbase + q + 3);
+      issue(g1, d_next);
+      __builtin_amdgcn_sched_barrier(0);
+      compute(g0, A0);
+      __builtin_amdgcn_sched_barrier(0);
+      const int4 d_b = desc(q + 3);
+      A0 = aload(gbase + q + 4);
+      issue(g0, d_a);
+      __builtin_amdgcn_sched_barrier(0);
+      if (q + 1 < ngrp) compute(g1, A1);
+      __builtin_amdgcn_sched_barrier(0);
+      const int4 d_c = desc(q + 4);
+      A1 = aload(gbase + q + 5);
+      issue(g1, d_b);
+      __builtin_amdgcn_sched_barrier(0);
+      if (q + 2 < ngrp) compute(g0, A2);
+      __builtin_amdgcn_sched_barrier(0);
+      const int4 d_d = desc(q + 5);
+      A2 = aload(gbase + q + 6);
+      issue(g0, d_c);
+      __builtin_amdgcn_sched_barrier(0);
+      if (q + 3 < ngrp) compute(g1, A3);
+      __builtin_amdgcn_sched_barrier(0);
+      d_next = d_d;
+    }
+    // add the 4 oi groups (fixed order), then group g owns channel 4*nq + g of rows m0..m0+3:
+    // hidden channels go straight to xnext[b][ch][d], pooled ones wait in LDS for the sum over d
+    const int ch = 4 * nq + g;
+    f32x4 o;
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+      f32x4 v = oacc[rt];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float t = v[r];
+        t += __shfl_xor(t, 16);
+        t += __shfl_xor(t, 32);
+        v[r] = t;
+      }
+      o[rt] = (g == 0 ? v[0] : (g == 1 ? v[1] : (g == 2 ? v[2] : v[3]))) * scale;
+    }
+    if (ch < c.n_hidden) {
+      if (vec_store) {  // 4 | D: the 4 rows are 4 consecutive d of one sample
+        if (m0 < cols) {
+          const int bl = m0 / c.D, dd = m0 - bl * c.D;
+          *reinterpret_cast<f32x4*>(xn + (bl * c.n_hidden + ch) * c.D + dd) = o;
+        }
+      } else {
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+          const int m = m0 + rt;
+          if (m < cols) {
+            const int bl = m / c.D, dd = m - bl * c.D;
+            xn[(bl * c.n_hidden + ch) * c.D + dd] = o[rt];
+          }
+        }
+      }
+    } else if (ch < c.L) {
+      *reinterpret_cast<f32x4*>(outs + (ch - c.n_hidden) * Tp + m0) = o;
+    }
+  }
+  if (npool > 0) {
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < npool * nb; idx += blockDim.x) {
+      const int p = idx / nb;
+      const int bl = idx - p * nb;
+      float s = 0.f;
+      for (int d = 0; d < c.D; ++d) s += outs[p * Tp + bl * c.D + d];  // reduce_sum over D (:270)
+      pooled[(b0 + bl) * pool_stride + pool_off + p] = s;
     }
   }
 }
@@ -724,38 +948,53 @@ bool mfma_supported(int64_t B, int F, int H, int D, int L) {
   const int Lp = 4 * smax_for(S) + 1;
   const size_t dx_lds = ((size_t)(2 * Hp + 2 * Fp) * (64 + kPad) + (size_t)4 * Hp * Lp) * sizeof(float);
   if (dx_lds > kLdsLimit) return false;
+  // forward tile: both inputs and the pooled channels of 256 rows
+  if ((size_t)(Hp + Fp + L) * (256 + kPad) * sizeof(float) > kLdsLimit) return false;
   (void)B;
   return true;
 }
 
+// which input is the K side of the forward product: the longer feature axis
+static bool fwd_swap(int F, int H, int masked) { return !masked && F > H; }
+
+size_t fwd_mfma_workspace_floats(int64_t B, int F, int H, int D, int L) {
+  (void)B;
+  (void)D;
+  // unmasked count with the longer axis as K bounds every case
+  const int Ki = F > H ? F : H, Ko = F > H ? H : F;
+  const int noq = (Ko + 3) / 4, nks = (Ki + 3) / 4, NQ = (L + 3) / 4;
+  const int nsteps_img = (fwd2_steps(noq, nks, 0) + 15) & ~15;
+  return (size_t)NQ * nsteps_img * 64 + nsteps_img;
+}
+
 int fwd_mfma(const CinDims& c, const float* x0, const float* xk, const float* w, float* xnext,
-             float* pooled, int pool_stride, int pool_off, hipStream_t st) {
-  constexpr int RT = 4;
-  constexpr int ROWS = 64 * RT;
+             float* pooled, int pool_stride, int pool_off, float* ws, hipStream_t st) {
+  const bool swap = fwd_swap(c.F, c.H, c.masked);
+  const float* xi = swap ? x0 : xk;
+  const float* xo = swap ? xk : x0;
+  const int Ki = swap ? c.F : c.H, Ko = swap ? c.H : c.F;
+  const int Kip = (Ki + 3) & ~3, Kop = (Ko + 3) & ~3;
+  const int noq = Kop / 4, nks = Kip / 4, NQ = (c.L + 3) / 4;
+  const int nsteps = fwd2_steps(noq, nks, c.masked);
+  const int ngrp = (nsteps + 3) / 4;
+  // the image holds a multiple of 4 groups (16 steps) per nq: the kernel's load ring runs four
+  // groups per trip
+  const int nsteps_img = (nsteps + 15) & ~15;
+  const int64_t img_floats = (int64_t)NQ * nsteps_img * 64;
+  XDFM_LAUNCH("cin_pack_fwd_kernel", st, cin_pack_fwd_kernel, dim3((unsigned)((img_floats + 255) / 256)),
+              dim3(256), 0, c, w, noq, nks, nsteps_img, NQ, swap ? 1 : 0, ws);
+  constexpr int ROWS = 256;
+  XDFM_REQUIRE(c.D <= ROWS, "xdfm_cin_fwd: dim %d does not fit a row tile", c.D);
   const int SPB = ROWS / c.D;
-  const int P = c.masked ? c.F * (c.F - 1) / 2 : c.F * c.H;
-  const int Ppad = (P + 3) & ~3;
-  const int nt_total = (c.L + 15) / 16;
-  const int NT = nt_total >= 4 ? 4 : (nt_total >= 2 ? 2 : 1);
-  int lds_rows = (xk == x0) ? c.H : c.H + c.F;
-  if (lds_rows < NT * 16) lds_rows = NT * 16;
-  const size_t lds_bytes = (size_t)lds_rows * (ROWS + kPad) * sizeof(float) + (size_t)(Ppad + 16) * sizeof(int);
+  const int lds_rows = Kip + ((xi == xo) ? 0 : Kop) + (c.L - c.n_hidden);
+  const size_t lds_bytes = (size_t)lds_rows * (ROWS + kPad) * sizeof(float);
   XDFM_REQUIRE(lds_bytes <= kLdsLimit, "xdfm_cin_fwd: tile does not fit the LDS");
-  dim3 grid((unsigned)((c.B + SPB - 1) / SPB), (unsigned)((nt_total + NT - 1) / NT));
-#define CALL(N)                                                                                   \
-  do {                                                                                            \
-    int rc = allow_lds(cin_fwd_mfma_kernel<N, RT>, lds_bytes);                                    \
-    if (rc) return rc;                                                                            \
-    XDFM_LAUNCH("cin_fwd_mfma_kernel<" #N ", 4>", st, (cin_fwd_mfma_kernel<N, RT>), grid, dim3(256), \
-                lds_bytes, c, x0, xk, w, xnext, pooled, pool_stride, pool_off, SPB, P, lds_rows); \
-  } while (0)
-  if (NT == 4)
-    CALL(4);
-  else if (NT == 2)
-    CALL(2);
-  else
-    CALL(1);
-#undef CALL
+  dim3 grid((unsigned)((c.B + SPB - 1) / SPB));
+  int rc = allow_lds(cin_fwd2_mfma_kernel, lds_bytes);
+  if (rc) return rc;
+  XDFM_LAUNCH("cin_fwd2_mfma_kernel", st, cin_fwd2_mfma_kernel, grid, dim3(256), lds_bytes, c, xi, xo, Ki, Ko,
+              ws, reinterpret_cast<const int*>(ws + img_floats), xnext, pooled, pool_stride, pool_off, SPB,
+              ngrp, NQ);
   XDFM_LAUNCH_CHECK();
   return XDFM_OK;
 }

@@ -337,6 +337,8 @@ class XDeepFMEngine(object):
                     buf("d_hid_%d" % k, B, nh * D)
                 _lib.check(self.lib.xdfm_cin_bwd_workspace_floats(B, F, H, D, L, ctypes.byref(sz)))
                 part_floats = max(part_floats, sz.value)
+                _lib.check(self.lib.xdfm_cin_fwd_workspace_floats(B, F, H, D, L, ctypes.byref(sz)))
+                part_floats = max(part_floats, sz.value)
             _lib.check(self.lib.xdfm_dense_bwd_workspace_floats(B, final_len, 1, ctypes.byref(sz)))
             part_floats = max(part_floats, sz.value)
         if hp.use_DNN_part:
@@ -474,7 +476,7 @@ class XDeepFMEngine(object):
                 _lib.check(
                     lib.xdfm_cin_fwd(_ptr(x0), _ptr(xk), _ptr(self.views["cin_f_%d" % k]), B, F, H, D,
                                      L, nh, 1 if k == 0 else 0, _ptr(xnext), _ptr(ws["pooled"]),
-                                     final_len, off, st)
+                                     final_len, off, _ptr(ws["part"]), st)
                 )
                 off += L - nh
                 xk = xnext

@@ -1,0 +1,53 @@
+#!/usr/bin/env python
+"""Per-kernel averages of rocprofv3 --pmc passes (counter_collection.csv files).
+
+    python tools/pmc_summary.py <dir with */*/*_counter_collection.csv> [substring filter]
+
+FETCH_SIZE / WRITE_SIZE are reported in bytes per launch with the corrections of
+/opt/skills/guides/MI355X_MICROARCH.md (TCC counters count 32 B... see HBM section):
+    HBM read bytes  = FETCH_SIZE * 1024 * 2   (kB units, gfx950 reports half)
+    HBM write bytes = WRITE_SIZE * 1024
+"""
+import collections
+import csv
+import glob
+import re
+import sys
+
+
+def short(name):
+    name = re.sub(r"^void ", "", name)
+    name = name.replace("xdfm_cin::(anonymous namespace)::", "").replace("(anonymous namespace)::", "")
+    m = re.match(r"[\w:]+(<[^()]*>)?", name)
+    name = m.group(0) if m and m.group(0) else name
+    return name[:90]
+
+
+def main():
+    root = sys.argv[1]
+    filt = sys.argv[2] if len(sys.argv) > 2 else ""
+    acc = collections.defaultdict(lambda: collections.defaultdict(list))
+    dur = collections.defaultdict(list)
+    for path in glob.glob(root + "/**/*_counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(path)):
+            k = short(r["Kernel_Name"]) + " lds=%s" % r.get("LDS_Block_Size", "?")
+            if filt not in k:
+                continue
+            acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+            dur[k].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    for k in sorted(acc, key=lambda k: -sum(dur[k])):
+        c = {n: sum(v) / len(v) for n, v in acc[k].items()}
+        n = max(len(v) for v in acc[k].values())
+        out = ["%-60s n=%d" % (k, n)]
+        if "FETCH_SIZE" in c:
+            out.append("hbm_read_MB=%.2f" % (c["FETCH_SIZE"] * 1024 * 2 / 1e6))
+        if "WRITE_SIZE" in c:
+            out.append("hbm_write_MB=%.2f" % (c["WRITE_SIZE"] * 1024 / 1e6))
+        for n_, v in sorted(c.items()):
+            if n_ not in ("FETCH_SIZE", "WRITE_SIZE"):
+                out.append("%s=%.4g" % (n_, v))
+        print("  ".join(out))
+
+
+if __name__ == "__main__":
+    main()
