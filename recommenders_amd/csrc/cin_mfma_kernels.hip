@@ -688,6 +688,196 @@ __global__ __launch_bounds__(256) void cin_bwd_dx_mfma_kernel(
   }
 }
 
+// ------------------------------------------------- input gradients, second form
+// Same contraction as above with the MFMA roles transposed so that no sum crosses lanes
+// inside the loop, and with everything that is not an MFMA or one of the 2 FMAs per product
+// kept out of it (fp32 MFMAs and VALU ops share the SIMD lanes):
+//   A[i][k] = w[(4ft + i>>2, 4ht + i&3)][4s + k]     packed image, streamed in tile order
+//   B[k][j] = dcurr[row][4s + k]                     registers, read once from d_xnext/d_pooled
+//   D[i = 4*fi + r][j]: lane (fi = lane>>4, j) holds T for f = 4ft+fi, h = 4ht+r, and the
+//   lane's 4 rows (m0..m0+3, one per row tile):
+//     dX0[row][4ft+fi] += sum_r xk[row][4ht+r] * T[r]      registers acc0[ft], no reduction
+//     dXk[row][4ht+r]  += x0[row][4ft+fi] * T[r]           registers accK, the 4 fi groups
+//                                                          are added once per h tile
+// h tiles run from the last to the first: once tile ht is done its rows of the X tile in LDS
+// are dead (also as x0 rows of the masked layer, which needs ft <= ht), so dXk replaces them
+// in place and the kernel needs no LDS beyond the X tiles.
+template <int S>
+__global__ void cin_pack_dx_kernel(CinDims c, const float* __restrict__ w, int nft, int nht,
+                                   int ntiles, float* __restrict__ wdx) {
+  constexpr int Sp = (S + 3) & ~3;
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t total = (int64_t)ntiles * 64 * Sp;
+  if (idx >= total) return;
+  const int s = (int)(idx % Sp);
+  const int lane = (int)((idx / Sp) & 63);
+  int t = (int)(idx / (64 * Sp));
+  // tile order of the kernel: ht descending, ft ascending (masked: ft <= ht)
+  int ht = nht - 1, ft = 0;
+  for (;; --ht) {
+    const int lim = c.masked ? (ht + 1 < nft ? ht + 1 : nft) : nft;
+    if (t < lim) {
+      ft = t;
+      break;
+    }
+    t -= lim;
+  }
+  const int i = lane & 15, k = lane >> 4;
+  const int f = 4 * ft + (i >> 2), h = 4 * ht + (i & 3), n = 4 * s + k;
+  const bool ok = f < c.F && h < c.H && n < c.L && (!c.masked || h > f);
+  wdx[idx] = ok ? w[(int64_t)(f * c.H + h) * c.L + n] : 0.f;
+}
+
+template <int NFT, int S>
+__global__ __launch_bounds__(256) void cin_bwd_dx2_mfma_kernel(
+    CinDims c, const float* __restrict__ x0, const float* __restrict__ xk,
+    const float* __restrict__ wdx, const float* __restrict__ d_xnext,
+    const float* __restrict__ d_pooled, int pool_stride, int pool_off, float* d_xk, float* d_x0,
+    int SPB, int ntiles) {
+  extern __shared__ float lds[];
+  constexpr int RT = 4;
+  constexpr int ROWS = 64 * RT;
+  constexpr int Tp = ROWS + kPad;
+  constexpr int Sp = (S + 3) & ~3;
+  constexpr int S4 = Sp / 4;
+  const bool shared_x = (xk == x0);
+  const int Hp = (c.H + 3) & ~3, Fp = (c.F + 3) & ~3;
+  const int nht = Hp >> 2, nft = Fp >> 2;
+  float* xs = lds;                            // [Hp][Tp]  xk, then dXk (+ dX0 when shared)
+  float* as = shared_x ? xs : xs + Hp * Tp;   // [Fp][Tp]  x0, then dX0
+
+  const int64_t b0 = (int64_t)blockIdx.x * SPB;
+  const int nb = (int)((c.B - b0 < SPB) ? (c.B - b0) : SPB);
+  const int cols = nb * c.D;
+  stage_cols(xk, b0, nb, c.H, Hp, c.D, xs, Tp);
+  if (!shared_x) stage_cols(x0, b0, nb, c.F, Fp, c.D, as, Tp);
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane & 15, g = lane >> 4;
+  const int m0 = wave * 64 + 4 * j;  // this lane's 4 rows
+  // B operands: dcurr[row][4s + g] for the lane's 4 rows, straight from the upstream tensors
+  float dc[S][RT];
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt) {
+    const int m = m0 + rt;
+    const bool valid = m < cols;
+    const int mc = valid ? m : 0;
+    const int bl = mc / c.D, d = mc - bl * c.D;
+    const int64_t b = b0 + bl;
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+      const int n = 4 * s + g;
+      float v = 0.f;
+      if (valid && n < c.L)
+        v = n < c.n_hidden ? d_xnext[(b * c.n_hidden + n) * c.D + d]
+                           : d_pooled[b * pool_stride + pool_off + n - c.n_hidden];
+      dc[s][rt] = v;
+    }
+  }
+  __syncthreads();  // the X tiles are staged
+
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  f32x4 acc0[NFT];  // [ft], component rt: dX0[m0+rt][4ft+g]
+#pragma unroll
+  for (int ft = 0; ft < NFT; ++ft) acc0[ft] = zero4;
+
+  const f32x4* img = reinterpret_cast<const f32x4*>(wdx) + (size_t)lane * S4;
+  const int tlast = ntiles - 1;
+  f32x4 a_cur[S4], a_nxt[S4];
+#pragma unroll
+  for (int q = 0; q < S4; ++q) a_cur[q] = img[q];
+  int t = 0;
+  const float* xlane = xs + m0;
+  const float* alane = as + g * Tp + m0;
+
+  for (int ht = nht - 1; ht >= 0; --ht) {
+    const int lim = c.masked ? (ht + 1 < nft ? ht + 1 : nft) : nft;
+    f32x4 xkv[4];  // [r], component rt: xk[m0+rt][4ht+r]
+#pragma unroll
+    for (int r = 0; r < 4; ++r) xkv[r] = *reinterpret_cast<const f32x4*>(xlane + (4 * ht + r) * Tp);
+    f32x4 accK[RT];  // [rt], component r: this fi group's part of dXk[m0+rt][4ht+r]
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) accK[rt] = zero4;
+    f32x4 U[2][RT];
+    f32x4 x0v[2];
+    auto fold = [&](int ft, const f32x4 (&T)[RT], const f32x4& xv) {
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          acc0[ft][rt] = fmaf(xkv[r][rt], T[rt][r], acc0[ft][rt]);
+          accK[rt][r] = fmaf(xv[rt], T[rt][r], accK[rt][r]);
+        }
+    };
+#pragma unroll
+    for (int ft = 0; ft < NFT; ++ft) {
+      if (ft < lim) {
+        const int tn = t + 1 < tlast ? t + 1 : tlast;  // next tile's image (clamped reload at the end)
+#pragma unroll
+        for (int q = 0; q < S4; ++q) a_nxt[q] = img[(size_t)tn * 64 * S4 + q];
+        x0v[ft & 1] = *reinterpret_cast<const f32x4*>(alane + 4 * ft * Tp);
+#pragma unroll
+        for (int s = 0; s < S; ++s)
+#pragma unroll
+          for (int rt = 0; rt < RT; ++rt)
+            U[ft & 1][rt] = mfma(a_cur[s >> 2][s & 3], dc[s][rt], s == 0 ? zero4 : U[ft & 1][rt]);
+#pragma unroll
+        for (int q = 0; q < S4; ++q) a_cur[q] = a_nxt[q];
+        ++t;
+      }
+      // the previous tile is folded in while this one multiplies
+      if (ft >= 1 && ft - 1 < lim) fold(ft - 1, U[(ft - 1) & 1], x0v[(ft - 1) & 1]);
+    }
+    if (NFT - 1 < lim) fold(NFT - 1, U[(NFT - 1) & 1], x0v[(NFT - 1) & 1]);
+    // add the 4 fi groups: after the two swaps lane group g holds the total of r = g
+    f32x4 tot;
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+      auto s02 = __builtin_amdgcn_permlane32_swap(__float_as_uint(accK[rt][0]), __float_as_uint(accK[rt][2]), false, false);
+      auto s13 = __builtin_amdgcn_permlane32_swap(__float_as_uint(accK[rt][1]), __float_as_uint(accK[rt][3]), false, false);
+      const float p0 = __uint_as_float(s02[0]) + __uint_as_float(s02[1]);
+      const float p1 = __uint_as_float(s13[0]) + __uint_as_float(s13[1]);
+      auto s01 = __builtin_amdgcn_permlane16_swap(__float_as_uint(p0), __float_as_uint(p1), false, false);
+      tot[rt] = __uint_as_float(s01[0]) + __uint_as_float(s01[1]);
+    }
+    *reinterpret_cast<f32x4*>(xs + (4 * ht + g) * Tp + m0) = tot;  // rows 4ht.. of xk are dead
+  }
+  // dX0: lane (g, j) owns feature 4ft+g of its rows
+#pragma unroll
+  for (int ft = 0; ft < NFT; ++ft) {
+    if (ft < nft) {
+      f32x4* dst = reinterpret_cast<f32x4*>(as + (4 * ft + g) * Tp + m0);
+      f32x4 v = acc0[ft];
+      if (shared_x) v += *dst;  // layer 0: both roles are x0
+      *dst = v;
+    }
+  }
+  __syncthreads();
+  const float scale = c.masked ? 2.f : 1.f;
+  {
+    const int total = nb * c.F * c.D;
+    float* base = d_x0 + b0 * c.F * c.D;
+    for (int idx = threadIdx.x; idx < total; idx += blockDim.x) {
+      const int bl = idx / (c.F * c.D);
+      const int rem = idx - bl * c.F * c.D;
+      const int f = rem / c.D;
+      const int d = rem - f * c.D;
+      base[idx] += as[f * Tp + bl * c.D + d] * scale;
+    }
+  }
+  if (!shared_x) {
+    const int total = nb * c.H * c.D;
+    float* base = d_xk + b0 * c.H * c.D;
+    for (int idx = threadIdx.x; idx < total; idx += blockDim.x) {
+      const int bl = idx / (c.H * c.D);
+      const int rem = idx - bl * c.H * c.D;
+      const int h = rem / c.D;
+      const int d = rem - h * c.D;
+      base[idx] = xs[h * Tp + bl * c.D + d] * scale;
+    }
+  }
+}
+
 // ----------------------------------------------------------------- filter gradient
 // tile t -> (ft, ht); the masked layer enumerates ht >= ft only, ft-major
 __host__ __device__ inline int n_tiles(int nft, int nht, int masked) {
@@ -999,11 +1189,20 @@ int fwd_mfma(const CinDims& c, const float* x0, const float* xk, const float* w,
   return XDFM_OK;
 }
 
+// filter image of the input-gradient kernels: the larger of the two layouts (the unmasked tile
+// count bounds the masked one)
+static size_t wpk_region_floats(int F, int H, int L) {
+  const int nft = (F + 3) / 4, nht = (H + 3) / 4, Hp = (H + 3) & ~3, S = (L + 3) / 4;
+  const size_t old_img = (size_t)nft * 4 * Hp * (4 * smax_for(S) + 1);
+  const size_t new_img = (size_t)nft * nht * 64 * (S <= 3 ? 4 : 8);  // S <= 5 only
+  return ((old_img > new_img ? old_img : new_img) + 3) & ~(size_t)3;
+}
+
 size_t bwd_mfma_workspace_floats(int64_t B, int F, int H, int D, int L, int masked) {
   const int nft = (F + 3) / 4, nht = (H + 3) / 4;
   const int ntile = n_tiles(nft, nht, masked);
   const int Hp = (H + 3) & ~3, S = (L + 3) / 4;
-  const size_t wpk = (size_t)nft * 4 * Hp * (4 * smax_for(S) + 1);
+  const size_t wpk = wpk_region_floats(F, H, L);
   return (((size_t)B * D * L + 3) & ~(size_t)3) + wpk + (size_t)dw_splits(B * D) * ntile * 16 * L;
 }
 
@@ -1013,7 +1212,7 @@ int bwd_mfma(const CinDims& c, const float* x0, const float* xk, const float* w,
   float* dc_mn = ws;
   float* wpk = ws + (((size_t)c.B * c.D * c.L + 3) & ~(size_t)3);  // 16-byte aligned: staged as float4
   const size_t wpk_floats = (size_t)((c.F + 3) / 4) * 4 * ((c.H + 3) & ~3) * (4 * smax_for((c.L + 3) / 4) + 1);
-  float* part = wpk + wpk_floats;
+  float* part = wpk + wpk_region_floats(c.F, c.H, c.L);
   {
     const int64_t total = c.B * c.D * c.L;
     XDFM_LAUNCH("cin_dcurr_kernel", st, cin_dcurr_kernel, dim3((unsigned)((total + 255) / 256)),
@@ -1024,7 +1223,35 @@ int bwd_mfma(const CinDims& c, const float* x0, const float* xk, const float* w,
   const int S = (c.L + 3) / 4;
   const bool shared_x = (xk == x0);
   // ---- input gradients
-  {
+  const size_t dx2_lds = (size_t)(Hp + (shared_x ? 0 : Fp)) * (256 + kPad) * sizeof(float);
+  if (nft <= 10 && S <= 5 && dx2_lds <= kLdsLimit) {
+    const int SPB = 256 / c.D;
+    const int ntiles = n_tiles(nft, nht, c.masked);
+    dim3 grid((unsigned)((c.B + SPB - 1) / SPB));
+#define CALL2(NF, SS)                                                                                  \
+  do {                                                                                                 \
+    const int64_t total = (int64_t)ntiles * 64 * ((SS + 3) & ~3);                                      \
+    XDFM_LAUNCH("cin_pack_dx_kernel", st, cin_pack_dx_kernel<SS>, dim3((unsigned)((total + 255) / 256)), \
+                dim3(256), 0, c, w, nft, nht, ntiles, wpk);                                            \
+    int rc = allow_lds(cin_bwd_dx2_mfma_kernel<NF, SS>, dx2_lds);                                      \
+    if (rc) return rc;                                                                                 \
+    XDFM_LAUNCH("cin_bwd_dx2_mfma_kernel<" #NF ", " #SS ">", st, (cin_bwd_dx2_mfma_kernel<NF, SS>),    \
+                grid, dim3(256), dx2_lds, c, x0, xk, wpk, d_xnext, d_pooled, pool_stride, pool_off,    \
+                d_xk, d_x0, SPB, ntiles);                                                              \
+  } while (0)
+    if (nft <= 3) {
+      if (S <= 3)
+        CALL2(3, 3);
+      else
+        CALL2(3, 5);
+    } else {
+      if (S <= 3)
+        CALL2(10, 3);
+      else
+        CALL2(10, 5);
+    }
+#undef CALL2
+  } else {
     const int SPB = 64 / c.D;
     const int Lp = 4 * smax_for(S) + 1;
     const size_t lds_bytes =
