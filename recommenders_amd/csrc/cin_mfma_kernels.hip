@@ -27,6 +27,7 @@
 namespace xdfm_cin {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 namespace {
 
@@ -902,44 +903,54 @@ __host__ __device__ inline int tile_index(int ft, int ht, int nft, int nht, int 
   return ft * nft - ft * (ft - 1) / 2 + (ht - ft);
 }
 
-// Block = 4 waves sharing RC rows at a time; wave w owns PT pair tiles.
-// A[i=pair][k=row] = x0[row][f_i] * xk[row][h_i]   (LDS, [row][feature] layout)
-// B[k=row][j=ch]   = dcurr[row][c0 + j]            (global)
-// D[pair=(lane>>4)*4+r][ch=lane&15]
-template <int PT, int NT>
+// Block = 4 waves sharing chunks of 64 rows; wave w owns PT pair tiles (4 f x 4 h each).
+//   A[i=pair][k=row] = x0[row][f_i] * xk[row][h_i]     one v_mul per operand
+//   B[k=row][j=ch]   = dcurr[row][c0 + j]
+//   D[pair=(lane>>4)*4+r][ch=lane&15]
+// Built to issue little besides MFMAs and that one multiply (fp32 MFMAs and VALU ops share the
+// SIMD lanes): the chunk sits in LDS as [feature][row] and [channel][row], the MFMA's k index
+// is mapped to rows as row = 8*stage + 2*k + step, so one ds_read_b64 at a loop-invariant
+// address plus an immediate offset feeds two k-steps; the next chunk is fetched into registers
+// (x0/xk from their tensors, dcurr straight from d_xnext / d_pooled) while this one multiplies
+// and goes to the other LDS buffer afterwards: one barrier per chunk.
+template <int PT, int NT, int XU>
 __global__ __launch_bounds__(256) void cin_bwd_dw_mfma_kernel(
     CinDims c, const float* __restrict__ x0, const float* __restrict__ xk,
-    const float* __restrict__ dc_mn, int64_t rows_total, int rows_per_split,
-    float* __restrict__ part) {
+    const float* __restrict__ d_xnext, const float* __restrict__ d_pooled, int pool_stride,
+    int pool_off, int64_t rows_total, int rows_per_split, float* __restrict__ part) {
   extern __shared__ float lds[];
-  constexpr int RC = 64;
+  constexpr int RC = 64;    // rows per chunk
+  constexpr int RCp = 80;   // row stride of the LDS images (floats)
+  constexpr int NCH = NT * 16;
   const bool shared_x = (xk == x0);
   const int Hp = (c.H + 3) & ~3, Fp = (c.F + 3) & ~3;
   const int nht = Hp >> 2, nft = Fp >> 2;
-  const int Hs = Hp | 1, Fs = Fp | 1;  // odd strides: the 8 addresses of a k-group pair hit 8 banks
-  float* xs = lds;                     // [RC][Hs]
-  float* as = shared_x ? xs : lds + RC * Hs;  // [RC][Fs]
   const int ntile = n_tiles(nft, nht, c.masked);
+  const int buf_floats = (Hp + (shared_x ? 0 : Fp) + NCH) * RCp;
+  // buffer b: xs [Hp][RCp], as [Fp][RCp] (xs when shared), dcs [NCH][RCp]
+  const int as_off = shared_x ? 0 : Hp * RCp;
+  const int dc_off = (Hp + (shared_x ? 0 : Fp)) * RCp;
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane & 15, kk = lane >> 4;
   const int fi = j >> 2, hi = j & 3;
-  const int c0 = blockIdx.z * (NT * 16);
+  const int c0 = blockIdx.z * NCH;
   const int t0 = (blockIdx.y * 4 + wave) * PT;
-  int choff[NT];
-#pragma unroll
-  for (int nt = 0; nt < NT; ++nt) {
-    const int ch = c0 + nt * 16 + j;
-    choff[nt] = ch < c.L ? ch : c.L - 1;
-  }
-  int foff[PT], hoff[PT];
+
+  // LDS addresses of this lane's operands in the current buffer; they move to the other buffer
+  // and back with one add per chunk
+  int a_ptr[PT], x_ptr[PT], b_ptr[NT];  // float offsets into lds
 #pragma unroll
   for (int p = 0; p < PT; ++p) {
     int ft = 0, ht = 0;
     if (t0 + p < ntile) tile_of(t0 + p, nft, nht, c.masked, &ft, &ht);
-    foff[p] = 4 * ft + fi;
-    hoff[p] = 4 * ht + hi;
+    a_ptr[p] = as_off + (4 * ft + fi) * RCp + 2 * kk;
+    x_ptr[p] = (4 * ht + hi) * RCp + 2 * kk;
   }
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) b_ptr[nt] = dc_off + (nt * 16 + j) * RCp + 2 * kk;
+  int buf_step = buf_floats;  // +buf_floats, -buf_floats, ...
+
   f32x4 acc[PT][NT];
 #pragma unroll
   for (int p = 0; p < PT; ++p)
@@ -950,92 +961,125 @@ __global__ __launch_bounds__(256) void cin_bwd_dw_mfma_kernel(
   int64_t r_end = r_beg + rows_per_split;
   if (r_end > rows_total) r_end = rows_total;
   const int HD = c.H * c.D, FD = c.F * c.D;
-  for (int64_t r0 = r_beg; r0 < r_end; r0 += RC) {
-    const int nr = (int)((r_end - r0 < RC) ? (r_end - r0) : RC);
-    __syncthreads();
-    // [row][h] <- xk[b][h][d] with row = b*D + d; unused cells are zero.  Thread t always
-    // serves row t & 63, so the sample / d split is done once per chunk.
-    {
-      const int rl = threadIdx.x & 63;
-      const int hq = threadIdx.x >> 6;  // 0..3
-      const int64_t m = r0 + rl;
-      const int64_t b = m / c.D;
-      const int d = (int)(m - b * c.D);
-      const bool row_ok = rl < nr;
-      const float* xrow = xk + b * HD + d;
-      for (int h0 = 0; h0 < Hp; h0 += 16) {
-        float v[4];
+
+  // staging: thread t serves row t & 63 of the chunk and the features / channels 4u + (its wave).
+  // Addresses are a wave-uniform base (scalar registers) plus one 32-bit lane offset, and LDS
+  // stores use immediate offsets, so nothing but the values themselves stays live over the loop.
+  const int srow = threadIdx.x & 63;
+  const int sq = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  float vx[XU], va[XU], vd[NCH / 4];
+  bool row_ok = false;  // of the fetched chunk; values are masked when they go to LDS, so that
+                        // nothing waits for the loads before the multiply loop
+  auto fetch = [&](int64_t r0) {
+    const int64_t m = r0 + srow;
+    row_ok = m < r_end;
+    const int64_t mc = row_ok ? m : r_beg;
+    const int b = (int)(mc / c.D);  // B*F*D < 2^31 (checked on the host)
+    const int d = (int)(mc - (int64_t)b * c.D);
+    const int xo = b * HD + d, ao = b * FD + d;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int h = h0 + 4 * u + hq;
-          v[u] = (row_ok && h < c.H) ? xrow[h * c.D] : 0.f;
-        }
+    for (int u = 0; u < XU; ++u) {
+      const int h = 4 * u + sq;
+      const float* hb = xk + (h < c.H ? h : c.H - 1) * c.D;  // uniform
+      vx[u] = hb[xo];
+    }
+    if (!shared_x) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int h = h0 + 4 * u + hq;
-          if (h < Hp) xs[rl * Hs + h] = v[u];
-        }
-      }
-      if (!shared_x) {
-        const float* arow = x0 + b * FD + d;
-        for (int f0 = 0; f0 < Fp; f0 += 16) {
-          float v[4];
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const int f = f0 + 4 * u + hq;
-            v[u] = (row_ok && f < c.F) ? arow[f * c.D] : 0.f;
-          }
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const int f = f0 + 4 * u + hq;
-            if (f < Fp) as[rl * Fs + f] = v[u];
-          }
-        }
+      for (int u = 0; u < XU; ++u) {
+        const int f = 4 * u + sq;
+        const float* fb = x0 + (f < c.F ? f : c.F - 1) * c.D;
+        va[u] = fb[ao];
       }
     }
-    __syncthreads();
+    const int no = b * c.n_hidden * c.D + d, po = b * pool_stride + pool_off - c.n_hidden;
+#pragma unroll
+    for (int u = 0; u < NCH / 4; ++u) {
+      const int ch = c0 + 4 * u + sq;
+      const int chc = ch < c.L ? ch : c.L - 1;  // uniform
+      if (chc < c.n_hidden)
+        vd[u] = (d_xnext + chc * c.D)[no];
+      else
+        vd[u] = (d_pooled + chc)[po];
+    }
+  };
+  auto stash = [&](float* buf) {
+    float* base = buf + sq * RCp + srow;
+#pragma unroll
+    for (int u = 0; u < XU; ++u)
+      if (4 * u + sq < Hp) base[4 * u * RCp] = (row_ok && 4 * u + sq < c.H) ? vx[u] : 0.f;
+    if (!shared_x) {
+#pragma unroll
+      for (int u = 0; u < XU; ++u)
+        if (4 * u + sq < Fp) base[as_off + 4 * u * RCp] = (row_ok && 4 * u + sq < c.F) ? va[u] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < NCH / 4; ++u)
+      base[dc_off + 4 * u * RCp] = (row_ok && c0 + 4 * u + sq < c.L) ? vd[u] : 0.f;
+  };
+
+  fetch(r_beg);
+  stash(lds);
+  __syncthreads();
+  int cur = 0;
+  for (int64_t r0 = r_beg; r0 < r_end; r0 += RC) {
+    const bool more = r0 + RC < r_end;
+    if (more) fetch(r0 + RC);
     if (t0 < ntile) {
-      // two k-steps (8 rows) per trip; operands of the next step are in flight while this one
-      // multiplies.  No predicated loads: rows past the chunk read zeros from LDS (so the
-      // clamped dcurr value they meet does not matter), channels past L are never stored.
-      struct Stage {
-        float b[NT];
-        float a[PT], x[PT];
+      // stage s = rows 8s .. 8s+7 (two k-steps), in two units of PT/2 tiles: the operands of the
+      // next unit are read while this one multiplies
+      constexpr int HP = PT / 2;
+      struct Unit {
+        f32x2 a[HP], x[HP];
       };
-      auto issue = [&](Stage& st, int rl) {
-        int64_t row = r0 + rl;
-        row = row < rows_total ? row : rows_total - 1;
-        const float* dr = dc_mn + row * c.L;
+      f32x2 bS[2][NT];
+      auto issue = [&](Unit& un, int s, int hf) {
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) st.b[nt] = dr[choff[nt]];
-        const float* ar = as + rl * Fs;
-        const float* xr = xs + rl * Hs;
+        for (int p = 0; p < HP; ++p) {
+          un.a[p] = *reinterpret_cast<const f32x2*>(lds + a_ptr[hf * HP + p] + 8 * s);
+          un.x[p] = *reinterpret_cast<const f32x2*>(lds + x_ptr[hf * HP + p] + 8 * s);
+        }
+        if (hf == 0) {
 #pragma unroll
-        for (int p = 0; p < PT; ++p) {
-          st.a[p] = ar[foff[p]];
-          st.x[p] = xr[hoff[p]];
+          for (int nt = 0; nt < NT; ++nt) bS[s & 1][nt] = *reinterpret_cast<const f32x2*>(lds + b_ptr[nt] + 8 * s);
         }
       };
-      auto compute = [&](const Stage& st) {
+      auto compute = [&](const Unit& un, int s, int hf) {
 #pragma unroll
-        for (int p = 0; p < PT; ++p) {
-          const float a = st.a[p] * st.x[p];
+        for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-          for (int nt = 0; nt < NT; ++nt) acc[p][nt] = mfma(a, st.b[nt], acc[p][nt]);
-        }
+          for (int p = 0; p < HP; ++p) {
+            const float z = un.a[p][ks] * un.x[p][ks];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+              acc[hf * HP + p][nt] = mfma(z, bS[s & 1][nt][ks], acc[hf * HP + p][nt]);
+          }
       };
-      Stage s0, s1;
-      issue(s0, kk);
-      for (int ks = 0; ks < RC; ks += 8) {
-        issue(s1, ks + 4 + kk);
+      Unit u0, u1;
+      issue(u0, 0, 0);
+#pragma unroll
+      for (int s = 0; s < RC / 8; ++s) {
+        issue(u1, s, 1);
         __builtin_amdgcn_sched_barrier(0);
-        compute(s0);
+        compute(u0, s, 0);
         __builtin_amdgcn_sched_barrier(0);
-        issue(s0, (ks + 8 < RC ? ks + 8 : 0) + kk);  // last trip: a harmless re-read of row kk
+        if (s + 1 < RC / 8) issue(u0, s + 1, 0);
         __builtin_amdgcn_sched_barrier(0);
-        compute(s1);
+        compute(u1, s, 1);
         __builtin_amdgcn_sched_barrier(0);
       }
+    }
+    if (more) {
+      stash(lds + (cur ^ 1) * buf_floats);  // nobody reads that buffer during this chunk
+      __syncthreads();
+      cur ^= 1;
+#pragma unroll
+      for (int p = 0; p < PT; ++p) {
+        a_ptr[p] += buf_step;
+        x_ptr[p] += buf_step;
+      }
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) b_ptr[nt] += buf_step;
+      buf_step = -buf_step;
     }
   }
   // part[split][tile*16 + pair][L]
@@ -1140,7 +1184,8 @@ bool mfma_supported(int64_t B, int F, int H, int D, int L) {
   if (dx_lds > kLdsLimit) return false;
   // forward tile: both inputs and the pooled channels of 256 rows
   if ((size_t)(Hp + Fp + L) * (256 + kPad) * sizeof(float) > kLdsLimit) return false;
-  (void)B;
+  // the filter-gradient kernel addresses its inputs with 32-bit element offsets
+  if (B * (int64_t)(F > H ? F : H) * D >= (int64_t)1 << 31 || B * (int64_t)L * D >= (int64_t)1 << 31) return false;
   return true;
 }
 
@@ -1213,11 +1258,6 @@ int bwd_mfma(const CinDims& c, const float* x0, const float* xk, const float* w,
   float* wpk = ws + (((size_t)c.B * c.D * c.L + 3) & ~(size_t)3);  // 16-byte aligned: staged as float4
   const size_t wpk_floats = (size_t)((c.F + 3) / 4) * 4 * ((c.H + 3) & ~3) * (4 * smax_for((c.L + 3) / 4) + 1);
   float* part = wpk + wpk_region_floats(c.F, c.H, c.L);
-  {
-    const int64_t total = c.B * c.D * c.L;
-    XDFM_LAUNCH("cin_dcurr_kernel", st, cin_dcurr_kernel, dim3((unsigned)((total + 255) / 256)),
-                dim3(256), 0, c, d_xnext, d_pooled, pool_stride, pool_off, dc_mn);
-  }
   const int Hp = (c.H + 3) & ~3, Fp = (c.F + 3) & ~3;
   const int nht = Hp / 4, nft = Fp / 4;
   const int S = (c.L + 3) / 4;
@@ -1252,6 +1292,11 @@ int bwd_mfma(const CinDims& c, const float* x0, const float* xk, const float* w,
     }
 #undef CALL2
   } else {
+    {
+      const int64_t total = c.B * c.D * c.L;
+      XDFM_LAUNCH("cin_dcurr_kernel", st, cin_dcurr_kernel, dim3((unsigned)((total + 255) / 256)),
+                  dim3(256), 0, c, d_xnext, d_pooled, pool_stride, pool_off, dc_mn);
+    }
     const int SPB = 64 / c.D;
     const int Lp = 4 * smax_for(S) + 1;
     const size_t lds_bytes =
@@ -1305,16 +1350,30 @@ int bwd_mfma(const CinDims& c, const float* x0, const float* xk, const float* w,
     const int nt_total = (c.L + 15) / 16;
     const int NT = nt_total >= 2 ? 2 : 1;
     constexpr int PT = 8;
-    const size_t lds_bytes = (size_t)64 * ((Hp | 1) + (shared_x ? 0 : (Fp | 1))) * sizeof(float);
+    const size_t lds_bytes = (size_t)2 * (Hp + (shared_x ? 0 : Fp) + NT * 16) * 80 * sizeof(float);
     dim3 grid((unsigned)n_splits, (unsigned)((ntile + 4 * PT - 1) / (4 * PT)),
               (unsigned)((nt_total + NT - 1) / NT));
+    const int maxp = Hp > Fp ? Hp : Fp;
+#define CALLW(NTV, XUV)                                                                               \
+  do {                                                                                                \
+    int rc = allow_lds(cin_bwd_dw_mfma_kernel<PT, NTV, XUV>, lds_bytes);                              \
+    if (rc) return rc;                                                                                \
+    XDFM_LAUNCH("cin_bwd_dw_mfma_kernel<8, " #NTV ">", st, (cin_bwd_dw_mfma_kernel<PT, NTV, XUV>),    \
+                grid, dim3(256), lds_bytes, c, x0, xk, d_xnext, d_pooled, pool_stride, pool_off,      \
+                rows, rows_per_split, part);                                                          \
+  } while (0)
     if (NT == 2) {
-      XDFM_LAUNCH("cin_bwd_dw_mfma_kernel<8, 2>", st, (cin_bwd_dw_mfma_kernel<PT, 2>), grid, dim3(256),
-                  lds_bytes, c, x0, xk, dc_mn, rows, rows_per_split, part);
+      if (maxp <= 40)
+        CALLW(2, 10);
+      else
+        CALLW(2, 32);
     } else {
-      XDFM_LAUNCH("cin_bwd_dw_mfma_kernel<8, 1>", st, (cin_bwd_dw_mfma_kernel<PT, 1>), grid, dim3(256),
-                  lds_bytes, c, x0, xk, dc_mn, rows, rows_per_split, part);
+      if (maxp <= 40)
+        CALLW(1, 10);
+      else
+        CALLW(1, 32);
     }
+#undef CALLW
     const int64_t total = (int64_t)c.F * c.H * c.L;
     XDFM_LAUNCH("cin_dw_unpack_kernel", st, cin_dw_unpack_kernel, dim3((unsigned)((total + 31) / 32)),
                 dim3(256), 0, c, part, n_splits, d_w);
