@@ -96,14 +96,15 @@ def kernel_models(hp, nnz, uniq):
         pairs = F * (F - 1) // 2 if masked else F * H  # masked pairs (f >= h) are never computed
         rows = B * D
         nt_total = (L + 15) // 16
-        nt = 4 if nt_total >= 4 else (2 if nt_total >= 2 else 1)
-        add("cin_fwd_mfma_kernel<%d, 4>" % nt, "mfma", 2.0 * rows * pairs * L)
-        nht = (H + 3) // 4
+        add("cin_fwd2_mfma_kernel", "mfma", 2.0 * rows * pairs * L + 2.0 * rows * min(F, H) * L)
+        nft, nht = (F + 3) // 4, (H + 3) // 4
         S = (L + 3) // 4
-        nh = 3 if nht <= 3 else (10 if nht <= 10 else 32)
-        sm = 3 if S <= 3 else (5 if S <= 5 else (16 if S <= 16 else 64))
-        add("cin_bwd_dx_mfma_kernel<%d, %d>" % (nh, sm), "mfma", 2.0 * rows * pairs * L + 4.0 * rows * pairs)
-        add("cin_bwd_dw_mfma_kernel<8, %d>" % (2 if nt_total >= 2 else 1), "mfma", 2.0 * rows * pairs * L)
+        nf = 3 if nft <= 3 else 10
+        ss = 3 if S <= 3 else 5
+        add("cin_bwd_dx2_mfma_kernel<%d, %d>" % (nf, ss), "mfma", 2.0 * rows * pairs * L + 4.0 * rows * pairs)
+        ntile = nft * (nft + 1) // 2 if masked else nft * nht
+        pt = 7 if (ntile + 27) // 28 * 28 < (ntile + 31) // 32 * 32 else 8
+        add("cin_bwd_dw_mfma_kernel<%d, %d>" % (pt, 2 if nt_total >= 2 else 1), "mfma", 2.0 * rows * pairs * L)
         H = L // 2 if k != n_layers - 1 else L
     return m
 

@@ -1027,7 +1027,7 @@ __global__ __launch_bounds__(256) void cin_bwd_dw_mfma_kernel(
     if (t0 < ntile) {
       // stage s = rows 8s .. 8s+7 (two k-steps), in two units of PT/2 tiles: the operands of the
       // next unit are read while this one multiplies
-      constexpr int HP = PT / 2;
+      constexpr int HP = (PT + 1) / 2;  // unit 0: tiles 0..HP-1, unit 1: tiles HP..PT-1
       struct Unit {
         f32x2 a[HP], x[HP];
       };
@@ -1035,8 +1035,10 @@ __global__ __launch_bounds__(256) void cin_bwd_dw_mfma_kernel(
       auto issue = [&](Unit& un, int s, int hf) {
 #pragma unroll
         for (int p = 0; p < HP; ++p) {
-          un.a[p] = *reinterpret_cast<const f32x2*>(lds + a_ptr[hf * HP + p] + 8 * s);
-          un.x[p] = *reinterpret_cast<const f32x2*>(lds + x_ptr[hf * HP + p] + 8 * s);
+          if (hf * HP + p < PT) {
+            un.a[p] = *reinterpret_cast<const f32x2*>(lds + a_ptr[hf * HP + p] + 8 * s);
+            un.x[p] = *reinterpret_cast<const f32x2*>(lds + x_ptr[hf * HP + p] + 8 * s);
+          }
         }
         if (hf == 0) {
 #pragma unroll
@@ -1048,10 +1050,12 @@ __global__ __launch_bounds__(256) void cin_bwd_dw_mfma_kernel(
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
           for (int p = 0; p < HP; ++p) {
-            const float z = un.a[p][ks] * un.x[p][ks];
+            if (hf * HP + p < PT) {
+              const float z = un.a[p][ks] * un.x[p][ks];
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-              acc[hf * HP + p][nt] = mfma(z, bS[s & 1][nt][ks], acc[hf * HP + p][nt]);
+              for (int nt = 0; nt < NT; ++nt)
+                acc[hf * HP + p][nt] = mfma(z, bS[s & 1][nt][ks], acc[hf * HP + p][nt]);
+            }
           }
       };
       Unit u0, u1;
@@ -1349,29 +1353,35 @@ int bwd_mfma(const CinDims& c, const float* x0, const float* xk, const float* w,
     const int ntile = n_tiles(nft, nht, c.masked);
     const int nt_total = (c.L + 15) / 16;
     const int NT = nt_total >= 2 ? 2 : 1;
-    constexpr int PT = 8;
+    // pair tiles per wave: 7 when that wastes fewer wave slots than 8 (55 tiles: 56 vs 64)
+    const int maxp = Hp > Fp ? Hp : Fp;
+    const int slots8 = (ntile + 31) / 32 * 32, slots7 = (ntile + 27) / 28 * 28;
+    const int PT = (maxp <= 40 && slots7 < slots8) ? 7 : 8;
     const size_t lds_bytes = (size_t)2 * (Hp + (shared_x ? 0 : Fp) + NT * 16) * 80 * sizeof(float);
     dim3 grid((unsigned)n_splits, (unsigned)((ntile + 4 * PT - 1) / (4 * PT)),
               (unsigned)((nt_total + NT - 1) / NT));
-    const int maxp = Hp > Fp ? Hp : Fp;
-#define CALLW(NTV, XUV)                                                                               \
+#define CALLW(PTV, NTV, XUV)                                                                          \
   do {                                                                                                \
-    int rc = allow_lds(cin_bwd_dw_mfma_kernel<PT, NTV, XUV>, lds_bytes);                              \
+    int rc = allow_lds(cin_bwd_dw_mfma_kernel<PTV, NTV, XUV>, lds_bytes);                             \
     if (rc) return rc;                                                                                \
-    XDFM_LAUNCH("cin_bwd_dw_mfma_kernel<8, " #NTV ">", st, (cin_bwd_dw_mfma_kernel<PT, NTV, XUV>),    \
-                grid, dim3(256), lds_bytes, c, x0, xk, d_xnext, d_pooled, pool_stride, pool_off,      \
-                rows, rows_per_split, part);                                                          \
+    XDFM_LAUNCH("cin_bwd_dw_mfma_kernel<" #PTV ", " #NTV ">", st,                                     \
+                (cin_bwd_dw_mfma_kernel<PTV, NTV, XUV>), grid, dim3(256), lds_bytes, c, x0, xk,       \
+                d_xnext, d_pooled, pool_stride, pool_off, rows, rows_per_split, part);                \
   } while (0)
     if (NT == 2) {
-      if (maxp <= 40)
-        CALLW(2, 10);
+      if (maxp > 40)
+        CALLW(8, 2, 32);
+      else if (PT == 7)
+        CALLW(7, 2, 10);
       else
-        CALLW(2, 32);
+        CALLW(8, 2, 10);
     } else {
-      if (maxp <= 40)
-        CALLW(1, 10);
+      if (maxp > 40)
+        CALLW(8, 1, 32);
+      else if (PT == 7)
+        CALLW(7, 1, 10);
       else
-        CALLW(1, 32);
+        CALLW(8, 1, 10);
     }
 #undef CALLW
     const int64_t total = (int64_t)c.F * c.H * c.L;
