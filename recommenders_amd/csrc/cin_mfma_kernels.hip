@@ -1128,7 +1128,17 @@ __global__ __launch_bounds__(256) void cin_dw_unpack_kernel(CinDims c, const flo
       const int64_t slot = (int64_t)t * 16 + (f & 3) * 4 + (h & 3);
       const int64_t stride = (int64_t)ntile * 16 * c.L;
       const float* src = part + slot * c.L + n;
-      for (int k = g; k < n_splits; k += 8) s += src[k * stride];
+      // 8 loads in flight, added in split order
+      for (int k0 = g; k0 < n_splits; k0 += 64) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int k = k0 + 8 * u;
+          v[u] = src[(k < n_splits ? k : k0) * stride];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += (k0 + 8 * u < n_splits) ? v[u] : 0.f;
+      }
     }
   }
   red[g][e] = s;

@@ -229,47 +229,68 @@ __global__ __launch_bounds__(256) void dense_bwd_dw_mfma_kernel(
   int64_t r_end = r_beg + rows_per_split;
   if (r_end > B) r_end = B;
   if (r_beg >= r_end) r_end = r_beg;  // an empty split still writes its zero partials
+  // issue() only loads; masks and the activation gradient are applied in compute(), so that no
+  // stage waits for its own loads (a select right after a load would)
   struct Stage {
     float a[PT];
-    float b[NT];
+    float g[NT], yv[NT];
+    bool ok;
   };
   auto issue = [&](Stage& st, int64_t r) {
-    const bool ok = r < r_end;
-    int64_t rc = ok ? r : r_end - 1;
+    st.ok = r < r_end;
+    int64_t rc = st.ok ? r : r_end - 1;
     if (rc < 0) rc = 0;
     const float* xr = x + rc * K;
 #pragma unroll
     for (int p = 0; p < PT; ++p) {
       const int k = kcol[p];
-      float v = xr[k < K ? k : K - 1];
-      v = (k < K) ? v : (k == K ? 1.f : 0.f);
-      st.a[p] = ok ? v : 0.f;  // rows past the split contribute nothing
+      st.a[p] = xr[k < K ? k : K - 1];
     }
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-      const float g = dy[rc * Nout + choff[nt]] * act_grad(y[rc * Nout + choff[nt]], act);
-      st.b[nt] = chok[nt] ? g : 0.f;
+      st.g[nt] = dy[rc * Nout + choff[nt]];
+      st.yv[nt] = y[rc * Nout + choff[nt]];
     }
   };
   auto compute = [&](const Stage& st) {
+    float b[NT];
 #pragma unroll
-    for (int p = 0; p < PT; ++p)
+    for (int nt = 0; nt < NT; ++nt) {
+      const float g = st.g[nt] * act_grad(st.yv[nt], act);
+      b[nt] = (chok[nt] && st.ok) ? g : 0.f;  // rows past the split contribute nothing
+    }
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) acc[p][nt] = mfma(st.a[p], st.b[nt], acc[p][nt]);
+    for (int p = 0; p < PT; ++p) {
+      const int k = kcol[p];
+      const float a = (k < K) ? st.a[p] : (k == K ? 1.f : 0.f);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[p][nt] = mfma(a, b[nt], acc[p][nt]);
+    }
   };
-  Stage s0, s1;
+  // four stages (16 rows) in flight: the loop runs at memory latency otherwise
+  Stage s0, s1, s2, s3;
   int64_t r = r_beg + kk;
   issue(s0, r);
-  for (int64_t rb = r_beg; rb < r_end; rb += 8) {
-    issue(s1, r + 4);
+  issue(s1, r + 4);
+  issue(s2, r + 8);
+  for (int64_t rb = r_beg; rb < r_end; rb += 16) {
+    issue(s3, r + 12);
     __builtin_amdgcn_sched_barrier(0);
     compute(s0);
     __builtin_amdgcn_sched_barrier(0);
-    issue(s0, r + 8);
+    issue(s0, r + 16);
     __builtin_amdgcn_sched_barrier(0);
     compute(s1);
     __builtin_amdgcn_sched_barrier(0);
-    r += 8;
+    issue(s1, r + 20);
+    __builtin_amdgcn_sched_barrier(0);
+    compute(s2);
+    __builtin_amdgcn_sched_barrier(0);
+    issue(s2, r + 24);
+    __builtin_amdgcn_sched_barrier(0);
+    compute(s3);
+    __builtin_amdgcn_sched_barrier(0);
+    r += 16;
   }
   // part[split][k][n], k in [0, K] (row K = bias)
 #pragma unroll
@@ -297,8 +318,19 @@ __global__ __launch_bounds__(256) void dense_dw_reduce_kernel(const float* __res
   const int64_t idx = (int64_t)blockIdx.x * 32 + e;
   const int64_t total = (int64_t)(K + 1) * Nout;
   float s = 0.f;
-  if (idx < total)
-    for (int k = g; k < n_splits; k += 8) s += part[(int64_t)k * total + idx];
+  if (idx < total) {
+    // 8 loads in flight, added in split order
+    for (int k0 = g; k0 < n_splits; k0 += 64) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int k = k0 + 8 * u;
+        v[u] = part[(int64_t)(k < n_splits ? k : k0) * total + idx];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += (k0 + 8 * u < n_splits) ? v[u] : 0.f;
+    }
+  }
   red[g][e] = s;
   __syncthreads();
   if (g == 0 && idx < total) {
@@ -336,9 +368,13 @@ __global__ void cin_head_dpooled_kernel(const float* __restrict__ w, const float
   d_pooled[idx] = g[b] + g[b] * w[k];
 }
 
-int splits_for(int64_t B) {
-  int64_t s = (B + 127) / 128;
-  return (int)(s < 1 ? 1 : (s > 128 ? 128 : s));
+// row splits of the weight-gradient pass: as many as keep every split at >= 32 rows and the
+// partial sums ([split][K+1][Nout]) around 4 MB, at most 256
+int splits_for(int64_t B, int K, int Nout) {
+  int64_t s = (B + 31) / 32;
+  const int64_t by_size = ((int64_t)1 << 20) / ((int64_t)(K + 1) * Nout);
+  if (s > by_size) s = by_size;
+  return (int)(s < 1 ? 1 : (s > 256 ? 256 : s));
 }
 
 bool act_ok(int act) { return act >= XDFM_ACT_IDENTITY && act <= XDFM_ACT_ELU; }
@@ -369,7 +405,7 @@ extern "C" int xdfm_dense_fwd(const float* x, const float* w, const float* b, in
 
 extern "C" int xdfm_dense_bwd_workspace_floats(int64_t B, int32_t K, int32_t Nout, size_t* floats) {
   XDFM_REQUIRE(floats && B >= 0 && K > 0 && Nout > 0, "xdfm_dense_bwd_workspace_floats: bad argument");
-  *floats = (size_t)splits_for(B) * (K + 1) * Nout;
+  *floats = (size_t)splits_for(B, K, Nout) * (K + 1) * Nout;
   return XDFM_OK;
 }
 
@@ -387,7 +423,7 @@ extern "C" int xdfm_dense_bwd(const float* x, const float* w, const float* y, co
     XDFM_HIP(hipMemsetAsync(db, 0, (size_t)Nout * sizeof(float), st));
     return XDFM_OK;
   }
-  const int n_splits = splits_for(B);
+  const int n_splits = splits_for(B, K, Nout);
   const int rows_per_split = (int)((B + n_splits - 1) / n_splits);
   const int nt_total = (Nout + 15) / 16;
   const int ktiles = (K + 1 + 15) / 16;

@@ -92,27 +92,40 @@ __global__ __launch_bounds__(256) void dense_stats_kernel(SegTable tab, const fl
   }
 }
 
-// one block: finish the per-segment sums; pass 0 also produces the regularisation loss
-__global__ __launch_bounds__(kStatBlocks) void dense_stats_final_kernel(
+// one block of 16 waves: wave w finishes segments w and w + 16 (n_seg <= 32) with a fixed
+// shuffle tree, no barrier per segment; pass 0 also produces the regularisation loss
+__global__ __launch_bounds__(1024) void dense_stats_final_kernel(
     SegTable tab, const float* __restrict__ partial, int pass, float* __restrict__ stats,
     float* reg_loss, int accumulate) {
-  __shared__ float sh[kStatBlocks];
-  float reg = 0.f;
-  for (int s = 0; s < tab.n; ++s) {
-    const float a = block_sum<float, kStatBlocks>(partial[((size_t)s * kStatBlocks + threadIdx.x) * 2], sh);
-    const float b = block_sum<float, kStatBlocks>(partial[((size_t)s * kStatBlocks + threadIdx.x) * 2 + 1], sh);
-    if (threadIdx.x == 0) {
+  static_assert(kStatBlocks == 128, "two partials per lane");
+  __shared__ float regs[32];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int s = wave; s < tab.n; s += 16) {
+    const float* ps = partial + (size_t)s * kStatBlocks * 2;
+    float a = ps[lane * 2] + ps[(lane + 64) * 2];
+    float b = ps[lane * 2 + 1] + ps[(lane + 64) * 2 + 1];
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) {
+      a += __shfl_xor(a, m);
+      b += __shfl_xor(b, m);
+    }
+    if (lane == 0) {
       if (pass == 0) {
         stats[s * 4 + 0] = a;  // sum p^2
         stats[s * 4 + 1] = b;  // sum |p|
         // base_model.py:126-131 (l2_loss = sum/2), :141-147 (norm ord=1), :161-165 (ord=1, ord=2)
-        reg += tab.l2[s] * (a * 0.5f) + tab.l1[s] * b + tab.nl2[s] * sqrtf(a);
+        regs[s] = tab.l2[s] * (a * 0.5f) + tab.l1[s] * b + tab.nl2[s] * sqrtf(a);
       } else {
         stats[s * 4 + 2] = a;  // sum (total grad)^2
       }
     }
   }
-  if (threadIdx.x == 0 && pass == 0 && reg_loss) *reg_loss = accumulate ? *reg_loss + reg : reg;
+  __syncthreads();
+  if (threadIdx.x == 0 && pass == 0 && reg_loss) {
+    float reg = 0.f;
+    for (int s = 0; s < tab.n; ++s) reg += regs[s];
+    *reg_loss = accumulate ? *reg_loss + reg : reg;
+  }
 }
 
 __global__ __launch_bounds__(256) void dense_update_kernel(SegTable tab, OptDev o, float* __restrict__ param,
@@ -439,12 +452,12 @@ extern "C" int xdfm_dense_update(float* param, const float* grad, float* slot_m,
   if (need_stats) {
     XDFM_LAUNCH("dense_stats_kernel", st, dense_stats_kernel, dim3(kStatBlocks, n_seg), dim3(256), 0, tab, param, grad,
                        stats, 0, partial);
-    XDFM_LAUNCH("dense_stats_final_kernel", st, dense_stats_final_kernel, dim3(1), dim3(kStatBlocks), 0, tab, partial, 0,
+    XDFM_LAUNCH("dense_stats_final_kernel", st, dense_stats_final_kernel, dim3(1), dim3(1024), 0, tab, partial, 0,
                        stats, reg_loss, accumulate_reg_loss);
     if (opt->clip_norm > 0.f) {
       XDFM_LAUNCH("dense_stats_kernel", st, dense_stats_kernel, dim3(kStatBlocks, n_seg), dim3(256), 0, tab, param,
                          grad, stats, 1, partial);
-      XDFM_LAUNCH("dense_stats_final_kernel", st, dense_stats_final_kernel, dim3(1), dim3(kStatBlocks), 0, tab, partial, 1,
+      XDFM_LAUNCH("dense_stats_final_kernel", st, dense_stats_final_kernel, dim3(1), dim3(1024), 0, tab, partial, 1,
                          stats, nullptr, 0);
     }
   }
