@@ -3,20 +3,24 @@
 //
 // Reference: recommenders/models/deeprec/models/xDeepFM.py:191-267.  The reference
 // materialises Z[b,d,f*H+h] = X0[b,f,d]*Xk[b,h,d] (:192-200), masks layer 0 (:208-217) and
-// runs a width-1 conv1d = GEMM over the pair index (:220-222).  Here Z is an MFMA operand
-// that is formed in registers (one v_mul per operand) from LDS-resident X tiles and never
-// stored.  With m = (sample, d) the three contractions are
+// runs a width-1 conv1d = GEMM over the pair index (:220-222).  Z is never stored here.
+// With m = (sample, d) the three contractions and the form each kernel uses:
 //
-//   forward   curr[m,n]   = sum_p  Z[m,p] W[p,n]          M = rows,  N = channels, K = pairs
-//   d-input   T[m,p]      = sum_n  dcurr[m,n] W[p,n]      M = rows,  N = pairs,    K = channels
-//             dXk[m,h]    = sum_f  X0[m,f] T[m,(f,h)] ,  dX0[m,f] = sum_h Xk[m,h] T[m,(f,h)]
-//   d-filter  dW[p,n]     = sum_m  Z[m,p] dcurr[m,n]      M = pairs, N = channels, K = rows
+//   forward   curr[m,n] = sum_o Xo[m,o] * (sum_i Xi[m,i] W[(o,i),n])   inner sum on the matrix
+//             cores (K = the longer feature axis), outer sum as 4 FMAs per 4x4 (o, n) tile
+//   d-input   T[(f,h),m] = sum_n W[(f,h),n] dcurr[m,n]                 matrix cores, K = channels
+//             dXk[m,h] = sum_f X0[m,f] T ,  dX0[m,f] = sum_h Xk[m,h] T   2 FMAs per product
+//   d-filter  dW[p,n] = sum_m Z[m,p] dcurr[m,n]     matrix cores, K = rows, Z = one v_mul per
+//             operand from LDS-resident X tiles
 //
-// Pairs of the masked layer 0 (f >= h) are never computed.  All sums have a fixed
-// association (no float atomics): results are bit-identical from run to run.
+// Pairs of the masked layer 0 (f >= h) are skipped at tile granularity.  All sums have a
+// fixed association (no float atomics): results are bit-identical from run to run.
+// On gfx950 fp32 MFMAs and fp32 VALU ops share the SIMD's lanes (tools/ub_mfma_mix.hip), so
+// every kernel is laid out to issue as little as possible besides its MFMAs: operands come
+// from LDS with wide reads at loop-invariant addresses, filters from images packed in MFMA
+// operand order.
 //
-// Layouts: x0[B][F][D], xk[B][H][D], w[F*H][L], xnext[B][n_hidden][D], pooled[B][stride],
-// dc_mn[B*D][L] (upstream gradient of curr in row-major (m, n) order).
+// Layouts: x0[B][F][D], xk[B][H][D], w[F*H][L], xnext[B][n_hidden][D], pooled[B][stride].
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
@@ -35,22 +39,6 @@ constexpr int kPad = 16;  // LDS row stride = rows + 16 floats: the four k-group
 
 __device__ __forceinline__ f32x4 mfma(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
-}
-
-// k-th valid pair -> (f, h); the masked layer enumerates f < h only, f-major
-__device__ __forceinline__ void pair_of(int q, int H, int masked, int* f, int* h) {
-  if (!masked) {
-    *f = q / H;
-    *h = q - *f * H;
-    return;
-  }
-  int ff = 0, rem = q;
-  while (rem >= H - 1 - ff) {
-    rem -= H - 1 - ff;
-    ++ff;
-  }
-  *f = ff;
-  *h = ff + 1 + rem;
 }
 
 // stage src[b0 .. b0+nb)[R][D] transposed into lds[r * Tp + bl*D + d]; rows R..Rpad are zero.
@@ -112,139 +100,6 @@ __device__ __forceinline__ void stage_cols(const float* __restrict__ src, int64_
   for (int idx = threadIdx.x; idx < R * padc; idx += nt) {
     const int r = idx / padc;
     lds[r * Tp + cols + (idx - r * padc)] = 0.f;
-  }
-}
-
-// ------------------------------------------------------------------------ forward
-// Block = 4 waves; a wave owns RT row tiles of 16 rows; NT channel tiles of 16 per block.
-// A[i=row][k=pair] = x0[f_k][row] * xk[h_k][row]   (lane: i = lane&15, k = lane>>4)
-// B[k=pair][j=ch]  = w[pair_k][c0 + j]             (lane: j = lane&15, k = lane>>4), from L1/L2
-template <int NT, int RT>
-__global__ __launch_bounds__(256) void cin_fwd_mfma_kernel(
-    CinDims c, const float* __restrict__ x0, const float* __restrict__ xk,
-    const float* __restrict__ w, float* __restrict__ xnext, float* __restrict__ pooled,
-    int pool_stride, int pool_off, int SPB, int P, int lds_rows) {
-  extern __shared__ float lds[];
-  constexpr int ROWS = 64 * RT;
-  constexpr int Tp = ROWS + kPad;
-  const bool shared_x = (xk == x0);
-  float* xs = lds;
-  float* as = shared_x ? xs : lds + c.H * Tp;
-  int* ptab = reinterpret_cast<int*>(lds + lds_rows * Tp);
-  const int Ppad = (P + 3) & ~3;
-
-  const int64_t b0 = (int64_t)blockIdx.x * SPB;
-  const int nb = (int)((c.B - b0 < SPB) ? (c.B - b0) : SPB);
-  stage_cols(xk, b0, nb, c.H, c.H, c.D, xs, Tp);
-  if (!shared_x) stage_cols(x0, b0, nb, c.F, c.F, c.D, as, Tp);
-  // pair table, padded by two steps so that the prefetches below never leave it;
-  // entry = f | h << 8, sign bit set for a padding slot (f = h = 0, operand forced to zero)
-  for (int k = threadIdx.x; k < Ppad + 8; k += blockDim.x) {
-    int f = 0, h = 0;
-    if (k < P) pair_of(k, c.H, c.masked, &f, &h);
-    ptab[k] = (k < P) ? (f | (h << 8)) : (int)0x80000000;
-  }
-  __syncthreads();
-
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int i = lane & 15, kk = lane >> 4;
-  const int c0 = blockIdx.y * (NT * 16);
-  const int rbase = wave * (16 * RT) + i;  // + 16*rt
-
-  f32x4 acc[RT][NT];
-#pragma unroll
-  for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) acc[rt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  // channel offsets, clamped: columns >= L compute garbage that is never stored
-  int choff[NT];
-#pragma unroll
-  for (int nt = 0; nt < NT; ++nt) {
-    const int ch = c0 + nt * 16 + i;
-    choff[nt] = ch < c.L ? ch : c.L - 1;
-  }
-  // Software pipeline, two steps per trip, no predicated loads: while step s multiplies,
-  // the filter values and X values of step s+1 are in flight and the pair of step s+2 is read.
-  struct Stage {
-    float b[NT];
-    float a[RT], x[RT];
-    int pt;
-  };
-  auto issue = [&](Stage& st, int pt) {
-    const int f = pt & 0xff, h = (pt >> 8) & 0xff;
-    const unsigned wrow = (unsigned)((f * c.H + h) * c.L);  // F*H*L < 2^31 (checked on the host)
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) st.b[nt] = w[wrow + (unsigned)choff[nt]];
-    const float* ap = as + f * Tp + rbase;
-    const float* xp = xs + h * Tp + rbase;
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt) {
-      st.a[rt] = ap[16 * rt];
-      st.x[rt] = xp[16 * rt];
-    }
-    st.pt = pt;
-  };
-  auto compute = [&](const Stage& st) {
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt) {
-      float a = st.a[rt] * st.x[rt];
-      a = st.pt < 0 ? 0.f : a;
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) acc[rt][nt] = mfma(a, st.b[nt], acc[rt][nt]);
-    }
-  };
-  Stage s0, s1;
-  issue(s0, ptab[kk]);
-  int pt_next = ptab[4 + kk];
-  for (int k0 = 0; k0 < Ppad; k0 += 8) {
-    // sched_barrier(0): keep the compiler from sinking the loads of the next step to their uses
-    const int pt_a = ptab[k0 + 8 + kk];
-    issue(s1, pt_next);
-    __builtin_amdgcn_sched_barrier(0);
-    compute(s0);
-    __builtin_amdgcn_sched_barrier(0);
-    const int pt_b = ptab[k0 + 12 + kk];
-    issue(s0, pt_a);
-    __builtin_amdgcn_sched_barrier(0);
-    compute(s1);  // a padding step when Ppad is not a multiple of 8: operands are zero
-    __builtin_amdgcn_sched_barrier(0);
-    pt_next = pt_b;
-  }
-
-  // epilogue: transpose through LDS so that the global stores run along d
-  const float scale = c.masked ? 2.f : 1.f;  // exact, so applying it last changes no bit
-  __syncthreads();                           // everyone is done with the X tiles
-  float* out = lds;                          // [NT*16][Tp]
-#pragma unroll
-  for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-        out[(nt * 16 + i) * Tp + wave * (16 * RT) + rt * 16 + kk * 4 + r] = acc[rt][nt][r] * scale;
-  __syncthreads();
-  const int cols = nb * c.D;
-  int nch = c.L - c0;
-  if (nch > NT * 16) nch = NT * 16;
-  for (int idx = threadIdx.x; idx < nch * cols; idx += blockDim.x) {
-    const int ch = idx / cols;
-    const int rl = idx - ch * cols;
-    const int g = c0 + ch;
-    if (g < c.n_hidden) {
-      const int bl = rl / c.D, d = rl - bl * c.D;
-      xnext[((b0 + bl) * c.n_hidden + g) * c.D + d] = out[ch * Tp + rl];
-    }
-  }
-  for (int idx = threadIdx.x; idx < nch * nb; idx += blockDim.x) {
-    const int ch = idx / nb;
-    const int bl = idx - ch * nb;
-    const int g = c0 + ch;
-    if (g >= c.n_hidden) {
-      float s = 0.f;
-      for (int d = 0; d < c.D; ++d) s += out[ch * Tp + bl * c.D + d];  // reduce_sum over D (:270)
-      pooled[(b0 + bl) * pool_stride + pool_off + g - c.n_hidden] = s;
-    }
   }
 }
 
@@ -1260,7 +1115,6 @@ static size_t wpk_region_floats(int F, int H, int L) {
 size_t bwd_mfma_workspace_floats(int64_t B, int F, int H, int D, int L, int masked) {
   const int nft = (F + 3) / 4, nht = (H + 3) / 4;
   const int ntile = n_tiles(nft, nht, masked);
-  const int Hp = (H + 3) & ~3, S = (L + 3) / 4;
   const size_t wpk = wpk_region_floats(F, H, L);
   return (((size_t)B * D * L + 3) & ~(size_t)3) + wpk + (size_t)dw_splits(B * D) * ntile * 16 * L;
 }
