@@ -100,32 +100,85 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(
   int err = 0;
 
   if (lane_on) {
-    for (int f = g; f < F; f += RPP) {
-      const int64_t r = b * F + f;
-      const int beg = row_ptr[r], end = row_ptr[r + 1];
-      float acc[VEC];
+    // Up to PU rows per lane group are handled together: their CSR bounds, then their first
+    // tokens, then the table rows of those tokens are each requested in one go, so a sample
+    // costs three memory round trips instead of three per row.  Further tokens of a multi-hot
+    // row follow in column order (the sums stay bit-identical to the sequential form).
+    constexpr int PU = 4;
+    for (int f0 = g; f0 < F; f0 += PU * RPP) {
+      int beg[PU], end[PU];
 #pragma unroll
-      for (int v = 0; v < VEC; ++v) acc[v] = 0.f;
-      for (int k = beg; k < end; ++k) {
-        const int64_t id = ids[k];
-        const float w = weights[k];
-        if ((uint64_t)id >= (uint64_t)N) {
-          err |= XDFM_DEVERR_ID_RANGE;
-          continue;
-        }
-        float e[VEC];
-        load_vec<VEC>(table + id * D + c * VEC, e);
-#pragma unroll
-        for (int v = 0; v < VEC; ++v) {
-          const float t = w * e[v];               // one rounding (TF: embeddings *= weights)
-          acc[v] = (k == beg) ? t : acc[v] + t;   // segment_sum in column order
-          q_acc[v] += t * t;
-        }
-        if (c == 0 && lin_w) lin_acc += w * lin_w[id];
+      for (int u = 0; u < PU; ++u) {
+        const int f = f0 + u * RPP;
+        const int64_t r = b * F + (f < F ? f : F - 1);
+        beg[u] = row_ptr[r];
+        end[u] = row_ptr[r + 1];
+        if (f >= F) end[u] = beg[u];  // no such row: behaves as empty, nothing is stored
       }
-      store_vec<VEC>(emb_out + r * D + c * VEC, acc);
+      int64_t id0[PU];
+      float w0[PU];
+      bool has[PU];
 #pragma unroll
-      for (int v = 0; v < VEC; ++v) s_acc[v] += acc[v];
+      for (int u = 0; u < PU; ++u) {
+        has[u] = end[u] > beg[u];
+        const int k = has[u] ? beg[u] : 0;
+        id0[u] = ids[k];
+        w0[u] = weights[k];
+      }
+      float e0[PU][VEC];
+      float l0[PU];
+      bool ok0[PU];
+#pragma unroll
+      for (int u = 0; u < PU; ++u) {
+        ok0[u] = has[u] && (uint64_t)id0[u] < (uint64_t)N;
+        const int64_t idc = ok0[u] ? id0[u] : 0;
+        load_vec<VEC>(table + idc * D + c * VEC, e0[u]);
+        l0[u] = (c == 0 && lin_w) ? lin_w[idc] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < PU; ++u) {
+        const int f = f0 + u * RPP;
+        if (f >= F) continue;
+        const int64_t r = b * F + f;
+        float acc[VEC];
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) acc[v] = 0.f;
+        if (has[u]) {
+          if (ok0[u]) {
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) {
+              const float t = w0[u] * e0[u][v];  // one rounding (TF: embeddings *= weights)
+              acc[v] = t;
+              q_acc[v] += t * t;
+            }
+            if (c == 0 && lin_w) lin_acc += w0[u] * l0[u];
+          } else {
+            err |= XDFM_DEVERR_ID_RANGE;
+          }
+        }
+        bool first = !(has[u] && ok0[u]);  // no valid token summed yet
+        for (int k = beg[u] + 1; k < end[u]; ++k) {
+          const int64_t id = ids[k];
+          const float w = weights[k];
+          if ((uint64_t)id >= (uint64_t)N) {
+            err |= XDFM_DEVERR_ID_RANGE;
+            continue;
+          }
+          float e[VEC];
+          load_vec<VEC>(table + id * D + c * VEC, e);
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) {
+            const float t = w * e[v];
+            acc[v] = first ? t : acc[v] + t;  // segment_sum in column order
+            q_acc[v] += t * t;
+          }
+          first = false;
+          if (c == 0 && lin_w) lin_acc += w * lin_w[id];
+        }
+        store_vec<VEC>(emb_out + r * D + c * VEC, acc);
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) s_acc[v] += acc[v];
+      }
     }
   }
   if (err) atomicOr(err_flag, err);
