@@ -39,7 +39,15 @@ from recommenders_amd.synth import criteo_shape_ids  # noqa: E402
 
 # HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE doubled as MI355X_MICROARCH.md
 # prescribes for gfx950, + WRITE_SIZE), measured on this workload: profiles/r01_pmc_traffic.txt
-TRAFFIC = {}
+TRAFFIC = {
+    "cin_fwd2_mfma_kernel": 26.90e6,  # mean of the two layers' launches
+    "cin_bwd_dw_mfma_kernel<7, 2>": 44.66e6,
+    "cin_bwd_dw_mfma_kernel<8, 1>": 31.53e6,
+    "cin_bwd_dx2_mfma_kernel<10, 5>": 68.42e6,
+    "cin_bwd_dx2_mfma_kernel<10, 3>": 73.05e6,
+    "embed_fwd_kernel<4>": 52.97e6,
+    "embed_bwd_kernel<4, 0>": 137.66e6,
+}
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 F32_MATRIX_PEAK_TFLOPS = 157.3  # same guide: fp32 MFMA / vector peak
@@ -109,7 +117,7 @@ def kernel_models(hp, nnz, uniq):
     return m
 
 
-def run_cpu_baseline(hp, batches, budget_s=20.0):
+def run_cpu_baseline(hp, batches, budget_s=15.0):
     """The oracle's train_step (torch CPU fp32, sparse_rows) on the first batch(es)."""
     from oracle import xdeepfm_oracle as X
 
@@ -132,7 +140,7 @@ def run_cpu_baseline(hp, batches, budget_s=20.0):
         X.train_step(params, st, batches[(done + 1) % len(batches)], hp, mode="sparse_rows")
         done += 1
         el = time.perf_counter() - t0
-        if el > budget_s or done >= 8:
+        if el > budget_s or done >= 32:
             break
     return {"value": done * hp.batch_size / el, "unit": "samples/s", "cores": cores, "kind": "port",
             "sample": "%d training steps of the same batch-%d workload (oracle/xdeepfm_oracle.py, "
