@@ -109,10 +109,13 @@ def kernel_models(hp, nnz, uniq):
         S = (L + 3) // 4
         nf = 3 if nft <= 3 else 10
         ss = 3 if S <= 3 else 5
-        add("cin_bwd_dx2_mfma_kernel<%d, %d>" % (nf, ss), "mfma", 2.0 * rows * pairs * L + 4.0 * rows * pairs)
         ntile = nft * (nft + 1) // 2 if masked else nft * nht
         pt = 7 if (ntile + 27) // 28 * 28 < (ntile + 31) // 32 * 32 else 8
-        add("cin_bwd_dw_mfma_kernel<%d, %d>" % (pt, 2 if nt_total >= 2 else 1), "mfma", 2.0 * rows * pairs * L)
+        nt_w = 2 if nt_total >= 2 else 1
+        dx_flops = 2.0 * rows * pairs * L + 4.0 * rows * pairs
+        dw_flops = 2.0 * rows * pairs * L
+        add("cin_bwd_dx2_mfma_kernel<%d, %d>" % (nf, ss), "mfma", dx_flops)
+        add("cin_bwd_dw_mfma_kernel<%d, %d>" % (pt, nt_w), "mfma", dw_flops)
         H = L // 2 if k != n_layers - 1 else L
     return m
 

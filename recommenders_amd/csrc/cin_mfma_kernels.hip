@@ -584,13 +584,33 @@ __global__ void cin_pack_dx_kernel(CinDims c, const float* __restrict__ w, int n
   wdx[idx] = ok ? w[(int64_t)(f * c.H + h) * c.L + n] : 0.f;
 }
 
+struct Dx2Args {
+  const float* wdx;
+  float* d_xk;
+  float* d_x0;
+  int SPB, ntiles;
+};
+struct BwdIn {  // what both backward kernels read
+  CinDims c;
+  const float* x0;
+  const float* xk;
+  const float* d_xnext;
+  const float* d_pooled;
+  int pool_stride, pool_off;
+};
+
 template <int NFT, int S>
-__global__ __launch_bounds__(256) void cin_bwd_dx2_mfma_kernel(
-    CinDims c, const float* __restrict__ x0, const float* __restrict__ xk,
-    const float* __restrict__ wdx, const float* __restrict__ d_xnext,
-    const float* __restrict__ d_pooled, int pool_stride, int pool_off, float* d_xk, float* d_x0,
-    int SPB, int ntiles) {
-  extern __shared__ float lds[];
+__device__ __forceinline__ void dx2_body(const BwdIn& in, const Dx2Args& ax, int bid, float* lds) {
+  const CinDims& c = in.c;
+  const float* __restrict__ x0 = in.x0;
+  const float* __restrict__ xk = in.xk;
+  const float* __restrict__ wdx = ax.wdx;
+  const float* __restrict__ d_xnext = in.d_xnext;
+  const float* __restrict__ d_pooled = in.d_pooled;
+  const int pool_stride = in.pool_stride, pool_off = in.pool_off;
+  float* d_xk = ax.d_xk;
+  float* d_x0 = ax.d_x0;
+  const int SPB = ax.SPB, ntiles = ax.ntiles;
   constexpr int RT = 4;
   constexpr int ROWS = 64 * RT;
   constexpr int Tp = ROWS + kPad;
@@ -602,7 +622,7 @@ __global__ __launch_bounds__(256) void cin_bwd_dx2_mfma_kernel(
   float* xs = lds;                            // [Hp][Tp]  xk, then dXk (+ dX0 when shared)
   float* as = shared_x ? xs : xs + Hp * Tp;   // [Fp][Tp]  x0, then dX0
 
-  const int64_t b0 = (int64_t)blockIdx.x * SPB;
+  const int64_t b0 = (int64_t)bid * SPB;
   const int nb = (int)((c.B - b0 < SPB) ? (c.B - b0) : SPB);
   const int cols = nb * c.D;
   stage_cols(xk, b0, nb, c.H, Hp, c.D, xs, Tp);
@@ -768,12 +788,24 @@ __host__ __device__ inline int tile_index(int ft, int ht, int nft, int nht, int 
 // address plus an immediate offset feeds two k-steps; the next chunk is fetched into registers
 // (x0/xk from their tensors, dcurr straight from d_xnext / d_pooled) while this one multiplies
 // and goes to the other LDS buffer afterwards: one barrier per chunk.
+struct DwArgs {
+  int64_t rows_total;
+  int rows_per_split;
+  float* part;
+};
+
 template <int PT, int NT, int XU>
-__global__ __launch_bounds__(256) void cin_bwd_dw_mfma_kernel(
-    CinDims c, const float* __restrict__ x0, const float* __restrict__ xk,
-    const float* __restrict__ d_xnext, const float* __restrict__ d_pooled, int pool_stride,
-    int pool_off, int64_t rows_total, int rows_per_split, float* __restrict__ part) {
-  extern __shared__ float lds[];
+__device__ __forceinline__ void dw_body(const BwdIn& in, const DwArgs& aw, int bx, int by, int bz,
+                                        float* lds) {
+  const CinDims& c = in.c;
+  const float* __restrict__ x0 = in.x0;
+  const float* __restrict__ xk = in.xk;
+  const float* __restrict__ d_xnext = in.d_xnext;
+  const float* __restrict__ d_pooled = in.d_pooled;
+  const int pool_stride = in.pool_stride, pool_off = in.pool_off;
+  const int64_t rows_total = aw.rows_total;
+  const int rows_per_split = aw.rows_per_split;
+  float* __restrict__ part = aw.part;
   constexpr int RC = 64;    // rows per chunk
   constexpr int RCp = 80;   // row stride of the LDS images (floats)
   constexpr int NCH = NT * 16;
@@ -789,8 +821,8 @@ __global__ __launch_bounds__(256) void cin_bwd_dw_mfma_kernel(
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane & 15, kk = lane >> 4;
   const int fi = j >> 2, hi = j & 3;
-  const int c0 = blockIdx.z * NCH;
-  const int t0 = (blockIdx.y * 4 + wave) * PT;
+  const int c0 = bz * NCH;
+  const int t0 = (by * 4 + wave) * PT;
 
   // LDS addresses of this lane's operands in the current buffer; they move to the other buffer
   // and back with one add per chunk
@@ -812,7 +844,7 @@ __global__ __launch_bounds__(256) void cin_bwd_dw_mfma_kernel(
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) acc[p][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int64_t r_beg = (int64_t)blockIdx.x * rows_per_split;
+  const int64_t r_beg = (int64_t)bx * rows_per_split;
   int64_t r_end = r_beg + rows_per_split;
   if (r_end > rows_total) r_end = rows_total;
   const int HD = c.H * c.D, FD = c.F * c.D;
@@ -951,13 +983,25 @@ __global__ __launch_bounds__(256) void cin_bwd_dw_mfma_kernel(
         if (ch < c.L) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const int64_t slot = (int64_t)blockIdx.x * ntile * 16 + (int64_t)(t0 + p) * 16 + kk * 4 + r;
+            const int64_t slot = (int64_t)bx * ntile * 16 + (int64_t)(t0 + p) * 16 + kk * 4 + r;
             part[slot * c.L + ch] = acc[p][nt][r];
           }
         }
       }
     }
   }
+}
+
+template <int NFT, int S>
+__global__ __launch_bounds__(256) void cin_bwd_dx2_mfma_kernel(BwdIn in, Dx2Args ax) {
+  extern __shared__ float lds[];
+  dx2_body<NFT, S>(in, ax, blockIdx.x, lds);
+}
+
+template <int PT, int NT, int XU>
+__global__ __launch_bounds__(256) void cin_bwd_dw_mfma_kernel(BwdIn in, DwArgs aw) {
+  extern __shared__ float lds[];
+  dw_body<PT, NT, XU>(in, aw, blockIdx.x, blockIdx.y, blockIdx.z, lds);
 }
 
 // d_w[(f,h), n] = scale * sum over splits; masked pairs get 0.  A block sums 32 elements:
@@ -1130,35 +1174,62 @@ int bwd_mfma(const CinDims& c, const float* x0, const float* xk, const float* w,
   const int nht = Hp / 4, nft = Fp / 4;
   const int S = (c.L + 3) / 4;
   const bool shared_x = (xk == x0);
+  const BwdIn in{c, x0, xk, d_xnext, d_pooled, pool_stride, pool_off};
+
+  // ---- filter gradient geometry
+  const int64_t rows = c.B * c.D;
+  const int n_splits = dw_splits(rows);
+  const int rows_per_split = (int)((rows + n_splits - 1) / n_splits);
+  const int ntile = n_tiles(nft, nht, c.masked);
+  const int nt_total = (c.L + 15) / 16;
+  const int NT = nt_total >= 2 ? 2 : 1;
+  // pair tiles per wave: 7 when that wastes fewer wave slots than 8 (55 tiles: 56 vs 64)
+  const int maxp = Hp > Fp ? Hp : Fp;
+  const int slots8 = (ntile + 31) / 32 * 32, slots7 = (ntile + 27) / 28 * 28;
+  const int PT = (maxp <= 40 && slots7 < slots8) ? 7 : 8;
+  const size_t dw_lds = (size_t)2 * (Hp + (shared_x ? 0 : Fp) + NT * 16) * 80 * sizeof(float);
+  const dim3 dw_grid((unsigned)n_splits, (unsigned)((ntile + 4 * PT - 1) / (4 * PT)),
+                     (unsigned)((nt_total + NT - 1) / NT));
+  const DwArgs aw{rows, rows_per_split, part};
+
   // ---- input gradients
   const size_t dx2_lds = (size_t)(Hp + (shared_x ? 0 : Fp)) * (256 + kPad) * sizeof(float);
   if (nft <= 10 && S <= 5 && dx2_lds <= kLdsLimit) {
     const int SPB = 256 / c.D;
     const int ntiles = n_tiles(nft, nht, c.masked);
-    dim3 grid((unsigned)((c.B + SPB - 1) / SPB));
-#define CALL2(NF, SS)                                                                                  \
-  do {                                                                                                 \
-    const int64_t total = (int64_t)ntiles * 64 * ((SS + 3) & ~3);                                      \
-    XDFM_LAUNCH("cin_pack_dx_kernel", st, cin_pack_dx_kernel<SS>, dim3((unsigned)((total + 255) / 256)), \
-                dim3(256), 0, c, w, nft, nht, ntiles, wpk);                                            \
-    int rc = allow_lds(cin_bwd_dx2_mfma_kernel<NF, SS>, dx2_lds);                                      \
-    if (rc) return rc;                                                                                 \
-    XDFM_LAUNCH("cin_bwd_dx2_mfma_kernel<" #NF ", " #SS ">", st, (cin_bwd_dx2_mfma_kernel<NF, SS>),    \
-                grid, dim3(256), dx2_lds, c, x0, xk, wpk, d_xnext, d_pooled, pool_stride, pool_off,    \
-                d_xk, d_x0, SPB, ntiles);                                                              \
-  } while (0)
-    if (nft <= 3) {
-      if (S <= 3)
-        CALL2(3, 3);
+    const int n_dx = (int)((c.B + SPB - 1) / SPB);
+    const Dx2Args ax{wpk, d_xk, d_x0, SPB, ntiles};
+    const int SS = S <= 3 ? 3 : 5;
+    {
+      const int64_t total = (int64_t)ntiles * 64 * ((SS + 3) & ~3);
+      if (SS == 3)
+        XDFM_LAUNCH("cin_pack_dx_kernel<3>", st, cin_pack_dx_kernel<3>, dim3((unsigned)((total + 255) / 256)),
+                    dim3(256), 0, c, w, nft, nht, ntiles, wpk);
       else
-        CALL2(3, 5);
-    } else {
-      if (S <= 3)
-        CALL2(10, 3);
-      else
-        CALL2(10, 5);
+        XDFM_LAUNCH("cin_pack_dx_kernel<5>", st, cin_pack_dx_kernel<5>, dim3((unsigned)((total + 255) / 256)),
+                    dim3(256), 0, c, w, nft, nht, ntiles, wpk);
     }
+    {
+#define CALL2(NF, SS_)                                                                                 \
+  do {                                                                                                 \
+    int rc = allow_lds(cin_bwd_dx2_mfma_kernel<NF, SS_>, dx2_lds);                                     \
+    if (rc) return rc;                                                                                 \
+    XDFM_LAUNCH("cin_bwd_dx2_mfma_kernel<" #NF ", " #SS_ ">", st, (cin_bwd_dx2_mfma_kernel<NF, SS_>),  \
+                dim3((unsigned)n_dx), dim3(256), dx2_lds, in, ax);                                     \
+  } while (0)
+      if (nft <= 3) {
+        if (SS == 3)
+          CALL2(3, 3);
+        else
+          CALL2(3, 5);
+      } else {
+        if (SS == 3)
+          CALL2(10, 3);
+        else
+          CALL2(10, 5);
+      }
 #undef CALL2
+    }
   } else {
     {
       const int64_t total = c.B * c.D * c.L;
@@ -1211,26 +1282,12 @@ int bwd_mfma(const CinDims& c, const float* x0, const float* xk, const float* w,
   }
   // ---- filter gradient
   {
-    const int64_t rows = c.B * c.D;
-    const int n_splits = dw_splits(rows);
-    const int rows_per_split = (int)((rows + n_splits - 1) / n_splits);
-    const int ntile = n_tiles(nft, nht, c.masked);
-    const int nt_total = (c.L + 15) / 16;
-    const int NT = nt_total >= 2 ? 2 : 1;
-    // pair tiles per wave: 7 when that wastes fewer wave slots than 8 (55 tiles: 56 vs 64)
-    const int maxp = Hp > Fp ? Hp : Fp;
-    const int slots8 = (ntile + 31) / 32 * 32, slots7 = (ntile + 27) / 28 * 28;
-    const int PT = (maxp <= 40 && slots7 < slots8) ? 7 : 8;
-    const size_t lds_bytes = (size_t)2 * (Hp + (shared_x ? 0 : Fp) + NT * 16) * 80 * sizeof(float);
-    dim3 grid((unsigned)n_splits, (unsigned)((ntile + 4 * PT - 1) / (4 * PT)),
-              (unsigned)((nt_total + NT - 1) / NT));
 #define CALLW(PTV, NTV, XUV)                                                                          \
   do {                                                                                                \
-    int rc = allow_lds(cin_bwd_dw_mfma_kernel<PTV, NTV, XUV>, lds_bytes);                             \
+    int rc = allow_lds(cin_bwd_dw_mfma_kernel<PTV, NTV, XUV>, dw_lds);                                \
     if (rc) return rc;                                                                                \
     XDFM_LAUNCH("cin_bwd_dw_mfma_kernel<" #PTV ", " #NTV ">", st,                                     \
-                (cin_bwd_dw_mfma_kernel<PTV, NTV, XUV>), grid, dim3(256), lds_bytes, c, x0, xk,       \
-                d_xnext, d_pooled, pool_stride, pool_off, rows, rows_per_split, part);                \
+                (cin_bwd_dw_mfma_kernel<PTV, NTV, XUV>), dw_grid, dim3(256), dw_lds, in, aw);         \
   } while (0)
     if (NT == 2) {
       if (maxp > 40)
@@ -1248,6 +1305,8 @@ int bwd_mfma(const CinDims& c, const float* x0, const float* xk, const float* w,
         CALLW(8, 1, 10);
     }
 #undef CALLW
+  }
+  {
     const int64_t total = (int64_t)c.F * c.H * c.L;
     XDFM_LAUNCH("cin_dw_unpack_kernel", st, cin_dw_unpack_kernel, dim3((unsigned)((total + 31) / 32)),
                 dim3(256), 0, c, part, n_splits, d_w);
