@@ -41,6 +41,12 @@ __device__ __forceinline__ f32x4 mfma(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
+// x / d for 0 <= x < 2^21 and 1 <= d, with inv = 1.0f / d: three VALU ops instead of the ~20
+// of an integer division (the index arithmetic below shares the SIMD lanes with the MFMAs).
+// (x + 0.5) / d is at least 0.5 / d away from an integer and the float error is below
+// x / d * 2^-22, so the truncation is exact.
+__device__ __forceinline__ int fdiv(int x, float inv) { return (int)(((float)x + 0.5f) * inv); }
+
 // stage src[b0 .. b0+nb)[R][D] transposed into lds[r * Tp + bl*D + d]; rows R..Rpad are zero.
 // Four loads per thread are in flight before the first LDS write (the tile is read once, so
 // this loop runs at memory latency unless it keeps several requests outstanding).
@@ -48,8 +54,10 @@ __device__ __forceinline__ void stage_cols(const float* __restrict__ src, int64_
                                            int Rpad, int D, float* lds, int Tp) {
   const float* base = src + b0 * R * D;
   const int nt = blockDim.x;
+  const float invR = 1.0f / (float)R;
   if ((D & 3) == 0) {
     const int D4 = D >> 2;
+    const float invD4 = 1.0f / (float)D4;
     const int total4 = nb * R * D4;
     const float4* base4 = reinterpret_cast<const float4*>(base);
     for (int q0 = threadIdx.x; q0 < total4; q0 += 4 * nt) {
@@ -63,9 +71,9 @@ __device__ __forceinline__ void stage_cols(const float* __restrict__ src, int64_
       for (int u = 0; u < 4; ++u) {
         const int q = q0 + u * nt;
         if (q < total4) {
-          const int row = q / D4;
+          const int row = fdiv(q, invD4);
           const int d4 = q - row * D4;
-          const int bl = row / R;
+          const int bl = fdiv(row, invR);
           const int r = row - bl * R;
           *reinterpret_cast<float4*>(lds + r * Tp + bl * D + 4 * d4) = v[u];
         }
@@ -73,6 +81,7 @@ __device__ __forceinline__ void stage_cols(const float* __restrict__ src, int64_
     }
   } else {
     const int total = nb * R * D;
+    const float invD = 1.0f / (float)D;
     for (int q0 = threadIdx.x; q0 < total; q0 += 4 * nt) {
       float v[4];
 #pragma unroll
@@ -84,9 +93,9 @@ __device__ __forceinline__ void stage_cols(const float* __restrict__ src, int64_
       for (int u = 0; u < 4; ++u) {
         const int q = q0 + u * nt;
         if (q < total) {
-          const int row = q / D;
+          const int row = fdiv(q, invD);
           const int d = q - row * D;
-          const int bl = row / R;
+          const int bl = fdiv(row, invR);
           const int r = row - bl * R;
           lds[r * Tp + bl * D + d] = v[u];
         }
@@ -638,7 +647,7 @@ __device__ __forceinline__ void dx2_body(const BwdIn& in, const Dx2Args& ax, int
     const int m = m0 + rt;
     const bool valid = m < cols;
     const int mc = valid ? m : 0;
-    const int bl = mc / c.D, d = mc - bl * c.D;
+    const int bl = fdiv(mc, 1.0f / (float)c.D), d = mc - bl * c.D;
     const int64_t b = b0 + bl;
 #pragma unroll
     for (int s = 0; s < S; ++s) {
@@ -730,28 +739,37 @@ __device__ __forceinline__ void dx2_body(const BwdIn& in, const Dx2Args& ax, int
   }
   __syncthreads();
   const float scale = c.masked ? 2.f : 1.f;
-  {
-    const int total = nb * c.F * c.D;
-    float* base = d_x0 + b0 * c.F * c.D;
-    for (int idx = threadIdx.x; idx < total; idx += blockDim.x) {
-      const int bl = idx / (c.F * c.D);
-      const int rem = idx - bl * c.F * c.D;
-      const int f = rem / c.D;
-      const int d = rem - f * c.D;
-      base[idx] += as[f * Tp + bl * c.D + d] * scale;
+  // results go out along d: [sample][feature][d] <- LDS [feature][row]; 16 bytes per lane when
+  // 4 | D (the index arithmetic uses fdiv: this loop is a fifth of the kernel's VALU work otherwise)
+  auto flush = [&](float* dst, const float* img, int R, bool accumulate) {
+    if ((c.D & 3) == 0 && (reinterpret_cast<uintptr_t>(dst) & 15) == 0) {
+      const int D4 = c.D >> 2, RD4 = R * D4;
+      const float invRD4 = 1.0f / (float)RD4, invD4 = 1.0f / (float)D4;
+      f32x4* base4 = reinterpret_cast<f32x4*>(dst + b0 * R * c.D);
+      for (int idx = threadIdx.x; idx < nb * RD4; idx += blockDim.x) {
+        const int bl = fdiv(idx, invRD4);
+        const int rem = idx - bl * RD4;
+        const int f = fdiv(rem, invD4);
+        const int d4 = rem - f * D4;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(img + f * Tp + bl * c.D + 4 * d4) * scale;
+        base4[idx] = accumulate ? base4[idx] + v : v;
+      }
+    } else {
+      const int RD = R * c.D;
+      const float invRD = 1.0f / (float)RD, invD = 1.0f / (float)c.D;
+      float* base = dst + b0 * R * c.D;
+      for (int idx = threadIdx.x; idx < nb * RD; idx += blockDim.x) {
+        const int bl = fdiv(idx, invRD);
+        const int rem = idx - bl * RD;
+        const int f = fdiv(rem, invD);
+        const int d = rem - f * c.D;
+        const float v = img[f * Tp + bl * c.D + d] * scale;
+        base[idx] = accumulate ? base[idx] + v : v;
+      }
     }
-  }
-  if (!shared_x) {
-    const int total = nb * c.H * c.D;
-    float* base = d_xk + b0 * c.H * c.D;
-    for (int idx = threadIdx.x; idx < total; idx += blockDim.x) {
-      const int bl = idx / (c.H * c.D);
-      const int rem = idx - bl * c.H * c.D;
-      const int h = rem / c.D;
-      const int d = rem - h * c.D;
-      base[idx] = xs[h * Tp + bl * c.D + d] * scale;
-    }
-  }
+  };
+  flush(d_x0, as, c.F, true);
+  if (!shared_x) flush(d_xk, xs, c.H, false);
 }
 
 // ----------------------------------------------------------------- filter gradient
