@@ -251,6 +251,7 @@ int xdfm_cin_bwd(const float* x0, const float* xk, const float* w, int64_t B, in
  *   x[B,K], w[K,Nout], b[Nout], y[B,Nout]
  * Backward: dy is the gradient w.r.t. y (post-activation); y is the saved output.
  *   dx[B,K] written or accumulated (accumulate_dx != 0), dw[K,Nout], db[Nout] written.
+ *   dx may be NULL (weight gradient only); dw, db and part may all be NULL (input gradient only).
  *   part: float scratch of xdfm_dense_bwd_workspace_floats(...) elements.
  * ---------------------------------------------------------------------- */
 int xdfm_dense_fwd(const float* x, const float* w, const float* b, int64_t B, int32_t K,

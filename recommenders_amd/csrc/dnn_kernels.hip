@@ -413,21 +413,25 @@ extern "C" int xdfm_dense_bwd(const float* x, const float* w, const float* y, co
                               int64_t B, int32_t K, int32_t Nout, int32_t act, float* dx,
                               int32_t accumulate_dx, float* dw, float* db, float* part,
                               void* stream) {
-  XDFM_REQUIRE(x && w && y && dy && dw && db && part, "xdfm_dense_bwd: null argument");
+  XDFM_REQUIRE(x && w && y && dy, "xdfm_dense_bwd: null argument");
+  XDFM_REQUIRE((dw && db && part) || (!dw && !db && dx),
+               "xdfm_dense_bwd: dw, db and part come together; without them dx must be given");
   XDFM_REQUIRE(B >= 0 && K > 0 && Nout > 0, "xdfm_dense_bwd: bad sizes");
   XDFM_REQUIRE((int64_t)K * Nout < ((int64_t)1 << 31), "xdfm_dense_bwd: weight too large");
   XDFM_REQUIRE(act_ok(act), "xdfm_dense_bwd: unknown activation %d", act);
   hipStream_t st = (hipStream_t)stream;
   if (B == 0) {
-    XDFM_HIP(hipMemsetAsync(dw, 0, (size_t)K * Nout * sizeof(float), st));
-    XDFM_HIP(hipMemsetAsync(db, 0, (size_t)Nout * sizeof(float), st));
+    if (dw) {
+      XDFM_HIP(hipMemsetAsync(dw, 0, (size_t)K * Nout * sizeof(float), st));
+      XDFM_HIP(hipMemsetAsync(db, 0, (size_t)Nout * sizeof(float), st));
+    }
     return XDFM_OK;
   }
   const int n_splits = splits_for(B, K, Nout);
   const int rows_per_split = (int)((B + n_splits - 1) / n_splits);
   const int nt_total = (Nout + 15) / 16;
   const int ktiles = (K + 1 + 15) / 16;
-  {
+  if (dw) {
     constexpr int PT = 4;
     if (nt_total >= 2) {
       dim3 grid((unsigned)n_splits, (unsigned)((ktiles + 4 * PT - 1) / (4 * PT)), (unsigned)((nt_total + 1) / 2));

@@ -9,6 +9,7 @@ engine without a visible GPU raises.
 """
 
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -179,6 +180,10 @@ class XDeepFMEngine(object):
         # name -> [(start_event, end_event)]: filled when bench.py asks for in-situ kernel times
         self.kernel_events = None
         self._side_stream = None
+        self._dnn_stream = None
+        # with both towers on, the DNN tower (small, latency/HBM-bound launches) runs on a second
+        # stream beside the CIN (matrix-core bound): the two share nothing but emb_out and d_emb
+        self.overlap_dnn = bool(hp.use_CIN_part and hp.use_DNN_part) and os.environ.get("XDFM_OVERLAP_DNN", "1") != "0"
         self.mean_count = 0  # set by the sharded engine: global batch size of the step
         self.init_parameters(seed)
 
@@ -341,18 +346,21 @@ class XDeepFMEngine(object):
                 part_floats = max(part_floats, sz.value)
             _lib.check(self.lib.xdfm_dense_bwd_workspace_floats(B, final_len, 1, ctypes.byref(sz)))
             part_floats = max(part_floats, sz.value)
+        dnn_part_floats = 1
         if hp.use_DNN_part:
             last = F * D
             for k, size in enumerate(hp.layer_sizes):
                 buf("h_%d" % k, B, int(size))
                 buf("d_h_%d" % k, B, int(size))
                 _lib.check(self.lib.xdfm_dense_bwd_workspace_floats(B, last, int(size), ctypes.byref(sz)))
-                part_floats = max(part_floats, sz.value)
+                dnn_part_floats = max(dnn_part_floats, sz.value)
                 last = int(size)
             buf("dnn_out", B)
             _lib.check(self.lib.xdfm_dense_bwd_workspace_floats(B, last, 1, ctypes.byref(sz)))
-            part_floats = max(part_floats, sz.value)
+            dnn_part_floats = max(dnn_part_floats, sz.value)
         buf("part", max(part_floats, 1))
+        # the DNN tower runs on its own stream beside the CIN: its partial sums get their own space
+        buf("part_dnn", dnn_part_floats)
         buf("pieces", 2 * (nnz // 64 + 1) * (D + 1))
         buf("long_list", nnz + 2, dtype=torch.int32)
         _lib.check(self.lib.xdfm_embed_plan_workspace_bytes(nnz, self.N, ctypes.byref(sz)))
@@ -464,6 +472,14 @@ class XDeepFMEngine(object):
             )
         )
         self._done(ev)
+        dnn_done = None
+        if self.overlap_dnn:
+            # fork: the DNN tower starts on its stream as soon as emb_out is there
+            side = self._branch_stream()
+            with torch.cuda.stream(side):
+                self._dnn_forward(B)
+                dnn_done = torch.cuda.Event()
+                dnn_done.record(side)
         if hp.use_CIN_part:
             ev = self._mark("cin_fwd")
             shapes = cin_shapes(hp)
@@ -486,21 +502,10 @@ class XDeepFMEngine(object):
                                       _ptr(ws["cin_out"]), st)
             )
             self._done(ev)
-        if hp.use_DNN_part:
-            ev = self._mark("dnn_fwd")
-            x, K = ws["emb_out"], F * D
-            for k, size in enumerate(hp.layer_sizes):
-                _lib.check(
-                    lib.xdfm_dense_fwd(_ptr(x), _ptr(self.views["dnn_w_%d" % k]),
-                                       _ptr(self.views["dnn_b_%d" % k]), B, K, int(size),
-                                       _ACT[hp.activation[k]], _ptr(ws["h_%d" % k]), st)
-                )
-                x, K = ws["h_%d" % k], int(size)
-            _lib.check(
-                lib.xdfm_dense_fwd(_ptr(x), _ptr(self.views["dnn_w_out"]), _ptr(self.views["dnn_b_out"]),
-                                   B, K, 1, 0, _ptr(ws["dnn_out"]), st)
-            )
-            self._done(ev)
+        if dnn_done is not None:
+            torch.cuda.current_stream(self.device).wait_event(dnn_done)
+        elif hp.use_DNN_part:
+            self._dnn_forward(B)
         ev = self._mark("logit_loss")
         _lib.check(
             lib.xdfm_logit_loss(
@@ -516,6 +521,71 @@ class XDeepFMEngine(object):
         )
         self._done(ev)
         return ws["pred"][:B]
+
+    def _branch_stream(self):
+        """The DNN tower's stream, made to wait for everything enqueued so far on the current one."""
+        if self._dnn_stream is None:
+            self._dnn_stream = torch.cuda.Stream(device=self.device)
+        ready = torch.cuda.Event()
+        ready.record(torch.cuda.current_stream(self.device))
+        self._dnn_stream.wait_event(ready)
+        return self._dnn_stream
+
+    def _dnn_forward(self, B):
+        """DNN tower (xDeepFM.py:473-533) on the current stream."""
+        hp, lib, ws, st = self.hp, self.lib, self.ws, self._stream()
+        ev = self._mark("dnn_fwd")
+        x, K = ws["emb_out"], self.F * self.D
+        for k, size in enumerate(hp.layer_sizes):
+            _lib.check(
+                lib.xdfm_dense_fwd(_ptr(x), _ptr(self.views["dnn_w_%d" % k]),
+                                   _ptr(self.views["dnn_b_%d" % k]), B, K, int(size),
+                                   _ACT[hp.activation[k]], _ptr(ws["h_%d" % k]), st)
+            )
+            x, K = ws["h_%d" % k], int(size)
+        _lib.check(
+            lib.xdfm_dense_fwd(_ptr(x), _ptr(self.views["dnn_w_out"]), _ptr(self.views["dnn_b_out"]),
+                               B, K, 1, 0, _ptr(ws["dnn_out"]), st)
+        )
+        self._done(ev)
+
+    def _dnn_backward(self, B, first_layer_dx):
+        """Backward of the DNN tower on the current stream.  first_layer_dx: None = leave the
+        gradient w.r.t. emb_out to dnn_backward_input(); else (buffer, accumulate)."""
+        hp, lib, ws, st = self.hp, self.lib, self.ws, self._stream()
+        g, gv = ws["g_logit"], self.grad_views
+        ev = self._mark("dnn_bwd")
+        n_layers = len(hp.layer_sizes)
+        sizes = [self.F * self.D] + [int(s) for s in hp.layer_sizes]
+        acts = [ws["emb_out"]] + [ws["h_%d" % k] for k in range(n_layers)]
+        d_acts = [None] + [ws["d_h_%d" % k] for k in range(n_layers)]
+        _lib.check(
+            lib.xdfm_dense_bwd(_ptr(acts[-1]), _ptr(self.views["dnn_w_out"]), _ptr(ws["dnn_out"]),
+                               _ptr(g), B, sizes[-1], 1, 0, _ptr(d_acts[-1]), 0, _ptr(gv["dnn_w_out"]),
+                               _ptr(gv["dnn_b_out"]), _ptr(ws["part_dnn"]), st)
+        )
+        for k in range(n_layers - 1, -1, -1):
+            if k == 0:
+                dx, acc = first_layer_dx if first_layer_dx is not None else (None, 0)
+            else:
+                dx, acc = d_acts[k], 0
+            _lib.check(
+                lib.xdfm_dense_bwd(_ptr(acts[k]), _ptr(self.views["dnn_w_%d" % k]), _ptr(acts[k + 1]),
+                                   _ptr(d_acts[k + 1]), B, sizes[k], sizes[k + 1],
+                                   _ACT[hp.activation[k]], _ptr(dx), acc,
+                                   _ptr(gv["dnn_w_%d" % k]), _ptr(gv["dnn_b_%d" % k]),
+                                   _ptr(ws["part_dnn"]), st)
+            )
+        self._done(ev)
+
+    def _dnn_backward_input(self, B, d_emb):
+        """d_emb += (gradient of the first DNN layer w.r.t. emb_out); input gradient only."""
+        hp, lib, ws, st = self.hp, self.lib, self.ws, self._stream()
+        _lib.check(
+            lib.xdfm_dense_bwd(_ptr(ws["emb_out"]), _ptr(self.views["dnn_w_0"]), _ptr(ws["h_0"]),
+                               _ptr(ws["d_h_0"]), B, self.F * self.D, int(hp.layer_sizes[0]),
+                               _ACT[hp.activation[0]], _ptr(d_emb), 1, None, None, None, st)
+        )
 
     # ---------------------------------------------------------------- backward
     def backward(self, batch):
@@ -533,27 +603,17 @@ class XDeepFMEngine(object):
                 lib.xdfm_dense_bwd(_ptr(g), _ptr(self.views["lin_b"]), _ptr(g), _ptr(g), B, 1, 1, 0, None,
                                    0, _ptr(ws["dummy"]), _ptr(gv["lin_b"]), _ptr(ws["part"]), st)
             )
-        if hp.use_DNN_part:
-            ev = self._mark("dnn_bwd")
-            n_layers = len(hp.layer_sizes)
-            sizes = [F * D] + [int(s) for s in hp.layer_sizes]
-            acts = [ws["emb_out"]] + [ws["h_%d" % k] for k in range(n_layers)]
-            d_acts = [d_emb] + [ws["d_h_%d" % k] for k in range(n_layers)]
-            _lib.check(
-                lib.xdfm_dense_bwd(_ptr(acts[-1]), _ptr(self.views["dnn_w_out"]), _ptr(ws["dnn_out"]),
-                                   _ptr(g), B, sizes[-1], 1, 0, _ptr(d_acts[-1]), 0, _ptr(gv["dnn_w_out"]),
-                                   _ptr(gv["dnn_b_out"]), _ptr(ws["part"]), st)
-            )
-            for k in range(n_layers - 1, -1, -1):
-                _lib.check(
-                    lib.xdfm_dense_bwd(_ptr(acts[k]), _ptr(self.views["dnn_w_%d" % k]), _ptr(acts[k + 1]),
-                                       _ptr(d_acts[k + 1]), B, sizes[k], sizes[k + 1],
-                                       _ACT[hp.activation[k]], _ptr(d_acts[k]), 0,
-                                       _ptr(gv["dnn_w_%d" % k]), _ptr(gv["dnn_b_%d" % k]),
-                                       _ptr(ws["part"]), st)
-                )
+        dnn_done = None
+        if self.overlap_dnn:
+            # fork: everything of the DNN tower but its gradient w.r.t. emb_out runs beside the CIN
+            side = self._branch_stream()
+            with torch.cuda.stream(side):
+                self._dnn_backward(B, None)
+                dnn_done = torch.cuda.Event()
+                dnn_done.record(side)
+        elif hp.use_DNN_part:
+            self._dnn_backward(B, (d_emb, 0))
             wrote_d_emb = True
-            self._done(ev)
         if not wrote_d_emb:
             d_emb[:B].zero_()
         if hp.use_CIN_part:
@@ -582,6 +642,10 @@ class XDeepFMEngine(object):
                                      _ptr(gv["cin_f_%d" % k]), _ptr(ws["part"]), st)
                 )
             self._done(ev)
+        if dnn_done is not None:
+            # join: d_h_0 is ready; the last piece of the DNN backward adds into d_emb
+            torch.cuda.current_stream(self.device).wait_event(dnn_done)
+            self._dnn_backward_input(B, d_emb)
 
     def _opt_args(self, l2=0.0, l1=0.0, clip=0.0):
         hp = self.hp
