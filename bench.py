@@ -208,10 +208,12 @@ def main():
         # one GPU: the whole step (copy of the batch arrays into the graph's inputs aside) is one
         # HIP graph launch; N > 1 stays eager (split sizes of the all-to-all are host values)
         graphed = eng.capture_step(*resident[0])
+        # the resident batches in the graph's input layout: handing one over is a single copy
+        packed = [graphed.pack(*r) for r in resident]
 
     def step(i):
         if graphed is not None:
-            return graphed.run(*resident[i % n_batches])
+            return graphed.run_packed(packed[i % n_batches])
         return eager_step(i)
 
     def fence():

@@ -790,9 +790,23 @@ class XDeepFMEngine(object):
 
 
 class GraphedStep(object):
+    """A captured train step.  The graph reads its batch from one flat device buffer (labels,
+    indices, ids, weights at 256-byte aligned offsets), so handing it a batch is one copy:
+    run_packed(buf) for a batch already laid out by pack(), run(...) for four arrays."""
+
     def __init__(self, engine, labels, dnn_idx, ids, weights):
         self.engine = engine
-        self.inputs = [t.clone() for t in (labels, dnn_idx, ids, weights)]
+        srcs = (labels, dnn_idx, ids, weights)
+        self._layout = []
+        off = 0
+        for t in srcs:
+            nbytes = t.numel() * t.element_size()
+            self._layout.append((off, nbytes, t.dtype, tuple(t.shape)))
+            off += (nbytes + 255) // 256 * 256
+        self.flat = torch.empty((max(off, 256),), dtype=torch.uint8, device=engine.device)
+        self.inputs = [self.flat[o:o + n].view(dt).view(shape) for (o, n, dt, shape) in self._layout]
+        for dst, src in zip(self.inputs, srcs):
+            dst.copy_(src)
         if engine.kernel_events is not None:
             raise RuntimeError("kernel event hooks cannot be captured")
         # warm up on a side stream (allocations, lazy module loads), as torch asks before a capture
@@ -807,6 +821,22 @@ class GraphedStep(object):
         with torch.cuda.graph(self.graph):
             self.batch = engine.make_batch(*self.inputs)
             self.loss, self.data_loss = engine.train_step(self.batch)
+
+    def pack(self, labels, dnn_idx, ids, weights):
+        """The four arrays of a batch in the graph's input layout (a new device buffer)."""
+        buf = torch.empty_like(self.flat)
+        for (o, n, dt, shape), src in zip(self._layout, (labels, dnn_idx, ids, weights)):
+            if tuple(src.shape) != shape or src.dtype != dt:
+                raise ValueError("batch array %s/%s does not match the captured shape %s/%s"
+                                 % (tuple(src.shape), src.dtype, shape, dt))
+            buf[o:o + n].view(dt).view(shape).copy_(src)
+        return buf
+
+    def run_packed(self, buf):
+        self.flat.copy_(buf, non_blocking=True)
+        self.graph.replay()
+        self.engine.step += 1
+        return self.loss, self.data_loss
 
     def run(self, labels, dnn_idx, ids, weights):
         for dst, src in zip(self.inputs, (labels, dnn_idx, ids, weights)):

@@ -268,7 +268,8 @@ def test_graph_replay_equals_eager_steps():
 
     losses_e = [float(eager.train_step(eager.make_batch(*dev(b)))[0]) for b in batches]
     gs = graph.capture_step(*dev(batches[0]))          # runs batch 0 once while warming up
-    losses_g = [float(gs.run(*dev(b))[0]) for b in batches[1:]]
+    # one batch through the four-array entry, one through the packed single-copy entry
+    losses_g = [float(gs.run(*dev(batches[1]))[0]), float(gs.run_packed(gs.pack(*dev(batches[2])))[0])]
     torch.cuda.synchronize()
     graph.check_errors()
     assert losses_g == losses_e[1:]
