@@ -95,6 +95,12 @@ CONFIGS = {
     "dnn_acts": dict(layer_sizes=[9, 33, 5], activation=["sigmoid", "elu", "identity"],
                      dropout=[0.0, 0.0, 0.0], use_CIN_part=False),
     "wide_dim": dict(FIELD_COUNT=6, dim=64, cross_layer_sizes=[34, 40], layer_sizes=[70], activation=["relu"]),
+    # the bench's shapes (same kernel instantiations: 16-byte paths, 10 f tiles, 7 pair tiles per wave)
+    "criteo_shape": dict(FIELD_COUNT=39, dim=16, FEATURE_COUNT=5000, cross_layer_sizes=[20, 10],
+                         layer_sizes=[20, 20], activation=["relu", "relu"]),
+    # more than 40 fields: the input-gradient kernel's first form and the wide staging of the filter gradient
+    "many_fields": dict(FIELD_COUNT=45, dim=4, FEATURE_COUNT=2000, cross_layer_sizes=[8, 4],
+                        layer_sizes=[16], activation=["relu"], dropout=[0.0]),
 }
 
 
