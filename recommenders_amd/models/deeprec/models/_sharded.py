@@ -46,10 +46,14 @@ class RoutePlan(object):
 
 
 class RowShardExchange(object):
-    def __init__(self, group=None):
+    def __init__(self, group=None, virtual_world=1):
+        """virtual_world > 1 (single process only, for tests): partition the tokens as if there
+        were that many owners, with every "owner" being this process.  The exchanges are then
+        identities, but the engine sees the permuted token order of a real multi-rank step."""
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.virtual_world = int(virtual_world) if self.world == 1 else 1
 
     def route(self, ids):
         """ids: int64 [n] global feature ids of this rank's tokens.  Sends every id to its
@@ -58,6 +62,15 @@ class RowShardExchange(object):
         plan = RoutePlan()
         n = int(ids.numel())
         plan.n_send = n
+        if G == 1 and self.virtual_world > 1:
+            order = torch.argsort(ids % self.virtual_world, stable=True)
+            inverse = torch.empty_like(order)
+            inverse[order] = torch.arange(n, dtype=order.dtype, device=order.device)
+            plan.order, plan.inverse = order, inverse
+            plan.send_counts = plan.recv_counts = [n]
+            plan.recv_rows = ids[order].contiguous()
+            plan.n_recv = n
+            return plan
         if G == 1:
             plan.order = plan.inverse = None
             plan.send_counts = plan.recv_counts = [n]
@@ -102,8 +115,8 @@ class ShardedXDeepFMEngine(XDeepFMEngine):
     """XDeepFMEngine whose table shard is 1/world of the rows.  `train_step(batch)` takes this
     rank's part of the global batch; all ranks must call it with equally sized batches."""
 
-    def __init__(self, hp, device=None, seed=None, group=None):
-        self.exchange = RowShardExchange(group)
+    def __init__(self, hp, device=None, seed=None, group=None, virtual_world=1):
+        self.exchange = RowShardExchange(group, virtual_world=virtual_world)
         self.world, self.rank = self.exchange.world, self.exchange.rank
         if hp.loss == "square_loss":
             raise ValueError("square_loss (a root of a mean) cannot be split over ranks")

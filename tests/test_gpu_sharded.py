@@ -18,13 +18,16 @@ def _upload(eng, b):
     return eng.upload(b["labels"], b["dnn_feat_indices"], b["dnn_feat_values"], b["dnn_feat_weights"])
 
 
+@pytest.mark.parametrize("virtual_world", [1, 3])
 @pytest.mark.parametrize("optimizer", ["adam", "adagrad"])
-def test_sharded_step_equals_plain_engine_and_oracle(optimizer):
+def test_sharded_step_equals_plain_engine_and_oracle(optimizer, virtual_world):
+    """virtual_world = 3: tokens are partitioned as for 3 owners (all of them this process), so
+    the kernels see the permuted token order and the inverse map of a real multi-rank step."""
     hp = make_hp(optimizer=optimizer, learning_rate=0.01, FEATURE_COUNT=300, cross_l2=0.01, cross_l1=0.001)
     rng = np.random.default_rng(5)
     p32 = X.init_params(hp, seed=9)
     plain = XDeepFMEngine(hp, embedding_update="sparse_rows")
-    shard = ShardedXDeepFMEngine(hp)
+    shard = ShardedXDeepFMEngine(hp, virtual_world=virtual_world)
     assert shard.world == 1 and shard.N == 300
     plain.load_state({k: v.clone() for k, v in p32.items()})
     shard.load_global_state({k: v.clone() for k, v in p32.items()})
