@@ -160,6 +160,8 @@ def main():
     ap.add_argument("--features", type=int, default=1 << 25)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly in the timed region")
+    ap.add_argument("--sharded", action="store_true",
+                    help="one GPU, but through the row-sharded engine (the N > 1 code path without peers)")
     ap.add_argument("--profile-steps", type=int, default=20,
                     help="eager steps after the timed region with per-kernel HIP events")
     args = ap.parse_args()
@@ -182,7 +184,7 @@ def main():
     n_batches = 8
     host_batches = synth_batches(hp, n_batches, seed=1234 + rank)
 
-    if world == 1:
+    if world == 1 and not args.sharded:
         from recommenders_amd.models.deeprec.models._engine import XDeepFMEngine
 
         eng = XDeepFMEngine(hp, device=dev, seed=7, embedding_update="sparse_rows")
@@ -204,7 +206,7 @@ def main():
         return eng.train_step(batch)  # N > 1: includes the all-to-all exchanges and the all-reduce
 
     graphed = None
-    if world == 1 and not args.no_graph:
+    if world == 1 and not args.no_graph and not args.sharded:
         # one GPU: the whole step (copy of the batch arrays into the graph's inputs aside) is one
         # HIP graph launch; N > 1 stays eager (split sizes of the all-to-all are host values)
         graphed = eng.capture_step(*resident[0])

@@ -142,6 +142,14 @@ int xdfm_embed_fwd(const float* table, const float* lin_w, int64_t N, int32_t D,
                    int64_t nnz, float* emb_out, float* lin_out, float* fm_out, float* fm_sum,
                    int32_t* err_flag, void* stream);
 
+/* Plain row gather: out[i,:] = table[rows[i],:], lin_out[i] = lin_w[rows[i]] (NULL ok).
+ * No counterpart in the reference (one device, one table): it is the owner-side lookup of the
+ * row-sharded table ("owners run K1 locally"), the same copy xdfm_embed_fwd
+ * does with one token of weight 1 per row, without spending a wave per row. */
+int xdfm_embed_gather(const float* table, const float* lin_w, int64_t N, int32_t D,
+                      const int64_t* rows, int64_t n, float* out, float* lin_out,
+                      int32_t* err_flag, void* stream);
+
 /* ------------------------------------------------------------------------
  * Embedding backward: deterministic sorted-key segment sum (+ row update).
  * Replaces TF's gradient of embedding_lookup_sparse / sparse_dense_matmul and

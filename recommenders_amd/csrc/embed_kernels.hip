@@ -592,6 +592,54 @@ extern "C" int xdfm_embed_fwd(const float* table, const float* lin_w, int64_t N,
   return XDFM_OK;
 }
 
+// plain row gather (owner side of the row-sharded table): D/VEC lanes per row
+template <int VEC>
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ table,
+                                                          const float* __restrict__ lin_w, int64_t N,
+                                                          int D, const int64_t* __restrict__ rows,
+                                                          int64_t n, float* __restrict__ out,
+                                                          float* __restrict__ lin_out, int32_t* err_flag) {
+  const int LPR = D / VEC;
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t r = t / LPR;
+  const int c = (int)(t - r * LPR);
+  if (r >= n) return;
+  int64_t id = rows[r];
+  if ((uint64_t)id >= (uint64_t)N) {
+    atomicOr(err_flag, XDFM_DEVERR_ID_RANGE);
+    id = 0;
+  }
+  float e[VEC];
+  load_vec<VEC>(table + id * D + c * VEC, e);
+  store_vec<VEC>(out + r * D + c * VEC, e);
+  if (lin_out && c == 0) lin_out[r] = lin_w[id];
+}
+
+extern "C" int xdfm_embed_gather(const float* table, const float* lin_w, int64_t N, int32_t D,
+                                 const int64_t* rows, int64_t n, float* out, float* lin_out,
+                                 int32_t* err_flag, void* stream) {
+  XDFM_REQUIRE(table && out && err_flag, "xdfm_embed_gather: null argument");
+  XDFM_REQUIRE(N > 0 && D > 0 && n >= 0, "xdfm_embed_gather: bad sizes");
+  XDFM_REQUIRE(!lin_out || lin_w, "xdfm_embed_gather: lin_out needs lin_w");
+  if (n == 0) return XDFM_OK;
+  XDFM_REQUIRE(rows, "xdfm_embed_gather: null rows");
+  const int vec = pick_vec(D);
+  const int64_t threads = n * (D / vec);
+  const unsigned blocks = (unsigned)((threads + 255) / 256);
+#define LAUNCH(V)                                                                                          \
+  XDFM_LAUNCH("gather_rows_kernel<" #V ">", stream, gather_rows_kernel<V>, dim3(blocks), dim3(256), 0, table, \
+              lin_out ? lin_w : nullptr, N, D, rows, n, out, lin_out, err_flag)
+  if (vec == 4)
+    LAUNCH(4);
+  else if (vec == 2)
+    LAUNCH(2);
+  else
+    LAUNCH(1);
+#undef LAUNCH
+  XDFM_LAUNCH_CHECK();
+  return XDFM_OK;
+}
+
 extern "C" int xdfm_embed_plan_workspace_bytes(int64_t nnz, int64_t N, size_t* bytes) {
   XDFM_REQUIRE(bytes && nnz >= 0 && N > 0, "xdfm_embed_plan_workspace_bytes: bad argument");
   size_t tmp = 0;

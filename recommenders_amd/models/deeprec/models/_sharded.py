@@ -165,10 +165,9 @@ class ShardedXDeepFMEngine(XDeepFMEngine):
         if n_recv:
             ev = self._mark("owner_gather")
             _lib.check(
-                lib.xdfm_embed_fwd(
-                    _ptr(self.table), _ptr(self.lin_w) if use_lin else None, self.N, D, 1, n_recv,
-                    _ptr(self._arange32(n_recv)), _ptr(plan.recv_rows), _ptr(self._ones(n_recv)), n_recv,
-                    _ptr(rows_out), _ptr(lin_out) if use_lin else None, None, None, _ptr(self.err_flag), st,
+                lib.xdfm_embed_gather(
+                    _ptr(self.table), _ptr(self.lin_w) if use_lin else None, self.N, D, _ptr(plan.recv_rows),
+                    n_recv, _ptr(rows_out), _ptr(lin_out) if use_lin else None, _ptr(self.err_flag), st,
                 )
             )
             self._done(ev)
