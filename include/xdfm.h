@@ -254,6 +254,28 @@ int xdfm_cin_bwd(const float* x0, const float* xk, const float* w, int64_t B, in
                  void* stream);
 
 /* ------------------------------------------------------------------------
+ * Fast (low-rank) CIN, one layer.   xDeepFM.py:295-451 (`_build_fast_CIN`, fast_CIN_d > 0)
+ *   x0[B,F,D], xk[B,H,D]; w[F, d*L], v[H, d*L] (the [1,F,d*L] / [1,H,d*L] conv1d filters);
+ *   c = l*d + dd.
+ *   first != 0 (layer 0, xk and v unused): curr[b,l,dim] = sum_dd 0.5*(sum_f x0*w - sum_f x0^2*w^2)
+ *   else:                                  curr[b,l,dim] = sum_dd (sum_f x0*w) * (sum_h xk*v)
+ *   split of curr into xnext (l < n_hidden) and pooled (sum over dim) as in xdfm_cin_fwd.
+ * Backward: d_x0 accumulated (+=), d_xk written (layer k), d_w[F,d*L], d_v[H,d*L] written.
+ *   workspace: float scratch of xdfm_fast_cin_bwd_workspace_floats(...) elements.
+ * ---------------------------------------------------------------------- */
+int xdfm_fast_cin_fwd(const float* x0, const float* xk, const float* w, const float* v, int64_t B,
+                      int32_t F, int32_t H, int32_t D, int32_t L, int32_t d, int32_t n_hidden,
+                      int32_t first, float* xnext, float* pooled, int32_t pool_stride,
+                      int32_t pool_off, void* stream);
+int xdfm_fast_cin_bwd_workspace_floats(int64_t B, int32_t F, int32_t H, int32_t D, int32_t L,
+                                       int32_t d, size_t* floats);
+int xdfm_fast_cin_bwd(const float* x0, const float* xk, const float* w, const float* v, int64_t B,
+                      int32_t F, int32_t H, int32_t D, int32_t L, int32_t d, int32_t n_hidden,
+                      int32_t first, const float* d_xnext, const float* d_pooled,
+                      int32_t pool_stride, int32_t pool_off, float* d_xk, float* d_x0, float* d_w,
+                      float* d_v, float* workspace, void* stream);
+
+/* ------------------------------------------------------------------------
  * Dense layer  y = act(x*W + b)     xDeepFM.py:491-507 (xw_plus_b + activation),
  * also the two output heads (xDeepFM.py:290-292, :531-533) with act = identity.
  *   x[B,K], w[K,Nout], b[Nout], y[B,Nout]

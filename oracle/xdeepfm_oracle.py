@@ -45,7 +45,13 @@ def param_shapes(hp):
         shapes["lin_b"] = (1,)  # :117-122
     if hp.use_CIN_part:
         for k, (H, L, _) in enumerate(cin_shapes(hp)):
-            shapes["cin_f_%d" % k] = (H * hp.FIELD_COUNT, L)  # :202-206 ([1, H*F, L] squeezed)
+            if hp.fast_CIN_d > 0:
+                # _build_fast_CIN: fast_w [1, F, d*L] (:330-334, :353-357), fast_v [1, H, d*L] (:358-362)
+                shapes["fcin_w_%d" % k] = (hp.FIELD_COUNT, hp.fast_CIN_d * L)
+                if k > 0:
+                    shapes["fcin_v_%d" % k] = (H, hp.fast_CIN_d * L)
+            else:
+                shapes["cin_f_%d" % k] = (H * hp.FIELD_COUNT, L)  # :202-206 ([1, H*F, L] squeezed)
         shapes["cin_w_out"] = (cin_final_len(hp), 1)  # :279-281
         shapes["cin_b_out"] = (1,)  # :282-287
     if hp.use_DNN_part:
@@ -64,7 +70,7 @@ def param_groups(hp):
     appends at xDeepFM.py:43, :129-130, :267, :288-289, :511-512, :529-530)."""
     names = list(param_shapes(hp))
     embed = ["embedding"]
-    cross = [n for n in names if n.startswith("cin_f_")]
+    cross = [n for n in names if n.startswith(("cin_f_", "fcin_"))]  # also :336, :364-365
     layer = [n for n in names if n not in embed and n not in cross]
     return embed, layer, cross
 
@@ -223,23 +229,34 @@ def forward(params, batch, hp, embedding_rows=None):
         logit = logit + fm
 
     if hp.use_CIN_part:  # :161-293 with res=True, direct=False, bias=False, is_masked=True
-        if hp.fast_CIN_d > 0:
-            raise NotImplementedError("fast CIN (xDeepFM.py:295-451) is not restated yet")
         x0 = embed_out.reshape(B, F, D)
         hidden = x0
         finals = []
         n_layers = len(hp.cross_layer_sizes)
+        fast_d = int(hp.fast_CIN_d)
+        x0t = x0.permute(0, 2, 1)  # [B,D,F]  (fast CIN works on this view, xDeepFM.py:321)
         for k, (H, L, n_hidden) in enumerate(cin_shapes(hp)):
-            # dot_result_m [D,B,F,H] -> [D,B,F*H] -> [B,D,F*H]   (:192-200)
-            z = torch.einsum("bfd,bhd->dbfh", x0, hidden).reshape(D, B, F * H).permute(1, 0, 2)
-            if k == 0:  # is_masked (:208-217): strictly upper, times 2
-                mask = torch.triu(torch.ones(F, F, dtype=dt), diagonal=1).reshape(1, 1, F * F)
-                z = z * mask * 2
-            curr = torch.matmul(z, params["cin_f_%d" % k])  # conv1d width 1 (:220-222) [B,D,L]
+            if fast_d > 0:  # _build_fast_CIN (xDeepFM.py:295-451), res=True, direct=False, bias=False
+                w = params["fcin_w_%d" % k]
+                if k == 0:
+                    dot1 = torch.matmul(x0t, w)  # :337-339 -- not squared in the reference
+                    dot2 = torch.matmul(x0t**2, w**2)  # :340-345
+                    dot = 0.5 * (dot1 - dot2)  # :346-349
+                else:
+                    v = params["fcin_v_%d" % k]
+                    dot = torch.matmul(x0t, w) * torch.matmul(hidden.permute(0, 2, 1), v)  # :367-381
+                curr = dot.reshape(B, D, L, fast_d).sum(3)  # :346-351 / :378-383  [B,D,L]
+            else:
+                # dot_result_m [D,B,F,H] -> [D,B,F*H] -> [B,D,F*H]   (:192-200)
+                z = torch.einsum("bfd,bhd->dbfh", x0, hidden).reshape(D, B, F * H).permute(1, 0, 2)
+                if k == 0:  # is_masked (:208-217): strictly upper, times 2
+                    mask = torch.triu(torch.ones(F, F, dtype=dt), diagonal=1).reshape(1, 1, F * F)
+                    z = z * mask * 2
+                curr = torch.matmul(z, params["cin_f_%d" % k])  # conv1d width 1 (:220-222) [B,D,L]
             if hp.enable_BN is True:
-                raise NotImplementedError("batch norm (xDeepFM.py:234-240) is not restated yet")
-            curr = _activate(curr, hp.cross_activation)  # :242
-            curr = curr.permute(0, 2, 1)  # [B,L,D]  (:244)
+                raise NotImplementedError("batch norm (xDeepFM.py:234-240, :394-400) is not restated yet")
+            curr = _activate(curr, hp.cross_activation)  # :242 / :402
+            curr = curr.permute(0, 2, 1)  # [B,L,D]  (:244; the fast branch splits axis 2 of [B,D,L], :412-414)
             if k != n_layers - 1:
                 nxt, direct = torch.split(curr, 2 * [int(L / 2)], 1)  # :254-256
             else:
@@ -425,7 +442,7 @@ def _regular_loss_subset(params, hp):
     """regular_loss over the dense parameters only (sparse_rows mode)."""
     total = 0
     for n, p in params.items():
-        if n.startswith("cin_f_"):
+        if n.startswith(("cin_f_", "fcin_")):
             total = total + hp.cross_l1 * p.abs().sum() + hp.cross_l2 * torch.sqrt((p**2).sum())
         else:
             total = total + hp.layer_l2 * (p**2).sum() / 2 + hp.layer_l1 * p.abs().sum()

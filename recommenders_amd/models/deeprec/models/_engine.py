@@ -50,7 +50,12 @@ def dense_param_shapes(hp):
         shapes["lin_b"] = (1,)
     if hp.use_CIN_part:
         for k, (H, L, _) in enumerate(cin_shapes(hp)):
-            shapes["cin_f_%d" % k] = (H * hp.FIELD_COUNT, L)
+            if hp.fast_CIN_d > 0:  # _build_fast_CIN filters (xDeepFM.py:330-334, :353-362)
+                shapes["fcin_w_%d" % k] = (hp.FIELD_COUNT, int(hp.fast_CIN_d) * L)
+                if k > 0:
+                    shapes["fcin_v_%d" % k] = (H, int(hp.fast_CIN_d) * L)
+            else:
+                shapes["cin_f_%d" % k] = (H * hp.FIELD_COUNT, L)
         shapes["cin_w_out"] = (sum(L - nh for (_, L, nh) in cin_shapes(hp)), 1)
         shapes["cin_b_out"] = (1,)
     if hp.use_DNN_part:
@@ -87,8 +92,7 @@ class XDeepFMEngine(object):
         # table_rows: rows held by this process (the sharded engine keeps FEATURE_COUNT / world)
         self.N = int(hp.FEATURE_COUNT) if table_rows is None else int(table_rows)
         self.F, self.D = int(hp.FIELD_COUNT), int(hp.dim)
-        if hp.fast_CIN_d > 0:
-            raise NotImplementedError("fast_CIN_d > 0 (xDeepFM.py:295-451) is not built yet")
+        self.fast_d = int(hp.fast_CIN_d) if hp.fast_CIN_d > 0 else 0
         if hp.enable_BN is True:
             raise NotImplementedError("enable_BN (xDeepFM.py:234-240, :497-503) is not built yet")
         if hp.user_dropout:
@@ -278,7 +282,7 @@ class XDeepFMEngine(object):
         l1 = np.zeros(max(n, 1), dtype=np.float32)
         nl2 = np.zeros(max(n, 1), dtype=np.float32)
         for i, name in enumerate(self.dense_shapes):
-            if name.startswith("cin_f_"):  # cross_params (base_model.py:158-166)
+            if name.startswith(("cin_f_", "fcin_")):  # cross_params (base_model.py:158-166)
                 l1[i] = hp.cross_l1
                 nl2[i] = hp.cross_l2
             else:  # layer_params (base_model.py:128-132, :143-148); biases included
@@ -340,6 +344,11 @@ class XDeepFMEngine(object):
                 if nh > 0:
                     buf("hid_%d" % k, B, nh * D)
                     buf("d_hid_%d" % k, B, nh * D)
+                if self.fast_d:
+                    _lib.check(self.lib.xdfm_fast_cin_bwd_workspace_floats(B, F, H, D, L, self.fast_d,
+                                                                           ctypes.byref(sz)))
+                    part_floats = max(part_floats, sz.value)
+                    continue
                 _lib.check(self.lib.xdfm_cin_bwd_workspace_floats(B, F, H, D, L, ctypes.byref(sz)))
                 part_floats = max(part_floats, sz.value)
                 _lib.check(self.lib.xdfm_cin_fwd_workspace_floats(B, F, H, D, L, ctypes.byref(sz)))
@@ -489,11 +498,19 @@ class XDeepFMEngine(object):
             xk = x0
             for k, (H, L, nh) in enumerate(shapes):
                 xnext = ws["hid_%d" % k] if nh > 0 else None
-                _lib.check(
-                    lib.xdfm_cin_fwd(_ptr(x0), _ptr(xk), _ptr(self.views["cin_f_%d" % k]), B, F, H, D,
-                                     L, nh, 1 if k == 0 else 0, _ptr(xnext), _ptr(ws["pooled"]),
-                                     final_len, off, _ptr(ws["part"]), st)
-                )
+                if self.fast_d:
+                    _lib.check(
+                        lib.xdfm_fast_cin_fwd(_ptr(x0), _ptr(xk), _ptr(self.views["fcin_w_%d" % k]),
+                                              _ptr(self.views["fcin_v_%d" % k]) if k > 0 else None, B, F, H,
+                                              D, L, self.fast_d, nh, 1 if k == 0 else 0, _ptr(xnext),
+                                              _ptr(ws["pooled"]), final_len, off, st)
+                    )
+                else:
+                    _lib.check(
+                        lib.xdfm_cin_fwd(_ptr(x0), _ptr(xk), _ptr(self.views["cin_f_%d" % k]), B, F, H, D,
+                                         L, nh, 1 if k == 0 else 0, _ptr(xnext), _ptr(ws["pooled"]),
+                                         final_len, off, _ptr(ws["part"]), st)
+                    )
                 off += L - nh
                 xk = xnext
             _lib.check(
@@ -635,6 +652,17 @@ class XDeepFMEngine(object):
                 xk = x0 if k == 0 else ws["hid_%d" % (k - 1)]
                 d_xnext = ws["d_hid_%d" % k] if nh > 0 else None
                 d_xk = None if k == 0 else ws["d_hid_%d" % (k - 1)]
+                if self.fast_d:
+                    _lib.check(
+                        lib.xdfm_fast_cin_bwd(_ptr(x0), _ptr(xk), _ptr(self.views["fcin_w_%d" % k]),
+                                              _ptr(self.views["fcin_v_%d" % k]) if k > 0 else None, B, F, H,
+                                              D, L, self.fast_d, nh, 1 if k == 0 else 0, _ptr(d_xnext),
+                                              _ptr(ws["d_pooled"]), final_len, offs[k], _ptr(d_xk),
+                                              _ptr(d_emb), _ptr(gv["fcin_w_%d" % k]),
+                                              _ptr(gv["fcin_v_%d" % k]) if k > 0 else None,
+                                              _ptr(ws["part"]), st)
+                    )
+                    continue
                 _lib.check(
                     lib.xdfm_cin_bwd(_ptr(x0), _ptr(xk), _ptr(self.views["cin_f_%d" % k]), B, F, H, D, L,
                                      nh, 1 if k == 0 else 0, _ptr(d_xnext), _ptr(ws["d_pooled"]),

@@ -53,7 +53,7 @@ class XDeepFMModel(BaseModel):
         if hparams.use_CIN_part:
             print("Add CIN part.")
             for name in eng.dense_shapes:
-                if name.startswith("cin_f_"):
+                if name.startswith(("cin_f_", "fcin_")):
                     self.cross_params.append(eng.views[name])
             self.layer_params.append(eng.views["cin_w_out"])
             self.layer_params.append(eng.views["cin_b_out"])

@@ -98,6 +98,13 @@ CONFIGS = {
     # the bench's shapes (same kernel instantiations: 16-byte paths, 10 f tiles, 7 pair tiles per wave)
     "criteo_shape": dict(FIELD_COUNT=39, dim=16, FEATURE_COUNT=5000, cross_layer_sizes=[20, 10],
                          layer_sizes=[20, 20], activation=["relu", "relu"]),
+    # _build_fast_CIN (fast_CIN_d > 0): oracle restated from xDeepFM.py:295-451, parity unpinned
+    # (no fixture of the reference covers this branch and TensorFlow is absent)
+    "fast_cin": dict(FIELD_COUNT=9, dim=6, fast_CIN_d=3, cross_layer_sizes=[10, 6, 5], layer_sizes=[8],
+                     activation=["relu"], dropout=[0.0]),
+    "fast_cin_criteo_shape": dict(FIELD_COUNT=39, dim=16, FEATURE_COUNT=5000, fast_CIN_d=4,
+                                  cross_layer_sizes=[20, 10], layer_sizes=[20], activation=["relu"],
+                                  dropout=[0.0]),
     # more than 40 fields: the input-gradient kernel's first form and the wide staging of the filter gradient
     "many_fields": dict(FIELD_COUNT=45, dim=4, FEATURE_COUNT=2000, cross_layer_sizes=[8, 4],
                         layer_sizes=[16], activation=["relu"], dropout=[0.0]),
@@ -155,12 +162,16 @@ def test_forward_and_gradients_match_oracle(name, loss):
     close(l32.numpy()[:, 0], logit.detach().numpy()[:, 0], rtol=5 * RTOL, what="oracle fp32 vs fp64")
 
 
+@pytest.mark.parametrize("fast_d", [0, 2])
 @pytest.mark.parametrize("optimizer", ["adam", "adagrad", "sgd"])
 @pytest.mark.parametrize("mode", ["dense_exact", "sparse_rows"])
-def test_training_steps_match_oracle(optimizer, mode):
+def test_training_steps_match_oracle(optimizer, mode, fast_d):
+    if fast_d and (optimizer != "adam"):
+        pytest.skip("the fast-CIN filters go through the same update path; one optimizer is enough")
     reg = dict(embed_l2=0.01, layer_l2=0.01, cross_l2=0.01, embed_l1=0.001, layer_l1=0.001, cross_l1=0.001)
     if mode == "sparse_rows":
         reg = dict(cross_l2=0.01, cross_l1=0.001)
+    reg["fast_CIN_d"] = fast_d
     hp = make_hp(optimizer=optimizer, learning_rate=0.01, FEATURE_COUNT=300, **reg)
     if mode == "sparse_rows":
         hp = make_hp(optimizer=optimizer, learning_rate=0.01, FEATURE_COUNT=300, use_Linear_part=True, **reg)
