@@ -228,7 +228,9 @@ def main():
         step(i)
     fence()
     eng.check_errors()
-    in_situ = graphed is None  # HIP events cannot be recorded inside a graph replay
+    # HIP events cannot be recorded inside a graph replay (the sharded engine replays its local
+    # part as a graph too)
+    in_situ = graphed is None and not getattr(eng, "graph_local", False)
     if in_situ:
         _lib.check(_lib.lib.xdfm_prof_enable(1))
     fence()
@@ -244,6 +246,8 @@ def main():
         final = float(loss)
         prof_steps = args.profile_steps
         _lib.check(_lib.lib.xdfm_prof_enable(1))
+        if hasattr(eng, "graph_local"):
+            eng.graph_local = False
         for i in range(prof_steps):
             eager_step(args.warmup + args.steps + i)
         fence()
@@ -310,7 +314,8 @@ def main():
                        "parallelism": "single GPU" if world == 1 else "table row-sharded x%d (all-to-all) + dense all-reduce" % world},
             "roofline": roofline,
             "kernel_time_ms_per_step": round(total_ms / prof_steps, 4),
-            "launch": "hip graph replay" if graphed is not None else "eager",
+            "launch": ("hip graph replay" if graphed is not None else
+                       "exchanges eager, local forward/backward as a hip graph" if not in_situ else "eager"),
             "kernel_timing": "HIP events around every launch, %s" % (
                 "in the timed region" if in_situ else "%d eager steps right after the timed graph replays" % prof_steps),
             "kernels": kernels,

@@ -102,11 +102,16 @@ class RowShardExchange(object):
         dist.all_to_all_single(out, x.contiguous(), plan.recv_counts, plan.send_counts, group=self.group)
         return out
 
-    def to_source(self, plan, y):
-        """y: [n_recv, ...] in the order of plan.recv_rows -> [n_send, ...] in partition order."""
+    def to_source(self, plan, y, out=None):
+        """y: [n_recv, ...] in the order of plan.recv_rows -> [n_send, ...] in partition order
+        (into `out` when given)."""
         if self.world == 1:
-            return y
-        out = y.new_empty((plan.n_send,) + tuple(y.shape[1:]))
+            if out is None:
+                return y
+            out.copy_(y)
+            return out
+        if out is None:
+            out = y.new_empty((plan.n_send,) + tuple(y.shape[1:]))
         dist.all_to_all_single(out, y.contiguous(), plan.send_counts, plan.recv_counts, group=self.group)
         return out
 
@@ -128,6 +133,10 @@ class ShardedXDeepFMEngine(XDeepFMEngine):
             dist.broadcast(self.dense, src=0, group=group)  # replicated parameters start identical
         self._consts = {}
         self._owner_ws = {}
+        # forward + backward + per-token gradients have fixed shapes once the rows are fetched:
+        # they replay as one HIP graph between the (variable-size) exchanges
+        self.graph_local = True
+        self._local_graphs = {}
 
     # ------------------------------------------------------------------ helpers
     def _arange32(self, n):
@@ -152,9 +161,10 @@ class ShardedXDeepFMEngine(XDeepFMEngine):
         return t
 
     # -------------------------------------------------------------------- step
-    def fetch_rows(self, batch):
+    def fetch_rows(self, batch, static=None):
         """Route the batch's ids, gather at the owners, bring the rows back.  Afterwards the
-        batch reads its embeddings from the fetched rows (token j -> fetched row inverse[j])."""
+        batch reads its embeddings from the fetched rows (token j -> fetched row inverse[j]).
+        static: a _LocalGraph whose buffers receive the rows instead of fresh tensors."""
         hp, lib, st = self.hp, self.lib, self._stream()
         D = self.D
         use_lin = bool(hp.use_Linear_part)
@@ -174,6 +184,12 @@ class ShardedXDeepFMEngine(XDeepFMEngine):
         batch.route = plan
         # owner-side sort of the received row ids: runs beside the forward pass
         self._owner_plan_async(batch)
+        if static is not None:
+            self.exchange.to_source(plan, rows_out, out=static.src_table)
+            if use_lin:
+                self.exchange.to_source(plan, lin_out, out=static.src_lin)
+            static.src_ids.copy_(self._arange64(batch.nnz)[:batch.nnz] if plan.inverse is None else plan.inverse)
+            return
         batch.src_table = self.exchange.to_source(plan, rows_out)
         batch.src_lin = self.exchange.to_source(plan, lin_out) if use_lin else None
         if plan.inverse is None:
@@ -216,33 +232,38 @@ class ShardedXDeepFMEngine(XDeepFMEngine):
             batch.owner_event = torch.cuda.Event()
             batch.owner_event.record(self._side_stream)
 
-    def _update_embedding(self, batch):
+    def _token_grads(self, batch, order32, send_g, send_gl):
+        """Per-token gradient rows in partition order (segment i = token order[i]) into send_g /
+        send_gl; `batch` carries src_table, tok_row, weights."""
         hp, lib, ws, st = self.hp, self.lib, self.ws, self._stream()
         D, nnz = self.D, batch.nnz
         use_lin, use_fm = bool(hp.use_Linear_part), bool(hp.use_FM_part)
-        plan = batch.route
-        # 1. per-token gradient rows, written in partition order (segment i = token order[i])
-        send_g = torch.empty((max(nnz, 1), D), dtype=torch.float32, device=self.device)
-        send_gl = torch.empty((max(nnz, 1),), dtype=torch.float32, device=self.device) if use_lin else None
-        order32 = (self._arange32(nnz) if plan.order is None else plan.order.to(torch.int32))
+        if not nnz:
+            return
         opt = self._opt_args()
-        if nnz:
-            ev = self._mark("token_grads")
-            _lib.check(
-                lib.xdfm_embed_bwd(
-                    1, _ptr(batch.src_table), None, None, None, None, None, _ptr(send_g),
-                    _ptr(send_gl) if use_lin else None, max(nnz, 1), D, self.F, batch.B,
-                    _ptr(self._arange32(nnz)), _ptr(order32), _ptr(batch.tok_row), _ptr(batch.weights), nnz,
-                    _ptr(ws["d_emb"]), _ptr(ws["g_logit"]) if (use_lin or use_fm) else None,
-                    _ptr(ws["fm_sum"]) if use_fm else None, 1 if use_fm else 0, ctypes.byref(opt),
-                    _ptr(ws["pieces"]), None, st,
-                )
+        ev = self._mark("token_grads")
+        _lib.check(
+            lib.xdfm_embed_bwd(
+                1, _ptr(batch.src_table), None, None, None, None, None, _ptr(send_g),
+                _ptr(send_gl) if use_lin else None, max(nnz, 1), D, self.F, batch.B,
+                _ptr(self._arange32(nnz)), _ptr(order32), _ptr(batch.tok_row), _ptr(batch.weights), nnz,
+                _ptr(ws["d_emb"]), _ptr(ws["g_logit"]) if (use_lin or use_fm) else None,
+                _ptr(ws["fm_sum"]) if use_fm else None, 1 if use_fm else 0, ctypes.byref(opt),
+                _ptr(ws["pieces"]), None, st,
             )
-            self._done(ev)
-        # 2. to the owners
+        )
+        self._done(ev)
+
+    def _owner_update(self, batch, send_g, send_gl):
+        """Gradient rows to their owners, then the owner's sorted-key segment sum over what
+        arrived + fused sparse row optimizer."""
+        hp, lib, st = self.hp, self.lib, self._stream()
+        D, nnz = self.D, batch.nnz
+        use_lin = bool(hp.use_Linear_part)
+        plan = batch.route
+        opt = self._opt_args()
         recv_g = self.exchange.to_owner(plan, send_g[:nnz])
         recv_gl = self.exchange.to_owner(plan, send_gl[:nnz]) if use_lin else None
-        # 3. owner: sorted-key segment sum over what arrived + fused sparse row optimizer
         n = plan.n_recv
         if n:
             if batch.owner_event is not None:
@@ -260,18 +281,49 @@ class ShardedXDeepFMEngine(XDeepFMEngine):
                 )
             )
             self._done(ev)
+
+    def _update_embedding(self, batch):
+        nnz, D = batch.nnz, self.D
+        plan = batch.route
+        send_g = torch.empty((max(nnz, 1), D), dtype=torch.float32, device=self.device)
+        send_gl = (torch.empty((max(nnz, 1),), dtype=torch.float32, device=self.device)
+                   if self.hp.use_Linear_part else None)
+        order32 = (self._arange32(nnz) if plan.order is None else plan.order.to(torch.int32))
+        self._token_grads(batch, order32, send_g, send_gl)
+        self._owner_update(batch, send_g, send_gl)
         return True
+
+    # ------------------------------------------------------ graph of the local part
+    def _local_graph(self, batch):
+        key = (batch.B, batch.nnz)
+        g = self._local_graphs.get(key)
+        if g is None and len(self._local_graphs) < 4:
+            g = _LocalGraph(self, batch)
+            self._local_graphs[key] = g
+        return g
 
     def train_step(self, batch):
         """One optimisation step on this rank's share of the global batch.  Returns this
         rank's (total_loss share, data_loss share) as device scalars: their sum over the ranks
         is the global mean loss (regularisation counted once, on rank 0's share)."""
         self.mean_count = batch.B * self.world
-        self.fetch_rows(batch)
-        self.forward(batch, with_loss=True, with_grad=True)
-        self.backward(batch)
-        self._advance_step()
-        self._update_embedding(batch)
+        g = None
+        if self.graph_local and self.kernel_events is None and batch.nnz > 0:
+            g = self._local_graph(batch)  # None: too many shapes seen, stay eager
+        if g is not None:
+            self.fetch_rows(batch, static=g)
+            g.load(batch)
+            if g.graph is None:
+                g.capture()  # no collective in here: ranks may capture at different steps
+            g.graph.replay()
+            self._advance_step()
+            self._owner_update(batch, g.send_g, g.send_gl)
+        else:
+            self.fetch_rows(batch)
+            self.forward(batch, with_loss=True, with_grad=True)
+            self.backward(batch)
+            self._advance_step()
+            self._update_embedding(batch)
         if self.world > 1:
             ev = self._mark("dense_allreduce")
             dist.all_reduce(self.dense_grad, group=self.exchange.group)
@@ -313,3 +365,66 @@ class ShardedXDeepFMEngine(XDeepFMEngine):
                     dist.broadcast(lb, src=r, group=self.exchange.group)
                 lin[r::G] = lb
         return full, lin
+
+
+class _LocalGraph(object):
+    """forward + backward + per-token gradients of one rank for batches of one shape, captured
+    as a HIP graph over static buffers (the rows fetched from the owners land in src_table)."""
+
+    def __init__(self, eng, batch):
+        from recommenders_amd.models.deeprec.models._engine import DeviceBatch
+
+        dev, nnz, B, D = eng.device, batch.nnz, batch.B, eng.D
+        use_lin = bool(eng.hp.use_Linear_part)
+        f32 = torch.float32
+        self.eng = eng
+        self.src_table = torch.zeros((nnz, D), dtype=f32, device=dev)
+        self.src_lin = torch.zeros((nnz,), dtype=f32, device=dev) if use_lin else None
+        self.src_ids = torch.zeros((nnz,), dtype=torch.int64, device=dev)
+        self.order32 = torch.zeros((nnz,), dtype=torch.int32, device=dev)
+        self.send_g = torch.zeros((nnz, D), dtype=f32, device=dev)
+        self.send_gl = torch.zeros((nnz,), dtype=f32, device=dev) if use_lin else None
+        sb = DeviceBatch()
+        sb.B, sb.nnz = B, nnz
+        sb.labels = torch.zeros_like(batch.labels)
+        sb.weights = torch.zeros_like(batch.weights)
+        sb.row_ptr = torch.zeros_like(batch.row_ptr)
+        sb.tok_row = torch.zeros_like(batch.tok_row)
+        sb.ids = None  # never read: the embeddings come from src_table
+        sb.src_table, sb.src_lin, sb.src_ids, sb.src_N = self.src_table, self.src_lin, self.src_ids, max(nnz, 1)
+        sb.sorted_ids = sb.sorted_tok = None
+        sb.planned = True
+        sb.plan_event = None
+        self.batch = sb
+        self.graph = None
+
+    def capture(self):
+        """A warm-up pass off the capture, then the capture (the inputs hold a real batch)."""
+        dev = self.eng.device
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            self._run()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self._run()
+
+    def _run(self):
+        eng = self.eng
+        eng.forward(self.batch, with_loss=True, with_grad=True)
+        eng.backward(self.batch)
+        eng._token_grads(self.batch, self.order32, self.send_g, self.send_gl)
+
+    def load(self, batch):
+        """Copy the per-batch arrays (and the partition order) into the graph's inputs."""
+        sb, plan = self.batch, batch.route
+        sb.labels.copy_(batch.labels)
+        sb.weights.copy_(batch.weights)
+        sb.row_ptr.copy_(batch.row_ptr)
+        sb.tok_row.copy_(batch.tok_row)
+        if plan.order is None:
+            self.order32.copy_(self.eng._arange32(batch.nnz)[:batch.nnz])
+        else:
+            self.order32.copy_(plan.order)
