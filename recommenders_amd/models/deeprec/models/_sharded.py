@@ -314,10 +314,27 @@ class ShardedXDeepFMEngine(XDeepFMEngine):
             self.fetch_rows(batch, static=g)
             g.load(batch)
             if g.graph is None:
-                g.capture()  # no collective in here: ranks may capture at different steps
-            g.graph.replay()
-            self._advance_step()
-            self._owner_update(batch, g.send_g, g.send_gl)
+                try:
+                    g.capture()  # no collective in here: ranks may capture at different steps
+                except Exception as exc:  # stay correct if this runtime cannot capture the segment
+                    import warnings
+
+                    warnings.warn("local HIP graph capture failed (%s); running eagerly" % (exc,))
+                    self.graph_local = False
+                    self._local_graphs.clear()
+                    g.graph = None
+            if g.graph is not None:
+                g.graph.replay()
+                self._advance_step()
+                self._owner_update(batch, g.send_g, g.send_gl)
+            else:
+                # the fetched rows already sit in g's buffers: finish this step without the graph
+                batch.src_table, batch.src_lin, batch.src_ids = g.src_table, g.src_lin, g.src_ids
+                batch.src_N = max(batch.nnz, 1)
+                self.forward(batch, with_loss=True, with_grad=True)
+                self.backward(batch)
+                self._advance_step()
+                self._update_embedding(batch)
         else:
             self.fetch_rows(batch)
             self.forward(batch, with_loss=True, with_grad=True)
@@ -407,9 +424,11 @@ class _LocalGraph(object):
             self._run()
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        graph = torch.cuda.CUDAGraph()
+        # thread_local: the process group's watchdog thread may touch the runtime meanwhile
+        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
             self._run()
+        self.graph = graph
 
     def _run(self):
         eng = self.eng
