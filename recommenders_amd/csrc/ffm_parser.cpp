@@ -20,7 +20,10 @@
 #include <cstdlib>
 #include <limits>
 #include <numeric>
+#include <cstdarg>
+#include <cstdio>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "xdfm_common.h"
@@ -93,6 +96,42 @@ inline bool ieq(const char* b, const char* e, const char* word) {
 bool parse_py_float(Span s, double* out) {
   s = strip(s);
   if (s.empty()) return false;
+  {
+    // fast path (Clinger): [+-] digits [. digits] with at most 15 significant digits is
+    // mantissa / 10^k with both exactly representable, so one division rounds correctly --
+    // the same double Python's float() returns.  Anything else takes the general path below.
+    static const double kPow10[] = {1e0,  1e1,  1e2,  1e3,  1e4,  1e5,  1e6,  1e7,  1e8,  1e9,  1e10, 1e11,
+                                    1e12, 1e13, 1e14, 1e15, 1e16, 1e17, 1e18, 1e19, 1e20, 1e21, 1e22};
+    const char* q = s.b;
+    bool neg = false;
+    if (*q == '+' || *q == '-') neg = (*q++ == '-');
+    unsigned long long mant = 0;
+    int nd = 0, frac = 0;
+    bool ok = q < s.e, dot = false, any = false;
+    for (; q < s.e; ++q) {
+      const char ch = *q;
+      if (ch >= '0' && ch <= '9') {
+        mant = mant * 10 + (unsigned)(ch - '0');
+        any = true;
+        if (mant != 0 || nd != 0) ++nd;  // leading zeros are not significant
+        if (dot) ++frac;
+        if (nd > 15 || frac > 22) {
+          ok = false;
+          break;
+        }
+      } else if (ch == '.' && !dot) {
+        dot = true;
+      } else {
+        ok = false;
+        break;
+      }
+    }
+    if (ok && any) {
+      const double v = (double)mant / kPow10[frac];
+      *out = neg ? -v : v;
+      return true;
+    }
+  }
   char buf[96];
   size_t n = 0;
   const char* p = s.b;
@@ -153,6 +192,47 @@ bool parse_py_float(Span s, double* out) {
 
 using xdfm::Span;
 
+// what parsing a run of lines produces, in file order
+struct Staging {
+  std::vector<float> labels;
+  std::vector<int64_t> tok_sample, tok_feat, dnn_row, dnn_col;
+  std::vector<float> tok_val;
+  std::vector<int64_t> imp_off;  // start of each sample's impression id in imp_chars
+  std::vector<uint8_t> imp_present;
+  std::string imp_chars;
+  int64_t dnn_width = 0;
+  // per-sample scratch: running count per field (reference: dnn_feat_dic, :178-185)
+  std::vector<int64_t> cnt, stamp;                        // fields inside [0, F)
+  std::vector<std::pair<int64_t, int64_t>> field_count;   // any other field index
+  int err_code = 0;
+  std::string err;
+
+  void clear() {
+    labels.clear();
+    tok_sample.clear();
+    tok_feat.clear();
+    dnn_row.clear();
+    dnn_col.clear();
+    tok_val.clear();
+    imp_off.clear();
+    imp_present.clear();
+    imp_chars.clear();
+    dnn_width = 0;
+    err_code = 0;
+    err.clear();
+  }
+  int fail(int code, const char* fmt, ...) {
+    char buf[256];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    err_code = code;
+    err = buf;
+    return code;
+  }
+};
+
 struct xdfm_ffm_reader {
   int fd = -1;
   const char* data = nullptr;
@@ -163,16 +243,11 @@ struct xdfm_ffm_reader {
   char col_sep = ' ', id_sep = '%';
   // staged batch, file order
   int64_t first_line = 0;
-  std::vector<float> labels;
-  std::vector<int64_t> tok_sample, tok_feat, dnn_row, dnn_col;
-  std::vector<float> tok_val;
+  Staging st;                    // the batch
+  std::vector<Staging> workers;  // per-thread pieces of it
+  std::vector<xdfm::Span> lines;
   std::vector<uint32_t> order;  // dnn view permutation (stable by (row, col))
-  std::vector<int64_t> imp_off;
-  std::vector<uint8_t> imp_present;
-  std::string imp_chars;
-  int64_t dnn_width = 0;
-  // per-sample scratch: running count per field (reference: dnn_feat_dic, :178-185)
-  std::vector<std::pair<int64_t, int64_t>> field_count;
+  int threads = 1;
 };
 
 extern "C" int xdfm_ffm_open(const char* path, int64_t field_count, int64_t feature_count,
@@ -206,6 +281,12 @@ extern "C" int xdfm_ffm_open(const char* path, int64_t field_count, int64_t feat
   r->N = feature_count;
   r->col_sep = col_sep;
   r->id_sep = id_sep;
+  {
+    // parsing threads: XDFM_PARSE_THREADS, else the hardware's, at most 16
+    const char* e = getenv("XDFM_PARSE_THREADS");
+    int t = e ? atoi(e) : (int)std::thread::hardware_concurrency();
+    r->threads = t < 1 ? 1 : (t > 16 ? 16 : t);
+  }
   *out = r;
   return XDFM_OK;
 }
@@ -220,10 +301,9 @@ extern "C" int xdfm_ffm_close(xdfm_ffm_reader* r) {
 
 namespace {
 
-// one sample; appends to the reader's staging vectors
-int parse_line(xdfm_ffm_reader* r, Span line, int64_t sample) {
+// one sample (1-based line number ln, index `sample` in the batch); appends to st
+int parse_line(const xdfm_ffm_reader* r, Staging& st, Span line, int64_t sample, int64_t ln) {
   using namespace xdfm;
-  const int64_t ln = r->line_no;  // already incremented: 1-based number of this line
   line = strip(line);
   // words = line.split(ID_spliter); impression id only when len(words) == 2
   const char* first_sep = nullptr;
@@ -235,13 +315,13 @@ int parse_line(xdfm_ffm_reader* r, Span line, int64_t sample) {
     }
   Span head = line;
   if (first_sep) head.e = first_sep;
-  r->imp_off.push_back((int64_t)r->imp_chars.size());
+  st.imp_off.push_back((int64_t)st.imp_chars.size());
   if (seps == 1) {
     Span imp = strip(Span{first_sep + 1, line.e});
-    r->imp_chars.append(imp.b, imp.e);
-    r->imp_present.push_back(1);
+    st.imp_chars.append(imp.b, imp.e);
+    st.imp_present.push_back(1);
   } else {
-    r->imp_present.push_back(0);
+    st.imp_present.push_back(0);
   }
   head = strip(head);
 
@@ -259,46 +339,65 @@ int parse_line(xdfm_ffm_reader* r, Span line, int64_t sample) {
   next_word(&w);  // str.split always yields at least one (possibly empty) word
   double label;
   if (!parse_py_float(w, &label))
-    return fail(XDFM_E_PARSE, "line %lld: could not convert label '%.*s' to float", (long long)ln,
-                (int)std::min<ptrdiff_t>(w.e - w.b, 40), w.b);
-  r->labels.push_back((float)label);
+    return st.fail(XDFM_E_PARSE, "line %lld: could not convert label '%.*s' to float", (long long)ln,
+                   (int)std::min<ptrdiff_t>(w.e - w.b, 40), w.b);
+  st.labels.push_back((float)label);
 
-  r->field_count.clear();
+  st.field_count.clear();
+  if ((int64_t)st.cnt.size() != r->F) {
+    st.cnt.assign((size_t)r->F, 0);
+    st.stamp.assign((size_t)r->F, -1);
+  }
+  const int64_t epoch = ln;  // unique per line
   while (next_word(&w)) {
     if (strip(w).empty()) continue;
     // tokens = word.split(':'); tokens[0..2] used, extra ones ignored
     const char* c1 = (const char*)memchr(w.b, ':', (size_t)(w.e - w.b));
     const char* c2 = c1 ? (const char*)memchr(c1 + 1, ':', (size_t)(w.e - c1 - 1)) : nullptr;
     if (!c1 || !c2)
-      return fail(XDFM_E_PARSE, "line %lld: token '%.*s' is not field:feature:value",
-                  (long long)ln, (int)std::min<ptrdiff_t>(w.e - w.b, 40), w.b);
+      return st.fail(XDFM_E_PARSE, "line %lld: token '%.*s' is not field:feature:value", (long long)ln,
+                     (int)std::min<ptrdiff_t>(w.e - w.b, 40), w.b);
     const char* c3 = (const char*)memchr(c2 + 1, ':', (size_t)(w.e - c2 - 1));
     int64_t field, feat;
     double val;
     if (!parse_py_int(Span{w.b, c1}, &field) || !parse_py_int(Span{c1 + 1, c2}, &feat) ||
         !parse_py_float(Span{c2 + 1, c3 ? c3 : w.e}, &val))
-      return fail(XDFM_E_PARSE, "line %lld: invalid literal in token '%.*s'", (long long)ln,
-                  (int)std::min<ptrdiff_t>(w.e - w.b, 40), w.b);
+      return st.fail(XDFM_E_PARSE, "line %lld: invalid literal in token '%.*s'", (long long)ln,
+                     (int)std::min<ptrdiff_t>(w.e - w.b, 40), w.b);
     field -= 1;
     feat -= 1;
     // running count of this field inside the sample (column of the dnn view)
     int64_t col = 0;
-    bool seen = false;
-    for (auto& fc : r->field_count)
-      if (fc.first == field) {
-        col = ++fc.second;
-        seen = true;
-        break;
+    if (field >= 0 && field < r->F) {
+      if (st.stamp[(size_t)field] == epoch) {
+        col = ++st.cnt[(size_t)field];
+      } else {
+        st.stamp[(size_t)field] = epoch;
+        st.cnt[(size_t)field] = 0;
       }
-    if (!seen) r->field_count.emplace_back(field, 0);
-    r->tok_sample.push_back(sample);
-    r->tok_feat.push_back(feat);
-    r->tok_val.push_back((float)val);
-    r->dnn_row.push_back(sample * r->F + field);
-    r->dnn_col.push_back(col);
-    if (col + 1 > r->dnn_width) r->dnn_width = col + 1;
+    } else {
+      bool seen = false;
+      for (auto& fc : st.field_count)
+        if (fc.first == field) {
+          col = ++fc.second;
+          seen = true;
+          break;
+        }
+      if (!seen) st.field_count.emplace_back(field, 0);
+    }
+    st.tok_sample.push_back(sample);
+    st.tok_feat.push_back(feat);
+    st.tok_val.push_back((float)val);
+    st.dnn_row.push_back(sample * r->F + field);
+    st.dnn_col.push_back(col);
+    if (col + 1 > st.dnn_width) st.dnn_width = col + 1;
   }
   return XDFM_OK;
+}
+
+template <typename T>
+void append(std::vector<T>& dst, const std::vector<T>& src) {
+  dst.insert(dst.end(), src.begin(), src.end());
 }
 
 }  // namespace
@@ -306,53 +405,90 @@ int parse_line(xdfm_ffm_reader* r, Span line, int64_t sample) {
 extern "C" int xdfm_ffm_next(xdfm_ffm_reader* r, int64_t batch_size, xdfm_ffm_batch_info* info) {
   XDFM_REQUIRE(r && info, "xdfm_ffm_next: null argument");
   XDFM_REQUIRE(batch_size > 0, "xdfm_ffm_next: batch_size must be positive");
-  r->labels.clear();
-  r->tok_sample.clear();
-  r->tok_feat.clear();
-  r->tok_val.clear();
-  r->dnn_row.clear();
-  r->dnn_col.clear();
-  r->imp_off.clear();
-  r->imp_present.clear();
-  r->imp_chars.clear();
-  r->dnn_width = 0;
+  Staging& st = r->st;
+  st.clear();
   r->first_line = r->line_no + 1;
 
-  int64_t n = 0;
-  while (n < batch_size && r->pos < r->size) {
+  // 1. the next batch_size lines (universal newlines)
+  r->lines.clear();
+  const char* end = r->data + r->size;
+  while ((int64_t)r->lines.size() < batch_size && r->pos < r->size) {
     const char* b = r->data + r->pos;
-    const char* end = r->data + r->size;
     const char* e = b;
     while (e < end && *e != '\n' && *e != '\r') ++e;
     size_t next = (size_t)(e - r->data);
     if (e < end) next += (*e == '\r' && e + 1 < end && e[1] == '\n') ? 2 : 1;
     r->pos = next;
-    r->line_no += 1;
-    int rc = parse_line(r, Span{b, e}, n);
-    if (rc != XDFM_OK) return rc;
-    ++n;
+    r->lines.push_back(Span{b, e});
   }
+  const int64_t n = (int64_t)r->lines.size();
   if (n == 0) return xdfm::fail(XDFM_E_EOF, "end of file");
-  r->imp_off.push_back((int64_t)r->imp_chars.size());
+
+  // 2. parse: contiguous runs of lines on up to r->threads threads, each into its own staging
+  int T = r->threads;
+  if (T > n / 256) T = (int)(n / 256);
+  if (T < 1) T = 1;
+  const int64_t base_line = r->line_no;
+  if (T == 1) {
+    for (int64_t i = 0; i < n; ++i)
+      if (parse_line(r, st, r->lines[(size_t)i], i, base_line + i + 1) != XDFM_OK) break;
+  } else {
+    if ((int)r->workers.size() < T) r->workers.resize((size_t)T);
+    std::vector<std::thread> pool;
+    const int64_t per = (n + T - 1) / T;
+    for (int t = 0; t < T; ++t) {
+      pool.emplace_back([r, t, per, n, base_line]() {
+        Staging& w = r->workers[(size_t)t];
+        w.clear();
+        const int64_t lo = t * per, hi = std::min<int64_t>(n, lo + per);
+        for (int64_t i = lo; i < hi; ++i)
+          if (parse_line(r, w, r->lines[(size_t)i], i, base_line + i + 1) != XDFM_OK) break;
+      });
+    }
+    for (auto& th : pool) th.join();
+    // 3. stitch the pieces together in file order; the first failing piece decides the error
+    for (int t = 0; t < T; ++t) {
+      Staging& w = r->workers[(size_t)t];
+      const int64_t imp_base = (int64_t)st.imp_chars.size();
+      append(st.labels, w.labels);
+      append(st.tok_sample, w.tok_sample);
+      append(st.tok_feat, w.tok_feat);
+      append(st.dnn_row, w.dnn_row);
+      append(st.dnn_col, w.dnn_col);
+      append(st.tok_val, w.tok_val);
+      append(st.imp_present, w.imp_present);
+      for (int64_t o : w.imp_off) st.imp_off.push_back(o + imp_base);
+      st.imp_chars += w.imp_chars;
+      if (w.dnn_width > st.dnn_width) st.dnn_width = w.dnn_width;
+      if (w.err_code) {
+        st.err_code = w.err_code;
+        st.err = w.err;
+        break;
+      }
+    }
+  }
+  r->line_no += n;
+  if (st.err_code) return xdfm::fail(st.err_code, "%s", st.err.c_str());
+  st.imp_off.push_back((int64_t)st.imp_chars.size());
 
   // dnn view order: stable by (row, col)   (iterator.py:198-201)
-  const size_t nnz = r->dnn_row.size();
+  const size_t nnz = r->st.dnn_row.size();
   r->order.resize(nnz);
   std::iota(r->order.begin(), r->order.end(), 0u);
   bool sorted = true;
   for (size_t k = 1; k < nnz && sorted; ++k)
-    sorted = std::make_pair(r->dnn_row[k - 1], r->dnn_col[k - 1]) <=
-             std::make_pair(r->dnn_row[k], r->dnn_col[k]);
+    sorted = std::make_pair(r->st.dnn_row[k - 1], r->st.dnn_col[k - 1]) <=
+             std::make_pair(r->st.dnn_row[k], r->st.dnn_col[k]);
   if (!sorted)
     std::stable_sort(r->order.begin(), r->order.end(), [r](uint32_t a, uint32_t b) {
-      if (r->dnn_row[a] != r->dnn_row[b]) return r->dnn_row[a] < r->dnn_row[b];
-      return r->dnn_col[a] < r->dnn_col[b];
+      if (r->st.dnn_row[a] != r->st.dnn_row[b]) return r->st.dnn_row[a] < r->st.dnn_row[b];
+      return r->st.dnn_col[a] < r->st.dnn_col[b];
     });
 
   info->n_rows = n;
   info->nnz = (int64_t)nnz;
-  info->dnn_width = r->dnn_width;
-  info->imp_bytes = (int64_t)r->imp_chars.size();
+  info->dnn_width = r->st.dnn_width;
+  info->imp_bytes = (int64_t)r->st.imp_chars.size();
   info->first_line = r->first_line;
   return XDFM_OK;
 }
@@ -363,23 +499,23 @@ extern "C" int xdfm_ffm_fill(xdfm_ffm_reader* r, float* labels, int64_t* fm_feat
                              int32_t* row_ptr, int64_t* imp_offsets, char* imp_chars,
                              uint8_t* imp_present) {
   XDFM_REQUIRE(r, "xdfm_ffm_fill: null reader");
-  const size_t n = r->labels.size();
-  const size_t nnz = r->dnn_row.size();
-  if (labels) memcpy(labels, r->labels.data(), n * sizeof(float));
+  const size_t n = r->st.labels.size();
+  const size_t nnz = r->st.dnn_row.size();
+  if (labels) memcpy(labels, r->st.labels.data(), n * sizeof(float));
   if (fm_feat_indices)
     for (size_t k = 0; k < nnz; ++k) {
-      fm_feat_indices[2 * k] = r->tok_sample[k];
-      fm_feat_indices[2 * k + 1] = r->tok_feat[k];
+      fm_feat_indices[2 * k] = r->st.tok_sample[k];
+      fm_feat_indices[2 * k + 1] = r->st.tok_feat[k];
     }
-  if (fm_feat_values) memcpy(fm_feat_values, r->tok_val.data(), nnz * sizeof(float));
+  if (fm_feat_values) memcpy(fm_feat_values, r->st.tok_val.data(), nnz * sizeof(float));
   for (size_t k = 0; k < nnz; ++k) {
     const uint32_t s = r->order[k];
     if (dnn_feat_indices) {
-      dnn_feat_indices[2 * k] = r->dnn_row[s];
-      dnn_feat_indices[2 * k + 1] = r->dnn_col[s];
+      dnn_feat_indices[2 * k] = r->st.dnn_row[s];
+      dnn_feat_indices[2 * k + 1] = r->st.dnn_col[s];
     }
-    if (dnn_feat_values) dnn_feat_values[k] = r->tok_feat[s];
-    if (dnn_feat_weights) dnn_feat_weights[k] = r->tok_val[s];
+    if (dnn_feat_values) dnn_feat_values[k] = r->st.tok_feat[s];
+    if (dnn_feat_weights) dnn_feat_weights[k] = r->st.tok_val[s];
   }
   if (row_ptr) {
     const int64_t rows = (int64_t)n * r->F;
@@ -387,7 +523,7 @@ extern "C" int xdfm_ffm_fill(xdfm_ffm_reader* r, float* labels, int64_t* fm_feat
                  "xdfm_ffm_fill: batch too large for int32 CSR offsets");
     memset(row_ptr, 0, (size_t)(rows + 1) * sizeof(int32_t));
     for (size_t k = 0; k < nnz; ++k) {
-      const int64_t row = r->dnn_row[k];
+      const int64_t row = r->st.dnn_row[k];
       if (row < 0 || row >= rows)
         return xdfm::fail(XDFM_E_INVALID,
                           "batch starting at line %lld: field index outside [1, FIELD_COUNT=%lld]",
@@ -396,8 +532,8 @@ extern "C" int xdfm_ffm_fill(xdfm_ffm_reader* r, float* labels, int64_t* fm_feat
     }
     for (int64_t i = 0; i < rows; ++i) row_ptr[i + 1] += row_ptr[i];
   }
-  if (imp_offsets) memcpy(imp_offsets, r->imp_off.data(), (n + 1) * sizeof(int64_t));
-  if (imp_chars && !r->imp_chars.empty()) memcpy(imp_chars, r->imp_chars.data(), r->imp_chars.size());
-  if (imp_present) memcpy(imp_present, r->imp_present.data(), n);
+  if (imp_offsets) memcpy(imp_offsets, r->st.imp_off.data(), (n + 1) * sizeof(int64_t));
+  if (imp_chars && !r->st.imp_chars.empty()) memcpy(imp_chars, r->st.imp_chars.data(), r->st.imp_chars.size());
+  if (imp_present) memcpy(imp_present, r->st.imp_present.data(), n);
   return XDFM_OK;
 }
