@@ -50,6 +50,9 @@ extern "C" {
 #define XDFM_OPT_SGD 0
 #define XDFM_OPT_ADAM 1
 #define XDFM_OPT_ADAGRAD 2
+#define XDFM_OPT_RMSPROP 3  /* beta2 = decay, eps; slot_m = rms (starts at 1) */
+#define XDFM_OPT_ADADELTA 4 /* beta2 = rho, eps; slot_m = accum, slot_v = accum_update */
+#define XDFM_OPT_FTRL 5     /* lr_power -0.5, l1 = l2 = 0; slot_m = accum (starts at 0.1), slot_v = linear */
 
 /* loss enum: base_model.py:215-262 */
 #define XDFM_LOSS_LOG 0           /* tf.compat.v1.losses.log_loss, eps 1e-7 */

@@ -338,8 +338,17 @@ def new_opt_state(params, hp):
         # fp32 beta powers multiplied up step by step, like TF's slot variables
         st["b1p"] = np.float32(1.0)
         st["b2p"] = np.float32(1.0)
-    elif hp.optimizer == "adagrad":
+    elif hp.optimizer in ("adagrad", "padagrad"):
+        # ProximalAdagradOptimizer(lr) has l1 = l2 = 0: its update is Adagrad's (base_model.py:295-296)
         st["acc"] = {n: torch.full_like(p, 0.1) for n, p in params.items()}  # initial_accumulator_value
+    elif hp.optimizer == "rmsprop":  # RMSPropOptimizer(lr): decay .9, momentum 0, eps 1e-10, rms slot = 1
+        st["ms"] = {n: torch.ones_like(p) for n, p in params.items()}
+    elif hp.optimizer == "adadelta":  # AdadeltaOptimizer(lr): rho .95, eps 1e-8, both slots 0
+        st["acc"] = {n: torch.zeros_like(p) for n, p in params.items()}
+        st["acc_upd"] = {n: torch.zeros_like(p) for n, p in params.items()}
+    elif hp.optimizer == "ftrl":  # FtrlOptimizer(lr): lr_power -.5, accum 0.1, l1 = l2 = 0
+        st["acc"] = {n: torch.full_like(p, 0.1) for n, p in params.items()}
+        st["lin"] = {n: torch.zeros_like(p) for n, p in params.items()}
     return st
 
 
@@ -362,11 +371,33 @@ def _apply(name, p, g, st, hp, rows=None):
         m[sel] = m[sel] + (g - m[sel]) * one_b1
         v[sel] = v[sel] + (g * g - v[sel]) * one_b2
         p[sel] = p[sel] - (m[sel] * alpha) / (torch.sqrt(v[sel]) + eps)
-    elif hp.optimizer == "adagrad":
+    elif hp.optimizer in ("adagrad", "padagrad"):
         acc = st["acc"][name]
         acc[sel] = acc[sel] + g * g
         p[sel] = p[sel] - (g * lr) / torch.sqrt(acc[sel])
-    else:  # sgd / gd / unknown -> GradientDescent (base_model.py:288, :293, :301-302)
+    elif hp.optimizer == "rmsprop":
+        # TF ApplyRMSProp: ms += (g^2 - ms)*(1-decay); mom = momentum*mom + lr*g*rsqrt(ms+eps); p -= mom
+        ms = st["ms"][name]
+        ms[sel] = ms[sel] + (g * g - ms[sel]) * (1 - 0.9)
+        p[sel] = p[sel] - (g * lr) / torch.sqrt(ms[sel] + 1e-10)
+    elif hp.optimizer == "adadelta":
+        # TF ApplyAdadelta: accum = rho*accum + (1-rho)*g^2; update = sqrt(accum_update+eps)*rsqrt(accum+eps)*g;
+        # accum_update = rho*accum_update + (1-rho)*update^2; p -= lr*update
+        acc, au = st["acc"][name], st["acc_upd"][name]
+        rho, eps = 0.95, 1e-8
+        acc[sel] = acc[sel] * rho + g * g * (1 - rho)
+        upd = torch.sqrt(au[sel] + eps) / torch.sqrt(acc[sel] + eps) * g
+        au[sel] = au[sel] * rho + upd * upd * (1 - rho)
+        p[sel] = p[sel] - upd * lr
+    elif hp.optimizer == "ftrl":
+        # TF ApplyFtrl with lr_power = -0.5, l1 = l2 = 0:
+        # new = accum + g^2; linear += g - (sqrt(new) - sqrt(accum))/lr * p; p = -linear / (sqrt(new)/lr)
+        acc, lin = st["acc"][name], st["lin"][name]
+        new = acc[sel] + g * g
+        lin[sel] = lin[sel] + g - (torch.sqrt(new) - torch.sqrt(acc[sel])) / lr * p[sel]
+        p[sel] = -lin[sel] / (torch.sqrt(new) / lr)
+        acc[sel] = new
+    else:  # sgd / gd / pgd (l1 = l2 = 0) / unknown -> GradientDescent (base_model.py:288, :293, :297-302)
         p[sel] = p[sel] - g * lr
 
 

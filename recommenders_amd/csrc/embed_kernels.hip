@@ -279,6 +279,41 @@ __device__ __forceinline__ void apply_row(const OptDev& o, float* p, float* m, f
       pv[i] = pv[i] - (g[i] * o.lr) / sqrtf(av[i]);
     }
     store_vec<VEC>(m, av);
+  } else if (o.kind == XDFM_OPT_RMSPROP) {
+    float av[VEC];
+    load_vec<VEC>(m, av);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      av[i] = av[i] + (g[i] * g[i] - av[i]) * o.one_minus_b2;
+      pv[i] = pv[i] - (g[i] * o.lr) / sqrtf(av[i] + o.eps);
+    }
+    store_vec<VEC>(m, av);
+  } else if (o.kind == XDFM_OPT_ADADELTA) {
+    float av[VEC], uv[VEC];
+    load_vec<VEC>(m, av);
+    load_vec<VEC>(v, uv);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      av[i] = av[i] * (1.f - o.one_minus_b2) + g[i] * g[i] * o.one_minus_b2;
+      const float upd = sqrtf(uv[i] + o.eps) / sqrtf(av[i] + o.eps) * g[i];
+      uv[i] = uv[i] * (1.f - o.one_minus_b2) + upd * upd * o.one_minus_b2;
+      pv[i] = pv[i] - upd * o.lr;
+    }
+    store_vec<VEC>(m, av);
+    store_vec<VEC>(v, uv);
+  } else if (o.kind == XDFM_OPT_FTRL) {
+    float av[VEC], lv[VEC];
+    load_vec<VEC>(m, av);
+    load_vec<VEC>(v, lv);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      const float nw = av[i] + g[i] * g[i];
+      lv[i] = lv[i] + g[i] - (sqrtf(nw) - sqrtf(av[i])) / o.lr * pv[i];
+      pv[i] = -lv[i] / (sqrtf(nw) / o.lr);
+      av[i] = nw;
+    }
+    store_vec<VEC>(m, av);
+    store_vec<VEC>(v, lv);
   } else {
 #pragma unroll
     for (int i = 0; i < VEC; ++i) pv[i] = pv[i] - g[i] * o.lr;
@@ -531,8 +566,7 @@ int pick_vec(int D) { return (D % 4 == 0) ? 4 : (D % 2 == 0 ? 2 : 1); }
 
 int make_opt(const xdfm_opt_args* opt, OptDev* o) {
   XDFM_REQUIRE(opt, "optimizer arguments are null");
-  XDFM_REQUIRE(opt->kind == XDFM_OPT_SGD || opt->kind == XDFM_OPT_ADAM ||
-                   opt->kind == XDFM_OPT_ADAGRAD,
+  XDFM_REQUIRE(opt->kind >= XDFM_OPT_SGD && opt->kind <= XDFM_OPT_FTRL,
                "unknown optimizer kind %d", opt->kind);
   o->kind = opt->kind;
   o->lr = opt->lr;
@@ -706,11 +740,11 @@ extern "C" int xdfm_embed_bwd(int32_t mode, float* table, float* slot_m, float* 
                  "xdfm_embed_bwd: sparse_rows mode cannot apply l1/l2/clip (their gradient is dense); "
                  "use mode 1 + xdfm_dense_update");
     XDFM_REQUIRE(opt->kind == XDFM_OPT_SGD || slot_m, "xdfm_embed_bwd: optimizer slot missing");
-    XDFM_REQUIRE(opt->kind != XDFM_OPT_ADAM || slot_v, "xdfm_embed_bwd: Adam needs slot_v");
+    XDFM_REQUIRE(!xdfm::opt_needs_v(opt->kind) || slot_v, "xdfm_embed_bwd: this optimizer needs slot_v");
     if (lin_w) {
       XDFM_REQUIRE(g_logit, "xdfm_embed_bwd: linear part needs g_logit");
       XDFM_REQUIRE(opt->kind == XDFM_OPT_SGD || lin_m, "xdfm_embed_bwd: lin slot missing");
-      XDFM_REQUIRE(opt->kind != XDFM_OPT_ADAM || lin_v, "xdfm_embed_bwd: lin slot_v missing");
+      XDFM_REQUIRE(!xdfm::opt_needs_v(opt->kind) || lin_v, "xdfm_embed_bwd: lin slot_v missing");
     }
   } else {
     XDFM_REQUIRE(grad_table, "xdfm_embed_bwd: scatter mode needs grad_table");

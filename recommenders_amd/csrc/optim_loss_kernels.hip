@@ -163,6 +163,27 @@ __global__ __launch_bounds__(256) void dense_update_kernel(SegTable tab, OptDev 
       a = a + g * g;
       p = p - (g * o.lr) / sqrtf(a);
       slot_m[i] = a;
+    } else if (o.kind == XDFM_OPT_RMSPROP) {
+      float a = slot_m[i];
+      a = a + (g * g - a) * o.one_minus_b2;
+      p = p - (g * o.lr) / sqrtf(a + o.eps);
+      slot_m[i] = a;
+    } else if (o.kind == XDFM_OPT_ADADELTA) {
+      float a = slot_m[i], u = slot_v[i];
+      a = a * (1.f - o.one_minus_b2) + g * g * o.one_minus_b2;
+      const float upd = sqrtf(u + o.eps) / sqrtf(a + o.eps) * g;
+      u = u * (1.f - o.one_minus_b2) + upd * upd * o.one_minus_b2;
+      p = p - upd * o.lr;
+      slot_m[i] = a;
+      slot_v[i] = u;
+    } else if (o.kind == XDFM_OPT_FTRL) {
+      const float a = slot_m[i];
+      float l = slot_v[i];
+      const float nw = a + g * g;
+      l = l + g - (sqrtf(nw) - sqrtf(a)) / o.lr * p;
+      p = -l / (sqrtf(nw) / o.lr);
+      slot_m[i] = nw;
+      slot_v[i] = l;
     } else {
       p = p - g * o.lr;
     }
@@ -412,10 +433,10 @@ extern "C" int xdfm_dense_update(float* param, const float* grad, float* slot_m,
                                  int32_t accumulate_reg_loss, void* stream) {
   XDFM_REQUIRE(param && seg_off && opt && stats, "xdfm_dense_update: null argument");
   XDFM_REQUIRE(n_seg > 0 && n_seg <= kMaxSeg, "xdfm_dense_update: n_seg %d outside [1,%d]", n_seg, kMaxSeg);
-  XDFM_REQUIRE(opt->kind == XDFM_OPT_SGD || opt->kind == XDFM_OPT_ADAM || opt->kind == XDFM_OPT_ADAGRAD,
+  XDFM_REQUIRE(opt->kind >= XDFM_OPT_SGD && opt->kind <= XDFM_OPT_FTRL,
                "xdfm_dense_update: unknown optimizer kind %d", opt->kind);
   XDFM_REQUIRE(opt->kind == XDFM_OPT_SGD || slot_m, "xdfm_dense_update: slot_m missing");
-  XDFM_REQUIRE(opt->kind != XDFM_OPT_ADAM || slot_v, "xdfm_dense_update: slot_v missing");
+  XDFM_REQUIRE(!xdfm::opt_needs_v(opt->kind) || slot_v, "xdfm_dense_update: slot_v missing");
   SegTable tab;
   memset(&tab, 0, sizeof(tab));
   tab.n = n_seg;

@@ -11,6 +11,8 @@ namespace xdfm {
 // thread-local message returned by xdfm_last_error()
 char* error_buffer();
 int fail(int code, const char* fmt, ...);
+// optimizers with a second slot: Adam (v), Adadelta (accum_update), FTRL (linear)
+inline bool opt_needs_v(int kind) { return kind == 1 || kind == 4 || kind == 5; }
 
 // Times everything enqueued on `stream` during its lifetime when xdfm_prof_enable(1) is on
 // (two HIP events); otherwise a no-op.  The name is the kernel's (as rocprofv3 prints it).

@@ -18,7 +18,15 @@ from recommenders_amd import _lib
 
 _ACT = {"identity": 0, "relu": 1, "sigmoid": 2, "tanh": 3, "elu": 4}
 _LOSS = {"log_loss": 0, "cross_entropy_loss": 1, "square_loss": 2}
-_OPT = {"sgd": 0, "gd": 0, "adam": 1, "adagrad": 2}
+# base_model.py:283-302.  ProximalAdagrad / ProximalGradientDescent are built with l1 = l2 = 0
+# there, which makes their updates Adagrad's / plain gradient descent's.
+_OPT = {"sgd": 0, "gd": 0, "pgd": 0, "adam": 1, "adagrad": 2, "padagrad": 2, "rmsprop": 3, "adadelta": 4,
+        "ftrl": 5}
+# (beta1, beta2, eps) as TF1 builds each optimizer from `lr` alone
+_OPT_CONST = {0: (0.0, 0.0, 0.0), 1: (0.9, 0.999, 1e-8), 2: (0.0, 0.0, 0.0), 3: (0.0, 0.9, 1e-10),
+              4: (0.0, 0.95, 1e-8), 5: (0.0, 0.0, 0.0)}
+# initial value of the first slot (Adagrad / FTRL accumulators 0.1, RMSProp's rms 1.0)
+_SLOT_M_INIT = {1: 0.0, 2: 0.1, 3: 1.0, 4: 0.0, 5: 0.1}
 
 _DEVERR = {
     1: "a feature index is outside [1, FEATURE_COUNT]",
@@ -116,8 +124,6 @@ class XDeepFMEngine(object):
         self.embedding_update = embedding_update
         self.opt_kind = _OPT.get(hp.optimizer)
         if self.opt_kind is None:
-            if hp.optimizer in ("adadelta", "ftrl", "padagrad", "pgd", "rmsprop"):
-                raise NotImplementedError("optimizer {0} is not built yet".format(hp.optimizer))
             self.opt_kind = 0  # unknown names fall back to SGD (base_model.py:301-302)
         if embedding_update == "sparse_rows":
             if hp.embed_l1 != 0.0 or hp.embed_l2 != 0.0:
@@ -148,17 +154,17 @@ class XDeepFMEngine(object):
             self.views[name] = self.dense[offs[i] : offs[i + 1]].view(shape)
             self.grad_views[name] = self.dense_grad[offs[i] : offs[i + 1]].view(shape)
         # ---- optimizer slots
-        slot_init = 0.1 if self.opt_kind == 2 else 0.0  # Adagrad initial_accumulator_value
-        need_m = self.opt_kind in (1, 2)
-        need_v = self.opt_kind == 1
+        need_m = self.opt_kind != 0
+        need_v = self.opt_kind in (1, 4, 5)  # Adam v, Adadelta accum_update, FTRL linear
 
-        def slot(like, on):
-            return torch.full_like(like, slot_init) if on else None
+        def slot(like, on, value=0.0):
+            return torch.full_like(like, value) if on else None
 
-        self.table_m, self.table_v = slot(self.table, need_m), slot(self.table, need_v)
-        self.lin_m = slot(self.lin_w, need_m) if self.lin_w is not None else None
+        m0 = _SLOT_M_INIT.get(self.opt_kind, 0.0)
+        self.table_m, self.table_v = slot(self.table, need_m, m0), slot(self.table, need_v)
+        self.lin_m = slot(self.lin_w, need_m, m0) if self.lin_w is not None else None
         self.lin_v = slot(self.lin_w, need_v) if self.lin_w is not None else None
-        self.dense_m, self.dense_v = slot(self.dense, need_m), slot(self.dense, need_v)
+        self.dense_m, self.dense_v = slot(self.dense, need_m, m0), slot(self.dense, need_v)
         self.step = 0
         self.b1p = np.float32(1.0)
         self.b2p = np.float32(1.0)
@@ -677,7 +683,8 @@ class XDeepFMEngine(object):
 
     def _opt_args(self, l2=0.0, l1=0.0, clip=0.0):
         hp = self.hp
-        return _lib.OptArgs(self.opt_kind, float(hp.learning_rate), 0.9, 0.999, 1e-8,
+        b1, b2, eps = _OPT_CONST[self.opt_kind]
+        return _lib.OptArgs(self.opt_kind, float(hp.learning_rate), b1, b2, eps,
                             float(self.b1p), float(self.b2p), float(l2), float(l1), float(clip), 0,
                             self.opt_state.data_ptr() if self.opt_kind == 1 else None)
 

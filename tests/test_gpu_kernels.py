@@ -163,7 +163,7 @@ def test_forward_and_gradients_match_oracle(name, loss):
 
 
 @pytest.mark.parametrize("fast_d", [0, 2])
-@pytest.mark.parametrize("optimizer", ["adam", "adagrad", "sgd"])
+@pytest.mark.parametrize("optimizer", ["adam", "adagrad", "sgd", "rmsprop", "adadelta", "ftrl", "padagrad", "pgd"])
 @pytest.mark.parametrize("mode", ["dense_exact", "sparse_rows"])
 def test_training_steps_match_oracle(optimizer, mode, fast_d):
     if fast_d and (optimizer != "adam"):
@@ -191,7 +191,10 @@ def test_training_steps_match_oracle(optimizer, mode, fast_d):
     eng.check_errors()
     sd = eng.state_dict()
     # a few Adam steps amplify fp32 rounding of tiny gradients by up to 1/sqrt(v): allow 2e-4 there
-    tol = 2e-4 if optimizer == "adam" else 2e-5
+    # (rmsprop / adadelta / ftrl divide by roots of small accumulators in the same way)
+    tol = 2e-4 if optimizer in ("adam", "rmsprop", "adadelta") else 2e-5
+    if optimizer == "ftrl":
+        tol = 2e-3  # p = -linear / quadratic with `linear` a cancelling sum (g - sigma*p): fp32 vs the fp64 oracle
     for k, v in p64.items():
         close(sd[k].cpu().numpy().reshape(v.shape), v.numpy(), rtol=tol, what="param " + k)
 
