@@ -256,6 +256,20 @@ int xdfm_cin_bwd(const float* x0, const float* xk, const float* w, int64_t B, in
                  int32_t pool_off, float* d_xk, float* d_x0, float* d_w, float* dw_part,
                  void* stream);
 
+/* cross_activation (xDeepFM.py:242, :402): the activation between a CIN layer's product and its
+ * split.  With a non-identity activation run the layer with n_hidden = L (raw curr[B,L,D] into a
+ * buffer of its own, no pooled output), then
+ *   xdfm_cin_act_fwd: curr <- act(curr) in place (kept for the backward), xnext / pooled as in
+ *                     xdfm_cin_fwd;
+ *   xdfm_cin_act_bwd: d_curr[B,L,D] = upstream * act'(y), to be handed to the layer's backward as
+ *                     its d_xnext with n_hidden = L.
+ * act: XDFM_ACT_* (softmax is not supported). */
+int xdfm_cin_act_fwd(float* curr, int64_t B, int32_t L, int32_t D, int32_t n_hidden, int32_t act,
+                     float* xnext, float* pooled, int32_t pool_stride, int32_t pool_off, void* stream);
+int xdfm_cin_act_bwd(const float* y, const float* d_xnext, const float* d_pooled, int32_t pool_stride,
+                     int32_t pool_off, int64_t B, int32_t L, int32_t D, int32_t n_hidden, int32_t act,
+                     float* d_curr, void* stream);
+
 /* ------------------------------------------------------------------------
  * Fast (low-rank) CIN, one layer.   xDeepFM.py:295-451 (`_build_fast_CIN`, fast_CIN_d > 0)
  *   x0[B,F,D], xk[B,H,D]; w[F, d*L], v[H, d*L] (the [1,F,d*L] / [1,H,d*L] conv1d filters);

@@ -97,6 +97,8 @@ SIGNATURES = {
     "xdfm_dense_fwd": [_P, _P, _P, _I64, _I32, _I32, _I32, _P, _P],
     "xdfm_dense_bwd_workspace_floats": [_I64, _I32, _I32, _PSZ],
     "xdfm_dense_bwd": [_P, _P, _P, _P, _I64, _I32, _I32, _I32, _P, _I32, _P, _P, _P, _P],
+    "xdfm_cin_act_fwd": [_P, _I64, _I32, _I32, _I32, _I32, _P, _P, _I32, _I32, _P],
+    "xdfm_cin_act_bwd": [_P, _P, _P, _I32, _I32, _I64, _I32, _I32, _I32, _I32, _P, _P],
     "xdfm_fast_cin_fwd": [_P, _P, _P, _P, _I64, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _P, _P, _I32, _I32, _P],
     "xdfm_fast_cin_bwd_workspace_floats": [_I64, _I32, _I32, _I32, _I32, _I32, _PSZ],
     "xdfm_fast_cin_bwd": [_P, _P, _P, _P, _I64, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _P, _P, _I32, _I32,

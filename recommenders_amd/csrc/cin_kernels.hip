@@ -17,6 +17,7 @@
 // Layouts: x0[B][F][D], xk[B][H][D], w[F*H][L], xnext[B][n_hidden][D], pooled[B][stride].
 #include <hip/hip_runtime.h>
 
+#include "act.h"
 #include "cin_common.h"
 #include "xdfm_common.h"
 
@@ -456,6 +457,81 @@ extern "C" int xdfm_cin_bwd(const float* x0, const float* xk, const float* w, in
     XDFM_LAUNCH("cin_dw_reduce_kernel", st, cin_dw_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
                        c, part, P > 0 ? n_splits : 0, d_w);
   }
+  XDFM_LAUNCH_CHECK();
+  return XDFM_OK;
+}
+
+// ------------------------------------------------------------------ cross_activation
+// `curr_out = self._activate(curr_out, hparams.cross_activation)` (xDeepFM.py:242, :402) sits
+// between the layer's product and its split into hidden / pooled channels.  With a
+// non-identity activation the layer kernels run with every channel "hidden" (raw curr into a
+// buffer of its own) and these two elementwise kernels do the rest.
+namespace {
+
+// y = act(curr) in place; xnext[b,n,d] = y (n < n_hidden); pooled[b, off+n-n_hidden] = sum_d y
+__global__ __launch_bounds__(256) void cin_act_fwd_kernel(float* __restrict__ curr, int64_t B, int L, int D,
+                                                          int n_hidden, int act, float* __restrict__ xnext,
+                                                          float* __restrict__ pooled, int pool_stride,
+                                                          int pool_off) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // (b, n)
+  if (idx >= B * L) return;
+  const int64_t b = idx / L;
+  const int n = (int)(idx - b * L);
+  float* row = curr + idx * D;
+  float s = 0.f;
+  for (int d = 0; d < D; ++d) {
+    const float y = activate(row[d], act);
+    row[d] = y;
+    if (n < n_hidden) xnext[(b * n_hidden + n) * D + d] = y;
+    s += y;  // reduce_sum over D in d order (:270)
+  }
+  if (n >= n_hidden) pooled[b * pool_stride + pool_off + n - n_hidden] = s;
+}
+
+// d_curr[b,n,d] = upstream(b,n,d) * act'(y)
+__global__ __launch_bounds__(256) void cin_act_bwd_kernel(const float* __restrict__ y,
+                                                          const float* __restrict__ d_xnext,
+                                                          const float* __restrict__ d_pooled, int pool_stride,
+                                                          int pool_off, int64_t B, int L, int D, int n_hidden,
+                                                          int act, float* __restrict__ d_curr) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // (b, n, d)
+  if (idx >= B * L * D) return;
+  const int d = (int)(idx % D);
+  const int64_t bn = idx / D;
+  const int64_t b = bn / L;
+  const int n = (int)(bn - b * L);
+  const float up = n < n_hidden ? d_xnext[(b * n_hidden + n) * D + d]
+                                : d_pooled[b * pool_stride + pool_off + n - n_hidden];
+  d_curr[idx] = up * act_grad(y[idx], act);
+}
+
+}  // namespace
+
+extern "C" int xdfm_cin_act_fwd(float* curr, int64_t B, int32_t L, int32_t D, int32_t n_hidden, int32_t act,
+                                float* xnext, float* pooled, int32_t pool_stride, int32_t pool_off,
+                                void* stream) {
+  XDFM_REQUIRE(curr && B >= 0 && L > 0 && D > 0 && n_hidden >= 0 && n_hidden <= L, "xdfm_cin_act_fwd: bad argument");
+  XDFM_REQUIRE(act >= XDFM_ACT_IDENTITY && act <= XDFM_ACT_ELU, "xdfm_cin_act_fwd: unknown activation %d", act);
+  XDFM_REQUIRE(n_hidden == 0 || xnext, "xdfm_cin_act_fwd: xnext is null");
+  XDFM_REQUIRE(n_hidden == L || pooled, "xdfm_cin_act_fwd: pooled is null");
+  if (B == 0) return XDFM_OK;
+  XDFM_LAUNCH("cin_act_fwd_kernel", stream, cin_act_fwd_kernel, dim3((unsigned)((B * L + 255) / 256)), dim3(256), 0,
+              curr, B, L, D, n_hidden, act, xnext, pooled, pool_stride, pool_off);
+  XDFM_LAUNCH_CHECK();
+  return XDFM_OK;
+}
+
+extern "C" int xdfm_cin_act_bwd(const float* y, const float* d_xnext, const float* d_pooled, int32_t pool_stride,
+                                int32_t pool_off, int64_t B, int32_t L, int32_t D, int32_t n_hidden, int32_t act,
+                                float* d_curr, void* stream) {
+  XDFM_REQUIRE(y && d_curr && B >= 0 && L > 0 && D > 0 && n_hidden >= 0 && n_hidden <= L,
+               "xdfm_cin_act_bwd: bad argument");
+  XDFM_REQUIRE(act >= XDFM_ACT_IDENTITY && act <= XDFM_ACT_ELU, "xdfm_cin_act_bwd: unknown activation %d", act);
+  XDFM_REQUIRE(n_hidden == 0 || d_xnext, "xdfm_cin_act_bwd: d_xnext is null");
+  XDFM_REQUIRE(n_hidden == L || d_pooled, "xdfm_cin_act_bwd: d_pooled is null");
+  if (B == 0) return XDFM_OK;
+  XDFM_LAUNCH("cin_act_bwd_kernel", stream, cin_act_bwd_kernel, dim3((unsigned)((B * L * D + 255) / 256)), dim3(256),
+              0, y, d_xnext, d_pooled, pool_stride, pool_off, B, L, D, n_hidden, act, d_curr);
   XDFM_LAUNCH_CHECK();
   return XDFM_OK;
 }

@@ -15,6 +15,7 @@
 // Layouts: x[B][K], w[K][Nout], b[Nout], y[B][Nout].
 #include <hip/hip_runtime.h>
 
+#include "act.h"
 #include "xdfm_common.h"
 
 namespace {
@@ -23,27 +24,6 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ f32x4 mfma(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
-}
-
-__device__ __forceinline__ float activate(float v, int act) {
-  switch (act) {
-    case XDFM_ACT_RELU: return v > 0.f ? v : 0.f;
-    case XDFM_ACT_SIGMOID: return 1.f / (1.f + expf(-v));
-    case XDFM_ACT_TANH: return tanhf(v);
-    case XDFM_ACT_ELU: return v > 0.f ? v : expm1f(v);
-    default: return v;
-  }
-}
-
-// derivative expressed through the saved output y = act(z)
-__device__ __forceinline__ float act_grad(float y, int act) {
-  switch (act) {
-    case XDFM_ACT_RELU: return y > 0.f ? 1.f : 0.f;
-    case XDFM_ACT_SIGMOID: return y * (1.f - y);
-    case XDFM_ACT_TANH: return 1.f - y * y;
-    case XDFM_ACT_ELU: return y > 0.f ? 1.f : y + 1.f;
-    default: return 1.f;
-  }
 }
 
 // ------------------------------------------------------------------------ forward

@@ -105,8 +105,13 @@ class XDeepFMEngine(object):
             raise NotImplementedError("enable_BN (xDeepFM.py:234-240, :497-503) is not built yet")
         if hp.user_dropout:
             raise NotImplementedError("user_dropout (base_model.py:335-336) is not built yet")
-        if hp.use_CIN_part and hp.cross_activation != "identity":
-            raise NotImplementedError("cross_activation other than identity is not built yet")
+        self.cross_act = 0
+        if hp.use_CIN_part:
+            if hp.cross_activation == "softmax":
+                raise NotImplementedError("cross_activation softmax is not built yet")
+            if hp.cross_activation not in _ACT:
+                raise ValueError("this activations not defined {0}".format(hp.cross_activation))
+            self.cross_act = _ACT[hp.cross_activation]
         if hp.loss not in _LOSS:
             raise ValueError("this loss not defined {0}".format(hp.loss))
         if hp.method not in ("classification", "regression"):
@@ -350,6 +355,12 @@ class XDeepFMEngine(object):
                 if nh > 0:
                     buf("hid_%d" % k, B, nh * D)
                     buf("d_hid_%d" % k, B, nh * D)
+                if self.cross_act:
+                    # a non-identity cross_activation: raw / activated curr of every channel is kept
+                    buf("cur_%d" % k, B, L * D)
+            if self.cross_act:
+                buf("d_cur", B, max(L for (_, L, _) in shapes) * D)
+            for k, (H, L, nh) in enumerate(shapes):
                 if self.fast_d:
                     _lib.check(self.lib.xdfm_fast_cin_bwd_workspace_floats(B, F, H, D, L, self.fast_d,
                                                                            ctypes.byref(sz)))
@@ -504,18 +515,26 @@ class XDeepFMEngine(object):
             xk = x0
             for k, (H, L, nh) in enumerate(shapes):
                 xnext = ws["hid_%d" % k] if nh > 0 else None
+                # with a cross_activation the layer writes raw curr for all L channels; the
+                # activation kernel then produces the hidden / pooled split
+                out_h, out_nh = (ws["cur_%d" % k], L) if self.cross_act else (xnext, nh)
                 if self.fast_d:
                     _lib.check(
                         lib.xdfm_fast_cin_fwd(_ptr(x0), _ptr(xk), _ptr(self.views["fcin_w_%d" % k]),
                                               _ptr(self.views["fcin_v_%d" % k]) if k > 0 else None, B, F, H,
-                                              D, L, self.fast_d, nh, 1 if k == 0 else 0, _ptr(xnext),
+                                              D, L, self.fast_d, out_nh, 1 if k == 0 else 0, _ptr(out_h),
                                               _ptr(ws["pooled"]), final_len, off, st)
                     )
                 else:
                     _lib.check(
                         lib.xdfm_cin_fwd(_ptr(x0), _ptr(xk), _ptr(self.views["cin_f_%d" % k]), B, F, H, D,
-                                         L, nh, 1 if k == 0 else 0, _ptr(xnext), _ptr(ws["pooled"]),
+                                         L, out_nh, 1 if k == 0 else 0, _ptr(out_h), _ptr(ws["pooled"]),
                                          final_len, off, _ptr(ws["part"]), st)
+                    )
+                if self.cross_act:
+                    _lib.check(
+                        lib.xdfm_cin_act_fwd(_ptr(ws["cur_%d" % k]), B, L, D, nh, self.cross_act, _ptr(xnext),
+                                             _ptr(ws["pooled"]), final_len, off, st)
                     )
                 off += L - nh
                 xk = xnext
@@ -658,12 +677,20 @@ class XDeepFMEngine(object):
                 xk = x0 if k == 0 else ws["hid_%d" % (k - 1)]
                 d_xnext = ws["d_hid_%d" % k] if nh > 0 else None
                 d_xk = None if k == 0 else ws["d_hid_%d" % (k - 1)]
+                d_pool, up_nh = ws["d_pooled"], nh
+                if self.cross_act:
+                    _lib.check(
+                        lib.xdfm_cin_act_bwd(_ptr(ws["cur_%d" % k]), _ptr(d_xnext), _ptr(ws["d_pooled"]),
+                                             final_len, offs[k], B, L, D, nh, self.cross_act,
+                                             _ptr(ws["d_cur"]), st)
+                    )
+                    d_xnext, d_pool, up_nh = ws["d_cur"], None, L
                 if self.fast_d:
                     _lib.check(
                         lib.xdfm_fast_cin_bwd(_ptr(x0), _ptr(xk), _ptr(self.views["fcin_w_%d" % k]),
                                               _ptr(self.views["fcin_v_%d" % k]) if k > 0 else None, B, F, H,
-                                              D, L, self.fast_d, nh, 1 if k == 0 else 0, _ptr(d_xnext),
-                                              _ptr(ws["d_pooled"]), final_len, offs[k], _ptr(d_xk),
+                                              D, L, self.fast_d, up_nh, 1 if k == 0 else 0, _ptr(d_xnext),
+                                              _ptr(d_pool), final_len, offs[k], _ptr(d_xk),
                                               _ptr(d_emb), _ptr(gv["fcin_w_%d" % k]),
                                               _ptr(gv["fcin_v_%d" % k]) if k > 0 else None,
                                               _ptr(ws["part"]), st)
@@ -671,7 +698,7 @@ class XDeepFMEngine(object):
                     continue
                 _lib.check(
                     lib.xdfm_cin_bwd(_ptr(x0), _ptr(xk), _ptr(self.views["cin_f_%d" % k]), B, F, H, D, L,
-                                     nh, 1 if k == 0 else 0, _ptr(d_xnext), _ptr(ws["d_pooled"]),
+                                     up_nh, 1 if k == 0 else 0, _ptr(d_xnext), _ptr(d_pool),
                                      final_len, offs[k], _ptr(d_xk), _ptr(d_emb),
                                      _ptr(gv["cin_f_%d" % k]), _ptr(ws["part"]), st)
                 )

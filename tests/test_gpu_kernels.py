@@ -105,6 +105,10 @@ CONFIGS = {
     "fast_cin_criteo_shape": dict(FIELD_COUNT=39, dim=16, FEATURE_COUNT=5000, fast_CIN_d=4,
                                   cross_layer_sizes=[20, 10], layer_sizes=[20], activation=["relu"],
                                   dropout=[0.0]),
+    # cross_activation between the CIN product and its split (xDeepFM.py:242, :402)
+    "cross_act_cin": dict(cross_activation="sigmoid", FIELD_COUNT=9, dim=8, cross_layer_sizes=[12, 8, 6]),
+    "cross_act_fast": dict(cross_activation="tanh", FIELD_COUNT=9, dim=6, fast_CIN_d=2,
+                           cross_layer_sizes=[10, 6], layer_sizes=[8], activation=["relu"], dropout=[0.0]),
     # more than 40 fields: the input-gradient kernel's first form and the wide staging of the filter gradient
     "many_fields": dict(FIELD_COUNT=45, dim=4, FEATURE_COUNT=2000, cross_layer_sizes=[8, 4],
                         layer_sizes=[16], activation=["relu"], dropout=[0.0]),
