@@ -308,6 +308,19 @@ int xdfm_dense_bwd(const float* x, const float* w, const float* y, const float* 
                    int32_t K, int32_t Nout, int32_t act, float* dx, int32_t accumulate_dx,
                    float* dw, float* db, float* part, void* stream);
 
+/* Dropout of a DNN layer (user_dropout, base_model.py:324-337, :355-365): tf.nn.dropout on the
+ * pre-activation, then the activation.  Run xdfm_dense_fwd with act = identity, then
+ *   xdfm_dropout_act_fwd: z[B,n] <- act(z * m / keep) in place, mask_scale[B,n] = m / keep kept for
+ *                         the backward; m is a counter-based hash of (seed, *step, element) -- step
+ *                         is a device float (the optimizer's step count), may be NULL;
+ *   xdfm_dropout_act_bwd: dz = dy * act'(y) * mask_scale, to be handed to xdfm_dense_bwd as dy with
+ *                         act = identity.
+ * TF's random stream is not reproducible: parity holds given the same masks. */
+int xdfm_dropout_act_fwd(float* z, float* mask_scale, int64_t B, int32_t n, float keep, int32_t act,
+                         uint64_t seed, const float* step, void* stream);
+int xdfm_dropout_act_bwd(const float* y, const float* dy, const float* mask_scale, int64_t B, int32_t n,
+                         int32_t act, float* dz, void* stream);
+
 /* ------------------------------------------------------------------------
  * CIN output head with the residual connection (res=True):
  *   exFM_out[b] = sum_n r[b,n] + (sum_n r[b,n]*w[n] + bias)        xDeepFM.py:269-293

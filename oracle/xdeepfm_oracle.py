@@ -184,7 +184,7 @@ def _activate(x, name):
     raise ValueError("this activations not defined {0}".format(name))
 
 
-def forward(params, batch, hp, embedding_rows=None):
+def forward(params, batch, hp, embedding_rows=None, dropout_masks=None):
     """Logit [B,1] of XDeepFMModel._build_graph (xDeepFM.py:24-71).
 
     batch: dict with the iterator's arrays (labels, dnn_feat_*, fm_feat_*) as numpy.
@@ -276,8 +276,11 @@ def forward(params, batch, hp, embedding_rows=None):
             h = h @ params["dnn_w_%d" % k] + params["dnn_b_%d" % k]
             if hp.enable_BN is True:
                 raise NotImplementedError("batch norm (xDeepFM.py:497-503) is not restated yet")
-            if hp.user_dropout:
-                raise NotImplementedError("dropout (base_model.py:335-336) is not restated yet")
+            if hp.user_dropout and dropout_masks is not None:
+                # _active_layer (base_model.py:335-336): tf.nn.dropout on the pre-activation.  TF's
+                # random stream is not reproducible: the caller supplies m / keep per layer
+                # (training); None = keep probability 1 (eval / infer, base_model.py:400, :414)
+                h = h * torch.as_tensor(dropout_masks[k], dtype=h.dtype)
             h = _activate(h, hp.activation[k])
         dnn = h @ params["dnn_w_out"] + params["dnn_b_out"]
         aux["dnn"] = dnn
@@ -401,7 +404,7 @@ def _apply(name, p, g, st, hp, rows=None):
         p[sel] = p[sel] - g * lr
 
 
-def train_step(params, st, batch, hp, mode="dense_exact"):
+def train_step(params, st, batch, hp, mode="dense_exact", dropout_masks=None):
     """One `sess.run(update)` (base_model.py:367-388): returns (loss, data_loss, grads).
 
     dense_exact : reference semantics -- every variable (the whole table included) takes an
@@ -437,12 +440,12 @@ def train_step(params, st, batch, hp, mode="dense_exact"):
             if n not in ("embedding", "lin_w"):
                 leaves[n] = p.clone().requires_grad_(True)
                 work[n] = leaves[n]
-        logit, aux = forward(work, batch, hp, embedding_rows=(sub, remap))
+        logit, aux = forward(work, batch, hp, embedding_rows=(sub, remap), dropout_masks=dropout_masks)
         reg_params = {n: leaves[n] for n in leaves if n not in ("embedding", "lin_w")}
     else:
         for n, p in params.items():
             leaves[n] = p.clone().requires_grad_(True)
-        logit, aux = forward(leaves, batch, hp)
+        logit, aux = forward(leaves, batch, hp, dropout_masks=dropout_masks)
         reg_params = leaves
 
     pred = pred_from_logit(logit, hp)

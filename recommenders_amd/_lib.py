@@ -103,6 +103,8 @@ SIGNATURES = {
     "xdfm_fast_cin_bwd_workspace_floats": [_I64, _I32, _I32, _I32, _I32, _I32, _PSZ],
     "xdfm_fast_cin_bwd": [_P, _P, _P, _P, _I64, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _P, _P, _I32, _I32,
                           _P, _P, _P, _P, _P, _P],
+    "xdfm_dropout_act_fwd": [_P, _P, _I64, _I32, ctypes.c_float, _I32, ctypes.c_uint64, _P, _P],
+    "xdfm_dropout_act_bwd": [_P, _P, _P, _I64, _I32, _I32, _P, _P],
     "xdfm_cin_head_fwd": [_P, _P, _P, _I64, _I32, _P, _P],
     "xdfm_cin_head_bwd": [_P, _P, _P, _I64, _I32, _P, _P, _P, _P, _P],
     "xdfm_logit_loss": [_P, _P, _P, _P, _P, _P, _I64, _I64, _I32, _I32, _P, _P, _P, _P, _P, _P],

@@ -474,3 +474,68 @@ extern "C" int xdfm_cin_head_bwd(const float* pooled, const float* w, const floa
   return xdfm_dense_bwd(pooled, w, g /* y unused for identity */, g, B, n, 1, XDFM_ACT_IDENTITY,
                         nullptr, 0, dw, db, part, stream);
 }
+
+// ------------------------------------------------------------------------ dropout
+// `_active_layer` (base_model.py:324-337): with hparams.user_dropout the layer's pre-activation
+// z goes through tf.nn.dropout(rate = 1 - keep) before the activation: y = act(z * m / keep),
+// m ~ Bernoulli(keep).  TF's random stream cannot be reproduced; this one is a counter-based
+// hash of (seed, layer, step, element), the step read from device memory so that a captured
+// step draws fresh masks on every replay.  The scaled mask is kept for the backward.
+namespace {
+
+__device__ __forceinline__ uint32_t mix32(uint64_t x) {  // splitmix64 finaliser, upper half
+  x += 0x9e3779b97f4a7c15ull;
+  x = (x ^ (x >> 30)) * 0xbf58476d1ce4e5b9ull;
+  x = (x ^ (x >> 27)) * 0x94d049bb133111ebull;
+  x ^= x >> 31;
+  return (uint32_t)(x >> 32);
+}
+
+__global__ __launch_bounds__(256) void dropout_act_fwd_kernel(float* __restrict__ z, float* __restrict__ mscale,
+                                                              int64_t total, float keep, int act, uint64_t seed,
+                                                              const float* __restrict__ step) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const uint64_t t = step ? (uint64_t)step[0] : 0ull;
+  const uint32_t r = mix32(seed ^ (t * 0xd1342543de82ef95ull) ^ ((uint64_t)i * 0x2545f4914f6cdd1dull + 1));
+  const float u = (float)(r >> 8) * (1.0f / 16777216.0f);  // [0, 1)
+  const float ms = u < keep ? 1.0f / keep : 0.f;
+  mscale[i] = ms;
+  z[i] = activate(z[i] * ms, act);
+}
+
+__global__ __launch_bounds__(256) void dropout_act_bwd_kernel(const float* __restrict__ y,
+                                                              const float* __restrict__ dy,
+                                                              const float* __restrict__ mscale, int64_t total,
+                                                              int act, float* __restrict__ dz) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  dz[i] = dy[i] * act_grad(y[i], act) * mscale[i];
+}
+
+}  // namespace
+
+extern "C" int xdfm_dropout_act_fwd(float* z, float* mask_scale, int64_t B, int32_t n, float keep, int32_t act,
+                                    uint64_t seed, const float* step, void* stream) {
+  XDFM_REQUIRE(z && mask_scale && B >= 0 && n > 0, "xdfm_dropout_act_fwd: bad argument");
+  XDFM_REQUIRE(keep > 0.f && keep <= 1.f, "xdfm_dropout_act_fwd: keep probability %g outside (0, 1]", (double)keep);
+  XDFM_REQUIRE(act_ok(act), "xdfm_dropout_act_fwd: unknown activation %d", act);
+  if (B == 0) return XDFM_OK;
+  const int64_t total = B * n;
+  XDFM_LAUNCH("dropout_act_fwd_kernel", stream, dropout_act_fwd_kernel, dim3((unsigned)((total + 255) / 256)),
+              dim3(256), 0, z, mask_scale, total, keep, act, seed, step);
+  XDFM_LAUNCH_CHECK();
+  return XDFM_OK;
+}
+
+extern "C" int xdfm_dropout_act_bwd(const float* y, const float* dy, const float* mask_scale, int64_t B, int32_t n,
+                                    int32_t act, float* dz, void* stream) {
+  XDFM_REQUIRE(y && dy && mask_scale && dz && B >= 0 && n > 0, "xdfm_dropout_act_bwd: bad argument");
+  XDFM_REQUIRE(act_ok(act), "xdfm_dropout_act_bwd: unknown activation %d", act);
+  if (B == 0) return XDFM_OK;
+  const int64_t total = B * n;
+  XDFM_LAUNCH("dropout_act_bwd_kernel", stream, dropout_act_bwd_kernel, dim3((unsigned)((total + 255) / 256)),
+              dim3(256), 0, y, dy, mask_scale, total, act, dz);
+  XDFM_LAUNCH_CHECK();
+  return XDFM_OK;
+}

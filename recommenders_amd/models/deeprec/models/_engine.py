@@ -103,8 +103,12 @@ class XDeepFMEngine(object):
         self.fast_d = int(hp.fast_CIN_d) if hp.fast_CIN_d > 0 else 0
         if hp.enable_BN is True:
             raise NotImplementedError("enable_BN (xDeepFM.py:234-240, :497-503) is not built yet")
-        if hp.user_dropout:
-            raise NotImplementedError("user_dropout (base_model.py:335-336) is not built yet")
+        # dropout of the DNN layers (base_model.py:335-336): keep = 1 - hparams.dropout[k] in training
+        self.use_dropout = bool(hp.user_dropout and hp.use_DNN_part)
+        if self.use_dropout and len(hp.dropout) < len(hp.layer_sizes):
+            raise ValueError("dropout needs one rate per DNN layer")
+        self.dropout_seed = 0x5DEECE66D ^ (0 if seed is None else int(seed))
+        self._dropout_live = False  # set by a training forward pass, read by the backward pass
         self.cross_act = 0
         if hp.use_CIN_part:
             if hp.cross_activation == "softmax":
@@ -378,6 +382,8 @@ class XDeepFMEngine(object):
             for k, size in enumerate(hp.layer_sizes):
                 buf("h_%d" % k, B, int(size))
                 buf("d_h_%d" % k, B, int(size))
+                if self.use_dropout:
+                    buf("drop_%d" % k, B, int(size))
                 _lib.check(self.lib.xdfm_dense_bwd_workspace_floats(B, last, int(size), ctypes.byref(sz)))
                 dnn_part_floats = max(dnn_part_floats, sz.value)
                 last = int(size)
@@ -480,6 +486,8 @@ class XDeepFMEngine(object):
     # ----------------------------------------------------------------- forward
     def forward(self, batch, with_loss=True, with_grad=False):
         hp, lib, ws, st = self.hp, self.lib, None, self._stream()
+        # layer_keeps = keep_prob_train only under train() (base_model.py:377); eval / infer feed ones
+        self._dropout_live = self.use_dropout and with_grad
         self._ensure_ws(batch.B, batch.nnz)
         ws = self.ws
         B, F, D = batch.B, self.F, self.D
@@ -579,11 +587,19 @@ class XDeepFMEngine(object):
         ev = self._mark("dnn_fwd")
         x, K = ws["emb_out"], self.F * self.D
         for k, size in enumerate(hp.layer_sizes):
+            act = _ACT[hp.activation[k]]
             _lib.check(
                 lib.xdfm_dense_fwd(_ptr(x), _ptr(self.views["dnn_w_%d" % k]),
                                    _ptr(self.views["dnn_b_%d" % k]), B, K, int(size),
-                                   _ACT[hp.activation[k]], _ptr(ws["h_%d" % k]), st)
+                                   0 if self._dropout_live else act, _ptr(ws["h_%d" % k]), st)
             )
+            if self._dropout_live:
+                _lib.check(
+                    lib.xdfm_dropout_act_fwd(_ptr(ws["h_%d" % k]), _ptr(ws["drop_%d" % k]), B, int(size),
+                                             float(1.0 - float(hp.dropout[k])), act,
+                                             (self.dropout_seed + 0x9E3779B97F4A7C15 * (k + 1)) & (2 ** 64 - 1),
+                                             _ptr(self.opt_state[3:]), st)
+                )
             x, K = ws["h_%d" % k], int(size)
         _lib.check(
             lib.xdfm_dense_fwd(_ptr(x), _ptr(self.views["dnn_w_out"]), _ptr(self.views["dnn_b_out"]),
@@ -611,10 +627,17 @@ class XDeepFMEngine(object):
                 dx, acc = first_layer_dx if first_layer_dx is not None else (None, 0)
             else:
                 dx, acc = d_acts[k], 0
+            act = _ACT[hp.activation[k]]
+            if self._dropout_live:
+                # dz = dy * act'(y) * mask/keep in place; the layer itself is then linear
+                _lib.check(
+                    lib.xdfm_dropout_act_bwd(_ptr(acts[k + 1]), _ptr(d_acts[k + 1]), _ptr(ws["drop_%d" % k]), B,
+                                             sizes[k + 1], act, _ptr(d_acts[k + 1]), st)
+                )
+                act = 0
             _lib.check(
                 lib.xdfm_dense_bwd(_ptr(acts[k]), _ptr(self.views["dnn_w_%d" % k]), _ptr(acts[k + 1]),
-                                   _ptr(d_acts[k + 1]), B, sizes[k], sizes[k + 1],
-                                   _ACT[hp.activation[k]], _ptr(dx), acc,
+                                   _ptr(d_acts[k + 1]), B, sizes[k], sizes[k + 1], act, _ptr(dx), acc,
                                    _ptr(gv["dnn_w_%d" % k]), _ptr(gv["dnn_b_%d" % k]),
                                    _ptr(ws["part_dnn"]), st)
             )
@@ -626,7 +649,8 @@ class XDeepFMEngine(object):
         _lib.check(
             lib.xdfm_dense_bwd(_ptr(ws["emb_out"]), _ptr(self.views["dnn_w_0"]), _ptr(ws["h_0"]),
                                _ptr(ws["d_h_0"]), B, self.F * self.D, int(hp.layer_sizes[0]),
-                               _ACT[hp.activation[0]], _ptr(d_emb), 1, None, None, None, st)
+                               0 if self._dropout_live else _ACT[hp.activation[0]], _ptr(d_emb), 1, None, None,
+                               None, st)
         )
 
     # ---------------------------------------------------------------- backward
@@ -717,7 +741,7 @@ class XDeepFMEngine(object):
 
     def _advance_step(self):
         self.step += 1
-        if self.opt_kind == 1:
+        if self.opt_kind == 1 or self.use_dropout:  # the device-side step count also seeds the dropout masks
             self.b1p = np.float32(self.b1p * np.float32(0.9))  # host mirror (checkpoints)
             self.b2p = np.float32(self.b2p * np.float32(0.999))
             _lib.check(self.lib.xdfm_opt_advance(_ptr(self.opt_state), float(self.hp.learning_rate), 0.9, 0.999,

@@ -131,6 +131,7 @@ class ShardedXDeepFMEngine(XDeepFMEngine):
                                embedding_update="sparse_rows", table_rows=max(rows, 1))
         if self.world > 1:
             dist.broadcast(self.dense, src=0, group=group)  # replicated parameters start identical
+        self.dropout_seed ^= (0x632BE59BD9B4E019 * self.rank) & (2 ** 64 - 1)  # ranks draw different masks
         self._consts = {}
         self._owner_ws = {}
         # forward + backward + per-token gradients have fixed shapes once the rows are fetched:

@@ -203,6 +203,42 @@ def test_training_steps_match_oracle(optimizer, mode, fast_d):
         close(sd[k].cpu().numpy().reshape(v.shape), v.numpy(), rtol=tol, what="param " + k)
 
 
+def test_dropout_training_matches_oracle_given_the_masks():
+    """user_dropout (base_model.py:335-336, :377): the masks come from the engine's own generator
+    (TF's stream is not reproducible); with the same masks the oracle must take the same steps.
+    Eval / infer feed keep = 1 (base_model.py:400, :414)."""
+    hp = make_hp(user_dropout=True, dropout=[0.3, 0.5], layer_sizes=[32, 16], activation=["relu", "tanh"],
+                 optimizer="adam", learning_rate=0.01, FEATURE_COUNT=300, layer_l2=0.01)
+    rng = np.random.default_rng(8)
+    p32 = X.init_params(hp, seed=4)
+    eng = load_engine(hp, p32)
+    p64 = {k: v.double() for k, v in p32.items()}
+    st = X.new_opt_state(p64, hp)
+    seen = []
+    for step in range(3):
+        B = 256 if step != 1 else 77
+        b = random_batch(rng, hp, B)
+        loss, dloss = eng.train_step(upload(eng, b))
+        masks = [eng.ws["drop_%d" % k][:B].cpu().numpy().astype(np.float64) for k in range(2)]
+        for k, m in enumerate(masks):
+            keep = 1.0 - hp.dropout[k]
+            assert set(np.unique(m.astype(np.float32))) <= {np.float32(0.0), np.float32(1.0 / keep)}
+            assert abs((m != 0).mean() - keep) < 0.05
+        seen.append(masks[0][:77] != 0)
+        o_loss, o_dl, _, _ = X.train_step(p64, st, b, hp, dropout_masks=masks)
+        close(float(dloss), o_dl, what="data loss step %d" % step)
+        close(float(loss), o_loss, what="total loss step %d" % step)
+    assert (seen[0] != seen[1]).any() and (seen[1] != seen[2]).any()  # a new mask every step
+    sd = eng.state_dict()
+    for k, v in p64.items():
+        close(sd[k].cpu().numpy().reshape(v.shape), v.numpy(), rtol=2e-4, what="param " + k)
+    # scoring: no dropout
+    b = random_batch(rng, hp, 50)
+    eng.forward(upload(eng, b), with_loss=False, with_grad=False)
+    logit, _ = X.forward(p64, b, hp)
+    close(eng.ws["logit"][:50].cpu().numpy(), logit.numpy()[:, 0], rtol=2e-4, what="eval logit")
+
+
 def test_clip_by_norm_matches_oracle():
     hp = make_hp(is_clip_norm=1, max_grad_norm=0.05, optimizer="sgd", learning_rate=0.1, FEATURE_COUNT=200,
                  embed_l2=0.01)
@@ -269,10 +305,13 @@ def test_eval_auc_logloss_matches_cal_metric(golden):
         assert abs(auc - exact) < 1e-15
 
 
-def test_graph_replay_equals_eager_steps():
+@pytest.mark.parametrize("dropout", [False, True])
+def test_graph_replay_equals_eager_steps(dropout):
     """A step captured into a HIP graph (device-side Adam scalars, side-stream sort joined
-    inside the capture) must reproduce the eager launches bit for bit."""
-    hp = make_hp(optimizer="adam", learning_rate=0.01, FEATURE_COUNT=400, cross_l2=0.01)
+    inside the capture) must reproduce the eager launches bit for bit.  With dropout the masks
+    are a function of (seed, device-side step count, element): replays draw the eager masks."""
+    hp = make_hp(optimizer="adam", learning_rate=0.01, FEATURE_COUNT=400, cross_l2=0.01,
+                 user_dropout=dropout, dropout=[0.2, 0.4])
     rng = np.random.default_rng(12)
     p32 = X.init_params(hp, seed=4)
     from oracle import ffm_iterator_oracle as O
