@@ -54,6 +54,33 @@ class RowShardExchange(object):
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.virtual_world = int(virtual_world) if self.world == 1 else 1
+        # rehearsal mode: the gloo backend has no all-to-all for device tensors, so several ranks
+        # sharing one GPU (tests on a one-GPU box) stage their exchanges through the host
+        self.host_staged = self.world > 1 and dist.get_backend(group) == "gloo"
+
+    def _a2a(self, out, x, out_splits=None, in_splits=None):
+        if self.host_staged and x.is_cuda:
+            h = torch.empty(out.shape, dtype=out.dtype)
+            dist.all_to_all_single(h, x.cpu(), out_splits, in_splits, group=self.group)
+            out.copy_(h)
+        else:
+            dist.all_to_all_single(out, x, out_splits, in_splits, group=self.group)
+
+    def all_reduce(self, x):
+        if self.host_staged and x.is_cuda:
+            h = x.cpu()
+            dist.all_reduce(h, group=self.group)
+            x.copy_(h)
+        else:
+            dist.all_reduce(x, group=self.group)
+
+    def broadcast(self, x, src):
+        if self.host_staged and x.is_cuda:
+            h = x.cpu()
+            dist.broadcast(h, src=src, group=self.group)
+            x.copy_(h)
+        else:
+            dist.broadcast(x, src=src, group=self.group)
 
     def route(self, ids):
         """ids: int64 [n] global feature ids of this rank's tokens.  Sends every id to its
@@ -82,7 +109,7 @@ class RowShardExchange(object):
         order = torch.argsort(dest, stable=True)
         send_counts = torch.bincount(dest, minlength=G)
         recv_counts = torch.empty_like(send_counts)
-        dist.all_to_all_single(recv_counts, send_counts, group=self.group)
+        self._a2a(recv_counts, send_counts)
         plan.send_counts = [int(v) for v in send_counts.tolist()]
         plan.recv_counts = [int(v) for v in recv_counts.tolist()]  # host sync: sizes of the exchange
         plan.order = order
@@ -99,7 +126,7 @@ class RowShardExchange(object):
         if self.world == 1:
             return x
         out = x.new_empty((plan.n_recv,) + tuple(x.shape[1:]))
-        dist.all_to_all_single(out, x.contiguous(), plan.recv_counts, plan.send_counts, group=self.group)
+        self._a2a(out, x.contiguous(), plan.recv_counts, plan.send_counts)
         return out
 
     def to_source(self, plan, y, out=None):
@@ -112,7 +139,7 @@ class RowShardExchange(object):
             return out
         if out is None:
             out = y.new_empty((plan.n_send,) + tuple(y.shape[1:]))
-        dist.all_to_all_single(out, y.contiguous(), plan.send_counts, plan.recv_counts, group=self.group)
+        self._a2a(out, y.contiguous(), plan.send_counts, plan.recv_counts)
         return out
 
 
@@ -130,7 +157,7 @@ class ShardedXDeepFMEngine(XDeepFMEngine):
         XDeepFMEngine.__init__(self, hp, device=device, seed=None if seed is None else seed + 7919 * self.rank,
                                embedding_update="sparse_rows", table_rows=max(rows, 1))
         if self.world > 1:
-            dist.broadcast(self.dense, src=0, group=group)  # replicated parameters start identical
+            self.exchange.broadcast(self.dense, 0)  # replicated parameters start identical
         self.dropout_seed ^= (0x632BE59BD9B4E019 * self.rank) & (2 ** 64 - 1)  # ranks draw different masks
         self._consts = {}
         self._owner_ws = {}
@@ -344,7 +371,7 @@ class ShardedXDeepFMEngine(XDeepFMEngine):
             self._update_embedding(batch)
         if self.world > 1:
             ev = self._mark("dense_allreduce")
-            dist.all_reduce(self.dense_grad, group=self.exchange.group)
+            self.exchange.all_reduce(self.dense_grad)
             self._done(ev)
         self._update_dense(True)
         reg = self.reg_loss if self.rank == 0 else torch.zeros_like(self.reg_loss)
@@ -375,12 +402,12 @@ class ShardedXDeepFMEngine(XDeepFMEngine):
             rows = local_rows(n, r, G)
             buf = self.table[:rows].clone() if r == self.rank else torch.empty((rows, self.D), device=self.device)
             if G > 1:
-                dist.broadcast(buf, src=r, group=self.exchange.group)
+                self.exchange.broadcast(buf, r)
             full[r::G] = buf
             if lin is not None:
                 lb = self.lin_w[:rows].clone() if r == self.rank else torch.empty((rows,), device=self.device)
                 if G > 1:
-                    dist.broadcast(lb, src=r, group=self.exchange.group)
+                    self.exchange.broadcast(lb, r)
                 lin[r::G] = lb
         return full, lin
 
