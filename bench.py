@@ -172,13 +172,21 @@ def main():
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
+    # XDFM_DIST_BACKEND=gloo: rehearsal of the N > 1 code on a box with fewer GPUs than ranks
+    # (ranks share devices, exchanges staged through the host) -- never a measurement
+    backend = os.environ.get("XDFM_DIST_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank %= max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
 
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     hp = workload_hparams(args)
     n_batches = 8
@@ -262,7 +270,7 @@ def main():
         raise SystemExit("training diverged: loss %r" % final_loss)
 
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -311,7 +319,8 @@ def main():
                                    "batch %d per GPU, linear+FM+CIN[20,10]+DNN[20,20], sparse-row Adam" % (hp.dim, hp.batch_size),
                        "FEATURE_COUNT": hp.FEATURE_COUNT, "FIELD_COUNT": 39, "dim": hp.dim,
                        "global_batch": world * hp.batch_size,
-                       "parallelism": "single GPU" if world == 1 else "table row-sharded x%d (all-to-all) + dense all-reduce" % world},
+                       "parallelism": "single GPU" if world == 1 else "table row-sharded x%d (all-to-all) + dense all-reduce%s" % (
+                           world, "" if backend == "nccl" else " [REHEARSAL over %s, ranks share GPUs: not a measurement]" % backend)},
             "roofline": roofline,
             "kernel_time_ms_per_step": round(total_ms / prof_steps, 4),
             "launch": ("hip graph replay" if graphed is not None else
