@@ -327,7 +327,8 @@ int xdfm_dropout_act_bwd(const float* y, const float* dy, const float* mask_scal
  *   pooled r[B,n], w[n], bias[1], out[B].
  * Backward (g = d loss / d exFM_out [B]): d_pooled[b,n] = g[b] + g[b]*w[n] (written),
  *   dw[n] = sum_b g[b]*r[b,n], db = sum_b g[b].  part: scratch of
- *   xdfm_dense_bwd_workspace_floats(B, n, 1) floats.
+ *   xdfm_dense_bwd_workspace_floats(B, n, 1) floats.  d_pooled may be NULL (weight gradients
+ *   only), or dw, db and part together (d_pooled only).
  * ---------------------------------------------------------------------- */
 int xdfm_cin_head_fwd(const float* pooled, const float* w, const float* bias, int64_t B,
                       int32_t n, float* out, void* stream);
@@ -351,6 +352,18 @@ int xdfm_logit_loss(const float* part0, const float* part1, const float* part2,
                     const float* part3, const float* bias, const float* labels, int64_t B,
                     int64_t mean_count, int32_t classification, int32_t loss_kind, float* logit,
                     float* pred, float* g_logit, float* loss, float* scratch, void* stream);
+
+/* The training step's chain xdfm_cin_head_fwd -> xdfm_logit_loss -> d_pooled of xdfm_cin_head_bwd
+ * as ONE launch (same expressions, bit-identical results): part2 of the logit is the CIN head
+ * computed here from pooled[B,n], head_w[n], head_b[1]; writes cin_out[B], logit, pred, g_logit,
+ * d_pooled[B,n] and the mean loss.  part0 / part1 / part3 and bias as in xdfm_logit_loss.
+ *   scratch: 1025 floats; element 1024 (a block counter) must be zero before the first call and
+ *   is left zero by every call.  square_loss runs the separate kernels (it needs the mean first). */
+int xdfm_head_loss(const float* part0, const float* part1, const float* part3, const float* bias,
+                   const float* pooled, const float* head_w, const float* head_b, int32_t n,
+                   const float* labels, int64_t B, int64_t mean_count, int32_t classification,
+                   int32_t loss_kind, float* logit, float* pred, float* cin_out, float* g_logit,
+                   float* d_pooled, float* loss, float* scratch, void* stream);
 
 /* ------------------------------------------------------------------------
  * Fused evaluation: AUC (ties grouped, == sklearn.roc_auc_score) and logloss

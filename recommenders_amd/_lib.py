@@ -108,6 +108,8 @@ SIGNATURES = {
     "xdfm_cin_head_fwd": [_P, _P, _P, _I64, _I32, _P, _P],
     "xdfm_cin_head_bwd": [_P, _P, _P, _I64, _I32, _P, _P, _P, _P, _P],
     "xdfm_logit_loss": [_P, _P, _P, _P, _P, _P, _I64, _I64, _I32, _I32, _P, _P, _P, _P, _P, _P],
+    "xdfm_head_loss": [_P, _P, _P, _P, _P, _P, _P, _I32, _P, _I64, _I64, _I32, _I32, _P, _P, _P, _P, _P, _P, _P,
+                       _P],
     "xdfm_eval_workspace_bytes": [_I64, _PSZ],
     "xdfm_eval_auc_logloss": [_P, _P, _I64, _P, _P, _SZ, _P],
 }

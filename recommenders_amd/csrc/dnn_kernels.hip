@@ -462,13 +462,19 @@ extern "C" int xdfm_cin_head_fwd(const float* pooled, const float* w, const floa
 extern "C" int xdfm_cin_head_bwd(const float* pooled, const float* w, const float* g, int64_t B,
                                  int32_t n, float* d_pooled, float* dw, float* db, float* part,
                                  void* stream) {
-  XDFM_REQUIRE(pooled && w && g && d_pooled && dw && db && part, "xdfm_cin_head_bwd: null argument");
+  XDFM_REQUIRE(pooled && w && g, "xdfm_cin_head_bwd: null argument");
+  XDFM_REQUIRE(d_pooled || dw, "xdfm_cin_head_bwd: nothing to compute");
+  XDFM_REQUIRE((dw && db && part) || (!dw && !db), "xdfm_cin_head_bwd: dw, db and part come together");
   XDFM_REQUIRE(B >= 0 && n > 0, "xdfm_cin_head_bwd: bad sizes");
   hipStream_t st = (hipStream_t)stream;
-  if (B > 0) {
+  if (B > 0 && d_pooled) {
     const int64_t tot = B * n;
     XDFM_LAUNCH("cin_head_dpooled_kernel", st, cin_head_dpooled_kernel, dim3((unsigned)((tot + 255) / 256)),
                 dim3(256), 0, w, g, B, n, d_pooled);
+  }
+  if (!dw) {
+    XDFM_LAUNCH_CHECK();
+    return XDFM_OK;
   }
   // dw, db: the weight-gradient path of a [n] -> [1] identity layer whose dy is g
   return xdfm_dense_bwd(pooled, w, g /* y unused for identity */, g, B, n, 1, XDFM_ACT_IDENTITY,

@@ -297,6 +297,99 @@ __global__ __launch_bounds__(256) void loss_bwd_kernel(LossArgs a, const float* 
   }
 }
 
+// ------------------------------------------------- CIN head + loss + gradients, one launch
+// The training step's chain cin_head_fwd -> loss_fwd -> loss_bwd -> cin_head_dpooled in one
+// kernel (each link is a few microseconds of work behind a launch on the step's critical path).
+// Same expressions in the same order as those kernels: results are bit-identical.  The mean
+// is finished by whichever block arrives last, summing the per-block partials in index order.
+struct HeadArgs {
+  const float *pooled, *w, *b;
+  int n;
+  float *cin_out, *d_pooled;
+};
+
+__global__ __launch_bounds__(256) void head_loss_kernel(LossArgs a, HeadArgs h, float* __restrict__ partial,
+                                                        unsigned* __restrict__ counter,
+                                                        float* __restrict__ loss_out) {
+  __shared__ float sh[256];
+  __shared__ float sh_g[256];
+  __shared__ unsigned ticket;
+  const float invB = 1.f / (float)a.mean_count;
+  float acc = 0.f;
+  for (long long i0 = (long long)blockIdx.x * 256; i0 < a.B; i0 += (long long)gridDim.x * 256) {
+    const long long i = i0 + threadIdx.x;
+    float g = 0.f;
+    if (i < a.B) {
+      float cin = 0.f;
+      if (h.pooled) {
+        const float* __restrict__ r = h.pooled + i * h.n;
+        float base = 0.f, dot = 0.f;
+        for (int k = 0; k < h.n; ++k) {
+          base += r[k];
+          dot = fmaf(r[k], h.w[k], dot);
+        }
+        cin = base + (dot + h.b[0]);
+        h.cin_out[i] = cin;
+      }
+      float z = 0.f;
+      bool first = true;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const bool is_cin = (k == 2 && h.pooled);
+        if (a.part[k] || is_cin) {
+          float v = is_cin ? cin : a.part[k][i];
+          if (k == 0 && a.bias) v += a.bias[0];
+          z = first ? v : z + v;
+          first = false;
+        }
+      }
+      const float p = a.classification ? sigmoidf(z) : z;
+      a.logit[i] = z;
+      a.pred[i] = p;
+      const float y = a.labels[i];
+      const float dp_dz = a.classification ? p * (1.f - p) : 1.f;
+      if (a.loss_kind == XDFM_LOSS_LOG) {
+        acc += -y * logf(p + kLogEps) - (1.f - y) * logf(1.f - p + kLogEps);
+        g = (-y / (p + kLogEps) + (1.f - y) / (1.f - p + kLogEps)) * dp_dz * invB;
+      } else {  // XDFM_LOSS_CROSS_ENTROPY (square_loss needs the finished mean first: not served here)
+        acc += fmaxf(z, 0.f) - z * y + log1pf(expf(-fabsf(z)));
+        g = (sigmoidf(z) - y) * invB;
+      }
+      a.g_logit[i] = g;
+    }
+    if (h.d_pooled) {
+      sh_g[threadIdx.x] = g;
+      __syncthreads();
+      const long long left = a.B - i0;
+      const int rows = (int)(left < 256 ? left : 256);
+      float* __restrict__ dp = h.d_pooled + i0 * h.n;
+      for (int idx = threadIdx.x; idx < rows * h.n; idx += 256) {
+        const int b = idx / h.n, k = idx - b * h.n;
+        const float gb = sh_g[b];
+        dp[idx] = gb + gb * h.w[k];
+      }
+      __syncthreads();
+    }
+  }
+  acc = block_sum<float, 256>(acc, sh);
+  if (threadIdx.x == 0) {
+    partial[blockIdx.x] = acc;
+    __threadfence();
+    ticket = atomicAdd(counter, 1u);
+  }
+  __syncthreads();
+  if (ticket != gridDim.x - 1) return;
+  __threadfence();
+  const volatile float* vp = partial;
+  float s = 0.f;
+  for (int k = threadIdx.x; k < (int)gridDim.x; k += 256) s += vp[k];
+  s = block_sum<float, 256>(s, sh);
+  if (threadIdx.x == 0) {
+    if (loss_out) *loss_out = s / (float)a.mean_count;
+    *counter = 0u;  // ready for the next launch
+  }
+}
+
 // ------------------------------------------------------------------ eval
 __device__ __forceinline__ uint32_t float_key(float f) {
   uint32_t u = __float_as_uint(f);
@@ -534,6 +627,50 @@ extern "C" int xdfm_logit_loss(const float* part0, const float* part1, const flo
   if (labels && (g_logit || loss))
     XDFM_LAUNCH("loss_bwd_kernel", st, loss_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, a, scratch,
                        (int)blocks, loss);
+  XDFM_LAUNCH_CHECK();
+  return XDFM_OK;
+}
+
+extern "C" int xdfm_head_loss(const float* part0, const float* part1, const float* part3, const float* bias,
+                              const float* pooled, const float* head_w, const float* head_b, int32_t n,
+                              const float* labels, int64_t B, int64_t mean_count, int32_t classification,
+                              int32_t loss_kind, float* logit, float* pred, float* cin_out, float* g_logit,
+                              float* d_pooled, float* loss, float* scratch, void* stream) {
+  XDFM_REQUIRE(pooled && head_w && head_b && cin_out && d_pooled && n > 0, "xdfm_head_loss: null head argument");
+  XDFM_REQUIRE(labels && logit && pred && g_logit && scratch, "xdfm_head_loss: null argument");
+  XDFM_REQUIRE(B > 0, "xdfm_head_loss: empty batch");
+  XDFM_REQUIRE(mean_count == 0 || mean_count >= B, "xdfm_head_loss: mean_count must be 0 or >= B");
+  XDFM_REQUIRE(loss_kind >= XDFM_LOSS_LOG && loss_kind <= XDFM_LOSS_SQUARE, "xdfm_head_loss: unknown loss %d",
+               loss_kind);
+  XDFM_REQUIRE(!bias || part0, "xdfm_head_loss: bias belongs to part0 (the linear part)");
+  if (loss_kind == XDFM_LOSS_SQUARE) {
+    // the gradient of a root of a mean needs the finished mean: the separate kernels serve it
+    int rc = xdfm_cin_head_fwd(pooled, head_w, head_b, B, n, cin_out, stream);
+    if (rc) return rc;
+    rc = xdfm_logit_loss(part0, part1, cin_out, part3, bias, labels, B, mean_count, classification, loss_kind,
+                         logit, pred, g_logit, loss, scratch, stream);
+    if (rc) return rc;
+    return xdfm_cin_head_bwd(pooled, head_w, g_logit, B, n, d_pooled, nullptr, nullptr, nullptr, stream);
+  }
+  LossArgs a;
+  a.part[0] = part0;
+  a.part[1] = part1;
+  a.part[2] = nullptr;
+  a.part[3] = part3;
+  a.bias = bias;
+  a.labels = labels;
+  a.B = B;
+  a.mean_count = mean_count > 0 ? mean_count : B;
+  a.classification = classification;
+  a.loss_kind = loss_kind;
+  a.logit = logit;
+  a.pred = pred;
+  a.g_logit = g_logit;
+  const HeadArgs h{pooled, head_w, head_b, n, cin_out, d_pooled};
+  long long blocks = (B + 255) / 256;
+  if (blocks > 1024) blocks = 1024;
+  XDFM_LAUNCH("head_loss_kernel", (hipStream_t)stream, head_loss_kernel, dim3((unsigned)blocks), dim3(256), 0, a, h,
+              scratch, reinterpret_cast<unsigned*>(scratch + 1024), loss);
   XDFM_LAUNCH_CHECK();
   return XDFM_OK;
 }

@@ -189,10 +189,12 @@ class XDeepFMEngine(object):
         # segment tables for xdfm_dense_update (host arrays)
         self._seg = self._segment_tables()
         self.err_flag = torch.zeros((1,), dtype=torch.int32, device=dev)
-        self.reg_loss = torch.zeros((1,), dtype=f32, device=dev)
-        self.data_loss = torch.zeros((1,), dtype=f32, device=dev)
+        # [data_loss, reg_loss] side by side: one scan yields (data, data + reg) at the end of a step
+        self._loss2 = torch.zeros((2,), dtype=f32, device=dev)
+        self.data_loss = self._loss2[0:1]
+        self.reg_loss = self._loss2[1:2]
         self.stats = torch.zeros((max(len(self.dense_shapes), 1) * 260 + 520,), dtype=f32, device=dev)
-        self.loss_scratch = torch.zeros((1024,), dtype=f32, device=dev)
+        self.loss_scratch = torch.zeros((1032,), dtype=f32, device=dev)  # [1024]: xdfm_head_loss's block counter
         self._cap_B = self._cap_nnz = 0
         self.ws = {}
         self._eval_ws = None
@@ -392,6 +394,12 @@ class XDeepFMEngine(object):
             dnn_part_floats = max(dnn_part_floats, sz.value)
         buf("part", max(part_floats, 1))
         # the DNN tower runs on its own stream beside the CIN: its partial sums get their own space
+        # (the lin_b / CIN head weight gradients run there too)
+        _lib.check(self.lib.xdfm_dense_bwd_workspace_floats(B, 1, 1, ctypes.byref(sz)))
+        dnn_part_floats = max(dnn_part_floats, sz.value)
+        if hp.use_CIN_part:
+            _lib.check(self.lib.xdfm_dense_bwd_workspace_floats(B, ws["pooled"].shape[1], 1, ctypes.byref(sz)))
+            dnn_part_floats = max(dnn_part_floats, sz.value)
         buf("part_dnn", dnn_part_floats)
         buf("pieces", 2 * (nnz // 64 + 1) * (D + 1))
         buf("long_list", nnz + 2, dtype=torch.int32)
@@ -512,8 +520,13 @@ class XDeepFMEngine(object):
             side = self._branch_stream()
             with torch.cuda.stream(side):
                 self._dnn_forward(B)
+                if with_grad:
+                    ws["d_emb"][:B].zero_()  # the CIN backward accumulates into it
                 dnn_done = torch.cuda.Event()
                 dnn_done.record(side)
+        # training step with a CIN: head, logit, loss, d(loss)/d(logit) and d_pooled in one launch
+        fused_head = bool(hp.use_CIN_part and with_grad and with_loss)
+        self._head_fused = fused_head
         if hp.use_CIN_part:
             ev = self._mark("cin_fwd")
             shapes = cin_shapes(hp)
@@ -546,17 +559,33 @@ class XDeepFMEngine(object):
                     )
                 off += L - nh
                 xk = xnext
-            _lib.check(
-                lib.xdfm_cin_head_fwd(_ptr(ws["pooled"]), _ptr(self.views["cin_w_out"]),
-                                      _ptr(self.views["cin_b_out"]), B, final_len,
-                                      _ptr(ws["cin_out"]), st)
-            )
+            if not fused_head:
+                _lib.check(
+                    lib.xdfm_cin_head_fwd(_ptr(ws["pooled"]), _ptr(self.views["cin_w_out"]),
+                                          _ptr(self.views["cin_b_out"]), B, final_len,
+                                          _ptr(ws["cin_out"]), st)
+                )
             self._done(ev)
         if dnn_done is not None:
             torch.cuda.current_stream(self.device).wait_event(dnn_done)
         elif hp.use_DNN_part:
             self._dnn_forward(B)
         ev = self._mark("logit_loss")
+        if fused_head:
+            _lib.check(
+                lib.xdfm_head_loss(
+                    _ptr(ws["lin_out"]) if use_lin else None, _ptr(ws["fm_out"]) if use_fm else None,
+                    _ptr(ws["dnn_out"]) if hp.use_DNN_part else None,
+                    _ptr(self.views["lin_b"]) if use_lin else None,
+                    _ptr(ws["pooled"]), _ptr(self.views["cin_w_out"]), _ptr(self.views["cin_b_out"]),
+                    ws["pooled"].shape[1], _ptr(batch.labels), B, int(self.mean_count or 0),
+                    1 if hp.method == "classification" else 0, _LOSS[hp.loss], _ptr(ws["logit"]),
+                    _ptr(ws["pred"]), _ptr(ws["cin_out"]), _ptr(ws["g_logit"]), _ptr(ws["d_pooled"]),
+                    _ptr(self.data_loss), _ptr(self.loss_scratch), st,
+                )
+            )
+            self._done(ev)
+            return ws["pred"][:B]
         _lib.check(
             lib.xdfm_logit_loss(
                 _ptr(ws["lin_out"]) if use_lin else None, _ptr(ws["fm_out"]) if use_fm else None,
@@ -663,34 +692,51 @@ class XDeepFMEngine(object):
         d_emb = ws["d_emb"]
         gv = self.grad_views
         wrote_d_emb = False
-        if hp.use_Linear_part:
-            # d lin_b = sum_b g  -- the bias row of a [1]->[1] identity layer
-            _lib.check(
-                lib.xdfm_dense_bwd(_ptr(g), _ptr(self.views["lin_b"]), _ptr(g), _ptr(g), B, 1, 1, 0, None,
-                                   0, _ptr(ws["dummy"]), _ptr(gv["lin_b"]), _ptr(ws["part"]), st)
-            )
+        fused_head = bool(hp.use_CIN_part and getattr(self, "_head_fused", False))
+
+        def small_grads(part):
+            """lin_b and CIN head weight gradients: read g and pooled only."""
+            if hp.use_Linear_part:
+                # d lin_b = sum_b g  -- the bias row of a [1]->[1] identity layer
+                _lib.check(
+                    lib.xdfm_dense_bwd(_ptr(g), _ptr(self.views["lin_b"]), _ptr(g), _ptr(g), B, 1, 1, 0, None,
+                                       0, _ptr(ws["dummy"]), _ptr(gv["lin_b"]), _ptr(part), st)
+                )
+            if hp.use_CIN_part:
+                _lib.check(
+                    lib.xdfm_cin_head_bwd(_ptr(ws["pooled"]), _ptr(self.views["cin_w_out"]), _ptr(g), B,
+                                          ws["pooled"].shape[1], None if fused_head else _ptr(ws["d_pooled"]),
+                                          _ptr(gv["cin_w_out"]), _ptr(gv["cin_b_out"]), _ptr(part), st)
+                )
+
         dnn_done = None
         if self.overlap_dnn:
-            # fork: everything of the DNN tower but its gradient w.r.t. emb_out runs beside the CIN
+            # fork: everything of the DNN tower but its gradient w.r.t. emb_out runs beside the CIN,
+            # and so do the small weight gradients that hang off g_logit
             side = self._branch_stream()
             with torch.cuda.stream(side):
+                st = self._stream()
+                if fused_head:
+                    small_grads(ws["part_dnn"])
                 self._dnn_backward(B, None)
                 dnn_done = torch.cuda.Event()
                 dnn_done.record(side)
-        elif hp.use_DNN_part:
-            self._dnn_backward(B, (d_emb, 0))
-            wrote_d_emb = True
+            st = self._stream()
+            if not fused_head:
+                small_grads(ws["part"])
+                d_emb[:B].zero_()
+            wrote_d_emb = True  # zeroed beside the forward pass (or just above)
+        else:
+            small_grads(ws["part"])
+            if hp.use_DNN_part:
+                self._dnn_backward(B, (d_emb, 0))
+                wrote_d_emb = True
         if not wrote_d_emb:
             d_emb[:B].zero_()
         if hp.use_CIN_part:
             ev = self._mark("cin_bwd")
             shapes = cin_shapes(hp)
             final_len = ws["pooled"].shape[1]
-            _lib.check(
-                lib.xdfm_cin_head_bwd(_ptr(ws["pooled"]), _ptr(self.views["cin_w_out"]), _ptr(g), B,
-                                      final_len, _ptr(ws["d_pooled"]), _ptr(gv["cin_w_out"]),
-                                      _ptr(gv["cin_b_out"]), _ptr(ws["part"]), st)
-            )
             offs, off = [], 0
             for (H, L, nh) in shapes:
                 offs.append(off)
@@ -849,7 +895,8 @@ class XDeepFMEngine(object):
         self.forward(batch, with_loss=True, with_grad=True)
         self.backward(batch)
         self.update(batch)
-        return (self.data_loss + self.reg_loss)[0], self.data_loss[0].clone()
+        tot = torch.cumsum(self._loss2, 0)  # one launch: [data, data + reg]
+        return tot[1], tot[0]
 
     def capture_step(self, labels, dnn_idx, ids, weights):
         """Capture CSR build + train_step for batches of exactly this shape into a HIP graph
