@@ -195,14 +195,16 @@ int xdfm_opt_advance(float* opt_state, float lr, float beta1, float beta2, void*
  *   mode 1 (scatter)    : store the sums into grad_table[N,D] / grad_lin[N] (rows of untouched
  *                         ids are left as they are: the caller keeps them zero).
  *   pieces: float scratch of 2*(nnz/64 + 1)*(D + 1) elements (partial sums of the segments that
- *   cross a 64-token chunk boundary); long_list: unused, may be NULL.
- *   d_emb[B,F,D]; g_logit[B] and fm_sum[B,D] only when the FM / linear parts are on. */
+ *   cross a 64-token chunk boundary).
+ *   d_emb[B,F,D]; d_emb2: NULL, or a second [B,F,D] array added to d_emb as it is read (two
+ *   producers, e.g. the CIN and the DNN tower, then need no common accumulator);
+ *   g_logit[B] and fm_sum[B,D] only when the FM / linear parts are on. */
 int xdfm_embed_bwd(int32_t mode, float* table, float* slot_m, float* slot_v, float* lin_w,
                    float* lin_m, float* lin_v, float* grad_table, float* grad_lin, int64_t N,
                    int32_t D, int32_t F, int64_t B, const int32_t* sorted_ids,
                    const int32_t* sorted_tok, const int32_t* tok_row, const float* weights,
                    int64_t nnz, const float* d_emb, const float* g_logit, const float* fm_sum,
-                   int32_t use_fm, const xdfm_opt_args* opt, float* pieces, int32_t* long_list,
+                   int32_t use_fm, const xdfm_opt_args* opt, float* pieces, const float* d_emb2,
                    void* stream);
 /* zero the rows of grad_table / grad_lin named by sorted_ids (restores the all-zero invariant) */
 int xdfm_embed_clear_rows(float* grad_table, float* grad_lin, int32_t D,

@@ -326,7 +326,7 @@ struct BwdArgs {
   int64_t N, B, nnz;
   int D, F;
   const int32_t *sorted_ids, *sorted_tok, *tok_row;
-  const float *weights, *d_emb, *g_logit, *fm_sum;
+  const float *weights, *d_emb, *d_emb2, *g_logit, *fm_sum;
   int use_fm;
   OptDev opt;
   float* pieces;      // head[nchunks][D], tail[nchunks][D], head_lin[nchunks], tail_lin[nchunks]
@@ -436,6 +436,12 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(BwdArgs a) {
     if (on) {
       float de[VEC];
       load_vec<VEC>(a.d_emb + (int64_t)row_q * a.D + c * VEC, de);
+      if (a.d_emb2) {  // a second producer's gradient (the DNN tower's), summed on the fly
+        float de2[VEC];
+        load_vec<VEC>(a.d_emb2 + (int64_t)row_q * a.D + c * VEC, de2);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) de[k] += de2[k];
+      }
 #pragma unroll
       for (int k = 0; k < VEC; ++k) v[k] = w_q * de[k];
       if (a.use_fm) {
@@ -722,11 +728,10 @@ extern "C" int xdfm_embed_bwd(int32_t mode, float* table, float* slot_m, float* 
                               const int32_t* tok_row, const float* weights, int64_t nnz,
                               const float* d_emb, const float* g_logit, const float* fm_sum,
                               int32_t use_fm, const xdfm_opt_args* opt, float* pieces,
-                              int32_t* long_list, void* stream) {
+                              const float* d_emb2, void* stream) {
   XDFM_REQUIRE(mode == 0 || mode == 1, "xdfm_embed_bwd: mode must be 0 or 1");
   XDFM_REQUIRE(N > 0 && D > 0 && F > 0 && B >= 0 && nnz >= 0, "xdfm_embed_bwd: bad sizes");
   if (nnz == 0) return XDFM_OK;
-  (void)long_list;  // kept in the signature; the chunked scheme needs no queue
   XDFM_REQUIRE(sorted_ids && sorted_tok && tok_row && weights && d_emb && pieces,
                "xdfm_embed_bwd: null argument");
   XDFM_REQUIRE(!use_fm || (g_logit && fm_sum && table), "xdfm_embed_bwd: FM needs g_logit, fm_sum, table");
@@ -768,6 +773,7 @@ extern "C" int xdfm_embed_bwd(int32_t mode, float* table, float* slot_m, float* 
   a.tok_row = tok_row;
   a.weights = weights;
   a.d_emb = d_emb;
+  a.d_emb2 = d_emb2;
   a.g_logit = g_logit;
   a.fm_sum = fm_sum;
   a.use_fm = use_fm;

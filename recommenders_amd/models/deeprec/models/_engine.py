@@ -402,7 +402,10 @@ class XDeepFMEngine(object):
             dnn_part_floats = max(dnn_part_floats, sz.value)
         buf("part_dnn", dnn_part_floats)
         buf("pieces", 2 * (nnz // 64 + 1) * (D + 1))
-        buf("long_list", nnz + 2, dtype=torch.int32)
+        if self.overlap_dnn:
+            # the DNN tower's gradient w.r.t. emb_out, written beside the CIN backward and added to
+            # d_emb where the table gradient reads it
+            buf("d_emb_dnn", B, F * D)
         _lib.check(self.lib.xdfm_embed_plan_workspace_bytes(nnz, self.N, ctypes.byref(sz)))
         buf("plan_ws", sz.value, dtype=torch.uint8)
         self.ws = ws
@@ -637,8 +640,8 @@ class XDeepFMEngine(object):
         self._done(ev)
 
     def _dnn_backward(self, B, first_layer_dx):
-        """Backward of the DNN tower on the current stream.  first_layer_dx: None = leave the
-        gradient w.r.t. emb_out to dnn_backward_input(); else (buffer, accumulate)."""
+        """Backward of the DNN tower on the current stream.  first_layer_dx: (buffer, accumulate)
+        for the gradient w.r.t. emb_out, None to skip it."""
         hp, lib, ws, st = self.hp, self.lib, self.ws, self._stream()
         g, gv = ws["g_logit"], self.grad_views
         ev = self._mark("dnn_bwd")
@@ -671,16 +674,6 @@ class XDeepFMEngine(object):
                                    _ptr(ws["part_dnn"]), st)
             )
         self._done(ev)
-
-    def _dnn_backward_input(self, B, d_emb):
-        """d_emb += (gradient of the first DNN layer w.r.t. emb_out); input gradient only."""
-        hp, lib, ws, st = self.hp, self.lib, self.ws, self._stream()
-        _lib.check(
-            lib.xdfm_dense_bwd(_ptr(ws["emb_out"]), _ptr(self.views["dnn_w_0"]), _ptr(ws["h_0"]),
-                               _ptr(ws["d_h_0"]), B, self.F * self.D, int(hp.layer_sizes[0]),
-                               0 if self._dropout_live else _ACT[hp.activation[0]], _ptr(d_emb), 1, None, None,
-                               None, st)
-        )
 
     # ---------------------------------------------------------------- backward
     def backward(self, batch):
@@ -718,7 +711,7 @@ class XDeepFMEngine(object):
                 st = self._stream()
                 if fused_head:
                     small_grads(ws["part_dnn"])
-                self._dnn_backward(B, None)
+                self._dnn_backward(B, (ws["d_emb_dnn"], 0))
                 dnn_done = torch.cuda.Event()
                 dnn_done.record(side)
             st = self._stream()
@@ -774,9 +767,11 @@ class XDeepFMEngine(object):
                 )
             self._done(ev)
         if dnn_done is not None:
-            # join: d_h_0 is ready; the last piece of the DNN backward adds into d_emb
-            torch.cuda.current_stream(self.device).wait_event(dnn_done)
-            self._dnn_backward_input(B, d_emb)
+            torch.cuda.current_stream(self.device).wait_event(dnn_done)  # join
+
+    def d_emb2(self):
+        """Second summand of the gradient w.r.t. emb_out (None when d_emb holds all of it)."""
+        return self.ws["d_emb_dnn"] if self.overlap_dnn else None
 
     def _opt_args(self, l2=0.0, l1=0.0, clip=0.0):
         hp = self.hp
@@ -823,7 +818,7 @@ class XDeepFMEngine(object):
                 _ptr(batch.weights), batch.nnz, _ptr(ws["d_emb"]),
                 _ptr(ws["g_logit"]) if (use_lin or use_fm) else None,
                 _ptr(ws["fm_sum"]) if use_fm else None, 1 if use_fm else 0,
-                ctypes.byref(opt_sparse), _ptr(ws["pieces"]), _ptr(ws["long_list"]), st,
+                ctypes.byref(opt_sparse), _ptr(ws["pieces"]), _ptr(self.d_emb2()), st,
             )
         )
         self._done(ev)

@@ -277,7 +277,7 @@ class ShardedXDeepFMEngine(XDeepFMEngine):
                 _ptr(self._arange32(nnz)), _ptr(order32), _ptr(batch.tok_row), _ptr(batch.weights), nnz,
                 _ptr(ws["d_emb"]), _ptr(ws["g_logit"]) if (use_lin or use_fm) else None,
                 _ptr(ws["fm_sum"]) if use_fm else None, 1 if use_fm else 0, ctypes.byref(opt),
-                _ptr(ws["pieces"]), None, st,
+                _ptr(ws["pieces"]), _ptr(self.d_emb2()), st,
             )
         )
         self._done(ev)
