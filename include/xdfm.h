@@ -258,6 +258,33 @@ int xdfm_cin_bwd(const float* x0, const float* xk, const float* w, int64_t B, in
                  int32_t pool_off, float* d_xk, float* d_x0, float* d_w, float* dw_part,
                  void* stream);
 
+/* Filters packed ahead of the layer calls.  xdfm_cin_fwd / xdfm_cin_bwd re-pack their filter into
+ * matrix-core operand order on every call; a training step can instead pack the filters of all
+ * its layers in ONE launch, before they are needed, and call the *_packed variants (same
+ * results, bit for bit).  No counterpart in the reference (TF re-reads its variables).
+ *   xdfm_cin_pack_floats: sizes of a layer's images; 0 = this shape has no packed path for that
+ *     direction (use xdfm_cin_fwd / xdfm_cin_bwd).
+ *   xdfm_cin_pack: up to 8 jobs per call; fwd_image / bwd_image may be NULL (skip).  Images are
+ *     16-byte aligned device buffers, valid for batch size B and dim D until the filter changes.
+ *   xdfm_cin_bwd_packed: dw_part sized by xdfm_cin_bwd_workspace_floats as for xdfm_cin_bwd. */
+typedef struct xdfm_cin_pack_job {
+  const float* w;    /* [F*H, L] */
+  int32_t F, H, L, masked;
+  float* fwd_image;  /* xdfm_cin_pack_floats fwd_floats elements, or NULL */
+  float* bwd_image;  /* bwd_floats elements, or NULL */
+} xdfm_cin_pack_job;
+int xdfm_cin_pack_floats(int64_t B, int32_t F, int32_t H, int32_t D, int32_t L, int32_t masked,
+                         size_t* fwd_floats, size_t* bwd_floats);
+int xdfm_cin_pack(const xdfm_cin_pack_job* jobs, int32_t n_jobs, int64_t B, int32_t D, void* stream);
+int xdfm_cin_fwd_packed(const float* x0, const float* xk, const float* fwd_image, int64_t B, int32_t F,
+                        int32_t H, int32_t D, int32_t L, int32_t n_hidden, int32_t masked, float* xnext,
+                        float* pooled, int32_t pool_stride, int32_t pool_off, void* stream);
+int xdfm_cin_bwd_packed(const float* x0, const float* xk, const float* bwd_image, int64_t B, int32_t F,
+                        int32_t H, int32_t D, int32_t L, int32_t n_hidden, int32_t masked,
+                        const float* d_xnext, const float* d_pooled, int32_t pool_stride,
+                        int32_t pool_off, float* d_xk, float* d_x0, float* d_w, float* dw_part,
+                        void* stream);
+
 /* cross_activation (xDeepFM.py:242, :402): the activation between a CIN layer's product and its
  * split.  With a non-identity activation run the layer with n_hidden = L (raw curr[B,L,D] into a
  * buffer of its own, no pooled output), then

@@ -50,6 +50,20 @@ class OptArgs(ctypes.Structure):
     ]
 
 
+class CinPackJob(ctypes.Structure):
+    """struct xdfm_cin_pack_job"""
+
+    _fields_ = [
+        ("w", ctypes.c_void_p),
+        ("F", ctypes.c_int32),
+        ("H", ctypes.c_int32),
+        ("L", ctypes.c_int32),
+        ("masked", ctypes.c_int32),
+        ("fwd_image", ctypes.c_void_p),
+        ("bwd_image", ctypes.c_void_p),
+    ]
+
+
 class BatchInfo(ctypes.Structure):
     """struct xdfm_ffm_batch_info"""
 
@@ -94,6 +108,11 @@ SIGNATURES = {
     "xdfm_cin_bwd_workspace_floats": [_I64, _I32, _I32, _I32, _I32, _PSZ],
     "xdfm_cin_bwd": [_P, _P, _P, _I64, _I32, _I32, _I32, _I32, _I32, _I32, _P, _P, _I32, _I32, _P,
                      _P, _P, _P, _P],
+    "xdfm_cin_pack_floats": [_I64, _I32, _I32, _I32, _I32, _I32, _PSZ, _PSZ],
+    "xdfm_cin_pack": [_P, _I32, _I64, _I32, _P],
+    "xdfm_cin_fwd_packed": [_P, _P, _P, _I64, _I32, _I32, _I32, _I32, _I32, _I32, _P, _P, _I32, _I32, _P],
+    "xdfm_cin_bwd_packed": [_P, _P, _P, _I64, _I32, _I32, _I32, _I32, _I32, _I32, _P, _P, _I32, _I32, _P,
+                            _P, _P, _P, _P],
     "xdfm_dense_fwd": [_P, _P, _P, _I64, _I32, _I32, _I32, _P, _P],
     "xdfm_dense_bwd_workspace_floats": [_I64, _I32, _I32, _PSZ],
     "xdfm_dense_bwd": [_P, _P, _P, _P, _I64, _I32, _I32, _I32, _P, _I32, _P, _P, _P, _P],

@@ -5,6 +5,8 @@
 #include <cstddef>
 #include <cstdint>
 
+#include "../../include/xdfm.h"
+
 namespace xdfm_cin {
 
 struct CinDims {
@@ -18,8 +20,12 @@ size_t fwd_mfma_workspace_floats(int64_t B, int F, int H, int D, int L);
 int fwd_mfma(const CinDims& c, const float* x0, const float* xk, const float* w, float* xnext,
              float* pooled, int pool_stride, int pool_off, float* ws, hipStream_t st);
 size_t bwd_mfma_workspace_floats(int64_t B, int F, int H, int D, int L, int masked);
-int bwd_mfma(const CinDims& c, const float* x0, const float* xk, const float* w,
+int bwd_mfma(const CinDims& c, const float* x0, const float* xk, const float* w, const float* packed_dx,
              const float* d_xnext, const float* d_pooled, int pool_stride, int pool_off, float* d_xk,
              float* d_x0, float* d_w, float* ws, hipStream_t st);
+
+// filter images packed ahead of the layer calls (xdfm_cin_pack*)
+void pack_floats(int64_t B, int F, int H, int D, int L, int masked, size_t* fwd_floats, size_t* bwd_floats);
+int pack_all(const xdfm_cin_pack_job* jobs, int n_jobs, int64_t B, int D, hipStream_t st);
 
 }  // namespace xdfm_cin

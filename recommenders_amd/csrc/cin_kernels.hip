@@ -410,7 +410,7 @@ extern "C" int xdfm_cin_bwd(const float* x0, const float* xk, const float* w, in
     return XDFM_OK;
   }
   if (xdfm_cin::mfma_supported(B, F, H, D, L))
-    return xdfm_cin::bwd_mfma(c, x0, xk, w, d_xnext, d_pooled, pool_stride, pool_off, d_xk, d_x0, d_w,
+    return xdfm_cin::bwd_mfma(c, x0, xk, w, nullptr, d_xnext, d_pooled, pool_stride, pool_off, d_xk, d_x0, d_w,
                               dw_part, st);
   float* dc_mn = dw_part;
   float* part = dw_part + (size_t)B * D * L;
@@ -459,6 +459,61 @@ extern "C" int xdfm_cin_bwd(const float* x0, const float* xk, const float* w, in
   }
   XDFM_LAUNCH_CHECK();
   return XDFM_OK;
+}
+
+// ------------------------------------------------------------- filters packed ahead
+extern "C" int xdfm_cin_pack_floats(int64_t B, int32_t F, int32_t H, int32_t D, int32_t L, int32_t masked,
+                                    size_t* fwd_floats, size_t* bwd_floats) {
+  XDFM_REQUIRE(fwd_floats && bwd_floats && B >= 0 && F > 0 && H > 0 && D > 0 && L > 0,
+               "xdfm_cin_pack_floats: bad argument");
+  xdfm_cin::pack_floats(B, F, H, D, L, masked, fwd_floats, bwd_floats);
+  return XDFM_OK;
+}
+
+extern "C" int xdfm_cin_pack(const xdfm_cin_pack_job* jobs, int32_t n_jobs, int64_t B, int32_t D, void* stream) {
+  XDFM_REQUIRE(jobs || n_jobs == 0, "xdfm_cin_pack: null jobs");
+  XDFM_REQUIRE(B >= 0 && D > 0, "xdfm_cin_pack: bad sizes");
+  if (B == 0 || n_jobs == 0) return XDFM_OK;
+  return xdfm_cin::pack_all(jobs, n_jobs, B, D, (hipStream_t)stream);
+}
+
+extern "C" int xdfm_cin_fwd_packed(const float* x0, const float* xk, const float* fwd_image, int64_t B, int32_t F,
+                                   int32_t H, int32_t D, int32_t L, int32_t n_hidden, int32_t masked,
+                                   float* xnext, float* pooled, int32_t pool_stride, int32_t pool_off,
+                                   void* stream) {
+  int rc = check_dims("xdfm_cin_fwd_packed", B, F, H, D, L, n_hidden, masked);
+  if (rc) return rc;
+  XDFM_REQUIRE(x0 && xk && fwd_image, "xdfm_cin_fwd_packed: null input");
+  XDFM_REQUIRE(n_hidden == 0 || xnext, "xdfm_cin_fwd_packed: xnext is null");
+  XDFM_REQUIRE(n_hidden == L || pooled, "xdfm_cin_fwd_packed: pooled is null");
+  XDFM_REQUIRE(xdfm_cin::mfma_supported(B, F, H, D, L), "xdfm_cin_fwd_packed: this shape has no packed path");
+  if (B == 0) return XDFM_OK;
+  CinDims cm{B, F, H, D, L, n_hidden, masked};
+  return xdfm_cin::fwd_mfma(cm, x0, xk, nullptr, xnext, pooled, pool_stride, pool_off,
+                            const_cast<float*>(fwd_image), (hipStream_t)stream);
+}
+
+extern "C" int xdfm_cin_bwd_packed(const float* x0, const float* xk, const float* bwd_image, int64_t B, int32_t F,
+                                   int32_t H, int32_t D, int32_t L, int32_t n_hidden, int32_t masked,
+                                   const float* d_xnext, const float* d_pooled, int32_t pool_stride,
+                                   int32_t pool_off, float* d_xk, float* d_x0, float* d_w, float* dw_part,
+                                   void* stream) {
+  int rc = check_dims("xdfm_cin_bwd_packed", B, F, H, D, L, n_hidden, masked);
+  if (rc) return rc;
+  XDFM_REQUIRE(x0 && xk && bwd_image && d_x0 && d_w && dw_part, "xdfm_cin_bwd_packed: null argument");
+  XDFM_REQUIRE(n_hidden == 0 || d_xnext, "xdfm_cin_bwd_packed: d_xnext is null");
+  XDFM_REQUIRE(n_hidden == L || d_pooled, "xdfm_cin_bwd_packed: d_pooled is null");
+  XDFM_REQUIRE((xk == x0) == (d_xk == nullptr),
+               "xdfm_cin_bwd_packed: d_xk must be NULL exactly when xk == x0 (layer 0)");
+  XDFM_REQUIRE(xdfm_cin::mfma_supported(B, F, H, D, L), "xdfm_cin_bwd_packed: this shape has no packed path");
+  hipStream_t st = (hipStream_t)stream;
+  if (B == 0) {
+    XDFM_HIP(hipMemsetAsync(d_w, 0, (size_t)F * H * L * sizeof(float), st));
+    return XDFM_OK;
+  }
+  CinDims c{B, F, H, D, L, n_hidden, masked};
+  return xdfm_cin::bwd_mfma(c, x0, xk, nullptr, bwd_image, d_xnext, d_pooled, pool_stride, pool_off, d_xk, d_x0,
+                            d_w, dw_part, st);
 }
 
 // ------------------------------------------------------------------ cross_activation

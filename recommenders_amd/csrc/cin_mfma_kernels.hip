@@ -24,6 +24,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
+#include <cstring>
 
 #include "cin_common.h"
 #include "cin_stage.h"
@@ -75,9 +76,9 @@ __device__ inline int fwd2_step_desc(int s, int noq, int nks, int masked) {
 }
 
 // image wq[nq][group][lane][4 steps] followed by the step descriptors stab[nsteps_img]
-__global__ void cin_pack_fwd_kernel(CinDims c, const float* __restrict__ w, int noq, int nks,
-                                    int nsteps_img, int NQ, int swap, float* __restrict__ wq) {
-  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void pack_fwd_body(const CinDims& c, const float* __restrict__ w, int noq, int nks,
+                                              int nsteps_img, int NQ, int swap, float* __restrict__ wq,
+                                              int64_t idx) {
   const int64_t total = (int64_t)NQ * nsteps_img * 64;
   if (idx < nsteps_img)
     reinterpret_cast<int*>(wq + total)[idx] = fwd2_step_desc((int)idx, noq, nks, c.masked);
@@ -93,6 +94,11 @@ __global__ void cin_pack_fwd_kernel(CinDims c, const float* __restrict__ w, int 
   const bool ok = (desc & kFwdValid) && f < c.F && h < c.H && n < c.L && (!c.masked || h > f);
   const float v = ok ? w[(int64_t)(f * c.H + h) * c.L + n] : 0.f;
   wq[(((int64_t)nq * (nsteps_img >> 2) + (s >> 2)) * 64 + lane) * 4 + (s & 3)] = v;
+}
+
+__global__ void cin_pack_fwd_kernel(CinDims c, const float* __restrict__ w, int noq, int nks,
+                                    int nsteps_img, int NQ, int swap, float* __restrict__ wq) {
+  pack_fwd_body(c, w, noq, nks, nsteps_img, NQ, swap, wq, (int64_t)blockIdx.x * blockDim.x + threadIdx.x);
 }
 
 // xi: K-side input [B][Ki][D], xo: folded input [B][Ko][D] (xi == xo for the masked layer)
@@ -497,10 +503,9 @@ __global__ __launch_bounds__(256) void cin_bwd_dx_mfma_kernel(
 // are dead (also as x0 rows of the masked layer, which needs ft <= ht), so dXk replaces them
 // in place and the kernel needs no LDS beyond the X tiles.
 template <int S>
-__global__ void cin_pack_dx_kernel(CinDims c, const float* __restrict__ w, int nft, int nht,
-                                   int ntiles, float* __restrict__ wdx) {
+__device__ __forceinline__ void pack_dx_body(const CinDims& c, const float* __restrict__ w, int nft, int nht,
+                                             int ntiles, float* __restrict__ wdx, int64_t idx) {
   constexpr int Sp = (S + 3) & ~3;
-  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t total = (int64_t)ntiles * 64 * Sp;
   if (idx >= total) return;
   const int s = (int)(idx % Sp);
@@ -520,6 +525,46 @@ __global__ void cin_pack_dx_kernel(CinDims c, const float* __restrict__ w, int n
   const int f = 4 * ft + (i >> 2), h = 4 * ht + (i & 3), n = 4 * s + k;
   const bool ok = f < c.F && h < c.H && n < c.L && (!c.masked || h > f);
   wdx[idx] = ok ? w[(int64_t)(f * c.H + h) * c.L + n] : 0.f;
+}
+
+template <int S>
+__global__ void cin_pack_dx_kernel(CinDims c, const float* __restrict__ w, int nft, int nht,
+                                   int ntiles, float* __restrict__ wdx) {
+  pack_dx_body<S>(c, w, nft, nht, ntiles, wdx, (int64_t)blockIdx.x * blockDim.x + threadIdx.x);
+}
+
+// Filter images of several layers in one launch (xdfm_cin_pack): a step packs once, ahead of
+// the layer calls, instead of once per call on the critical path.
+struct PackJob {
+  CinDims c;
+  const float* w;
+  float* fwd;  // forward image or nullptr
+  float* dx;   // input-gradient image or nullptr
+  int noq, nks, nsteps_img, NQ, swap;
+  int nft, nht, ntiles, SS;
+  unsigned first_block, fwd_blocks, dx_blocks;
+};
+constexpr int kMaxPackJobs = 8;
+struct PackJobs {
+  PackJob j[kMaxPackJobs];
+  int n;
+};
+
+__global__ void cin_pack_all_kernel(PackJobs jobs) {
+  int k = 0;
+  while (k + 1 < jobs.n && blockIdx.x >= jobs.j[k + 1].first_block) ++k;
+  const PackJob& J = jobs.j[k];
+  const unsigned local = blockIdx.x - J.first_block;
+  if (local < J.fwd_blocks) {
+    pack_fwd_body(J.c, J.w, J.noq, J.nks, J.nsteps_img, J.NQ, J.swap, J.fwd,
+                  (int64_t)local * blockDim.x + threadIdx.x);
+  } else {
+    const int64_t idx = (int64_t)(local - J.fwd_blocks) * blockDim.x + threadIdx.x;
+    if (J.SS == 3)
+      pack_dx_body<3>(J.c, J.w, J.nft, J.nht, J.ntiles, J.dx, idx);
+    else
+      pack_dx_body<5>(J.c, J.w, J.nft, J.nht, J.ntiles, J.dx, idx);
+  }
 }
 
 struct Dx2Args {
@@ -1062,6 +1107,7 @@ size_t fwd_mfma_workspace_floats(int64_t B, int F, int H, int D, int L) {
   return (size_t)NQ * nsteps_img * 64 + nsteps_img;
 }
 
+// w == nullptr: `ws` already holds the image (xdfm_cin_pack)
 int fwd_mfma(const CinDims& c, const float* x0, const float* xk, const float* w, float* xnext,
              float* pooled, int pool_stride, int pool_off, float* ws, hipStream_t st) {
   const bool swap = fwd_swap(c.F, c.H, c.masked);
@@ -1076,8 +1122,9 @@ int fwd_mfma(const CinDims& c, const float* x0, const float* xk, const float* w,
   // groups per trip
   const int nsteps_img = (nsteps + 15) & ~15;
   const int64_t img_floats = (int64_t)NQ * nsteps_img * 64;
-  XDFM_LAUNCH("cin_pack_fwd_kernel", st, cin_pack_fwd_kernel, dim3((unsigned)((img_floats + 255) / 256)),
-              dim3(256), 0, c, w, noq, nks, nsteps_img, NQ, swap ? 1 : 0, ws);
+  if (w)
+    XDFM_LAUNCH("cin_pack_fwd_kernel", st, cin_pack_fwd_kernel, dim3((unsigned)((img_floats + 255) / 256)),
+                dim3(256), 0, c, w, noq, nks, nsteps_img, NQ, swap ? 1 : 0, ws);
   constexpr int ROWS = 256;
   XDFM_REQUIRE(c.D <= ROWS, "xdfm_cin_fwd: dim %d does not fit a row tile", c.D);
   const int SPB = ROWS / c.D;
@@ -1110,7 +1157,13 @@ size_t bwd_mfma_workspace_floats(int64_t B, int F, int H, int D, int L, int mask
   return (((size_t)B * D * L + 3) & ~(size_t)3) + wpk + (size_t)dw_splits(B * D) * ntile * 16 * L;
 }
 
-int bwd_mfma(const CinDims& c, const float* x0, const float* xk, const float* w,
+static bool dx2_applies(int F, int H, int L, bool shared_x) {
+  const int Hp = (H + 3) & ~3, Fp = (F + 3) & ~3, S = (L + 3) / 4;
+  return Fp / 4 <= 10 && S <= 5 && (size_t)(Hp + (shared_x ? 0 : Fp)) * (256 + kPad) * sizeof(float) <= kLdsLimit;
+}
+
+// w == nullptr: `packed_dx` holds the input-gradient image (xdfm_cin_pack)
+int bwd_mfma(const CinDims& c, const float* x0, const float* xk, const float* w, const float* packed_dx,
              const float* d_xnext, const float* d_pooled, int pool_stride, int pool_off, float* d_xk,
              float* d_x0, float* d_w, float* ws, hipStream_t st) {
   float* dc_mn = ws;
@@ -1141,13 +1194,15 @@ int bwd_mfma(const CinDims& c, const float* x0, const float* xk, const float* w,
 
   // ---- input gradients
   const size_t dx2_lds = (size_t)(Hp + (shared_x ? 0 : Fp)) * (256 + kPad) * sizeof(float);
+  XDFM_REQUIRE(w || (packed_dx && dx2_applies(c.F, c.H, c.L, shared_x)),
+               "xdfm_cin_bwd_packed: this shape has no packed input-gradient path");
   if (nft <= 10 && S <= 5 && dx2_lds <= kLdsLimit) {
     const int SPB = 256 / c.D;
     const int ntiles = n_tiles(nft, nht, c.masked);
     const int n_dx = (int)((c.B + SPB - 1) / SPB);
-    const Dx2Args ax{wpk, d_xk, d_x0, SPB, ntiles};
+    const Dx2Args ax{w ? wpk : packed_dx, d_xk, d_x0, SPB, ntiles};
     const int SS = S <= 3 ? 3 : 5;
-    {
+    if (w) {
       const int64_t total = (int64_t)ntiles * 64 * ((SS + 3) & ~3);
       if (SS == 3)
         XDFM_LAUNCH("cin_pack_dx_kernel<3>", st, cin_pack_dx_kernel<3>, dim3((unsigned)((total + 255) / 256)),
@@ -1258,6 +1313,62 @@ int bwd_mfma(const CinDims& c, const float* x0, const float* xk, const float* w,
     XDFM_LAUNCH("cin_dw_unpack_kernel", st, cin_dw_unpack_kernel, dim3((unsigned)((total + 31) / 32)),
                 dim3(256), 0, c, part, n_splits, d_w);
   }
+  XDFM_LAUNCH_CHECK();
+  return XDFM_OK;
+}
+
+void pack_floats(int64_t B, int F, int H, int D, int L, int masked, size_t* fwd_floats, size_t* bwd_floats) {
+  *fwd_floats = *bwd_floats = 0;
+  if (!mfma_supported(B, F, H, D, L)) return;
+  *fwd_floats = (fwd_mfma_workspace_floats(B, F, H, D, L) + 3) & ~(size_t)3;
+  // one image serves both roles of the layer's inputs: shared_x only makes the LDS need smaller
+  if (dx2_applies(F, H, L, false)) {
+    const int nft = (F + 3) / 4, nht = (H + 3) / 4, S = (L + 3) / 4;
+    *bwd_floats = (size_t)n_tiles(nft, nht, masked) * 64 * (S <= 3 ? 4 : 8);
+  }
+}
+
+int pack_all(const xdfm_cin_pack_job* jobs, int n_jobs, int64_t B, int D, hipStream_t st) {
+  XDFM_REQUIRE(n_jobs >= 0 && n_jobs <= kMaxPackJobs, "xdfm_cin_pack: at most %d jobs per call", kMaxPackJobs);
+  PackJobs pj;
+  memset(&pj, 0, sizeof(pj));
+  unsigned blocks = 0;
+  for (int k = 0; k < n_jobs; ++k) {
+    const xdfm_cin_pack_job& in = jobs[k];
+    XDFM_REQUIRE(in.w && in.F > 0 && in.H > 0 && in.L > 0, "xdfm_cin_pack: bad job %d", k);
+    size_t ff, bf;
+    pack_floats(B, in.F, in.H, D, in.L, in.masked, &ff, &bf);
+    XDFM_REQUIRE(!in.fwd_image || ff, "xdfm_cin_pack: job %d has no packed forward path", k);
+    XDFM_REQUIRE(!in.bwd_image || bf, "xdfm_cin_pack: job %d has no packed backward path", k);
+    PackJob& J = pj.j[pj.n];
+    J.c = CinDims{B, in.F, in.H, D, in.L, 0, in.masked ? 1 : 0};
+    J.w = in.w;
+    J.fwd = in.fwd_image;
+    J.dx = in.bwd_image;
+    J.first_block = blocks;
+    if (in.fwd_image) {
+      const bool swap = fwd_swap(in.F, in.H, in.masked);
+      const int Ki = swap ? in.F : in.H, Ko = swap ? in.H : in.F;
+      J.noq = ((Ko + 3) & ~3) / 4;
+      J.nks = ((Ki + 3) & ~3) / 4;
+      J.NQ = (in.L + 3) / 4;
+      J.swap = swap ? 1 : 0;
+      J.nsteps_img = (fwd2_steps(J.noq, J.nks, in.masked) + 15) & ~15;
+      J.fwd_blocks = (unsigned)(((int64_t)J.NQ * J.nsteps_img * 64 + 255) / 256);
+    }
+    if (in.bwd_image) {
+      J.nft = (in.F + 3) / 4;
+      J.nht = (in.H + 3) / 4;
+      J.ntiles = n_tiles(J.nft, J.nht, in.masked);
+      J.SS = (in.L + 3) / 4 <= 3 ? 3 : 5;
+      J.dx_blocks = (unsigned)(((int64_t)J.ntiles * 64 * ((J.SS + 3) & ~3) + 255) / 256);
+    }
+    if (J.fwd_blocks + J.dx_blocks == 0) continue;
+    blocks += J.fwd_blocks + J.dx_blocks;
+    ++pj.n;
+  }
+  if (!blocks) return XDFM_OK;
+  XDFM_LAUNCH("cin_pack_all_kernel", st, cin_pack_all_kernel, dim3(blocks), dim3(256), 0, pj);
   XDFM_LAUNCH_CHECK();
   return XDFM_OK;
 }

@@ -204,6 +204,8 @@ class XDeepFMEngine(object):
         self._dnn_stream = None
         # with both towers on, the DNN tower (small, latency/HBM-bound launches) runs on a second
         # stream beside the CIN (matrix-core bound): the two share nothing but emb_out and d_emb
+        self.prepack = os.environ.get("XDFM_CIN_PREPACK", "1") != "0"
+        self._pack_jobs = None
         self.overlap_dnn = bool(hp.use_CIN_part and hp.use_DNN_part) and os.environ.get("XDFM_OVERLAP_DNN", "1") != "0"
         self.mean_count = 0  # set by the sharded engine: global batch size of the step
         self.init_parameters(seed)
@@ -376,6 +378,15 @@ class XDeepFMEngine(object):
                 part_floats = max(part_floats, sz.value)
                 _lib.check(self.lib.xdfm_cin_fwd_workspace_floats(B, F, H, D, L, ctypes.byref(sz)))
                 part_floats = max(part_floats, sz.value)
+                # filter images packed once per step, ahead of the layer calls (where the shape
+                # has a packed path)
+                fsz, bsz = ctypes.c_size_t(), ctypes.c_size_t()
+                _lib.check(self.lib.xdfm_cin_pack_floats(B, F, H, D, L, 1 if k == 0 else 0, ctypes.byref(fsz),
+                                                         ctypes.byref(bsz)))
+                if self.prepack and fsz.value:
+                    buf("img_f_%d" % k, fsz.value)
+                if self.prepack and bsz.value:
+                    buf("img_b_%d" % k, bsz.value)
             _lib.check(self.lib.xdfm_dense_bwd_workspace_floats(B, final_len, 1, ctypes.byref(sz)))
             part_floats = max(part_floats, sz.value)
         dnn_part_floats = 1
@@ -503,6 +514,8 @@ class XDeepFMEngine(object):
         ws = self.ws
         B, F, D = batch.B, self.F, self.D
         use_lin, use_fm = bool(hp.use_Linear_part), bool(hp.use_FM_part)
+        if hp.use_CIN_part and not self.fast_d:
+            self._pack_filters(B, with_grad)
         ev = self._mark("embed_fwd")
         _lib.check(
             lib.xdfm_embed_fwd(
@@ -548,6 +561,12 @@ class XDeepFMEngine(object):
                                               _ptr(self.views["fcin_v_%d" % k]) if k > 0 else None, B, F, H,
                                               D, L, self.fast_d, out_nh, 1 if k == 0 else 0, _ptr(out_h),
                                               _ptr(ws["pooled"]), final_len, off, st)
+                    )
+                elif ("img_f_%d" % k) in ws:
+                    _lib.check(
+                        lib.xdfm_cin_fwd_packed(_ptr(x0), _ptr(xk), _ptr(ws["img_f_%d" % k]), B, F, H, D,
+                                                L, out_nh, 1 if k == 0 else 0, _ptr(out_h), _ptr(ws["pooled"]),
+                                                final_len, off, st)
                     )
                 else:
                     _lib.check(
@@ -603,6 +622,25 @@ class XDeepFMEngine(object):
         )
         self._done(ev)
         return ws["pred"][:B]
+
+    def _pack_filters(self, B, with_grad):
+        """One launch packs the filter images of every CIN layer for this step."""
+        ws = self.ws
+        shapes = cin_shapes(self.hp)
+        jobs = (_lib.CinPackJob * len(shapes))()
+        n = 0
+        for k, (H, L, nh) in enumerate(shapes):
+            f_img = ws.get("img_f_%d" % k)
+            b_img = ws.get("img_b_%d" % k) if with_grad else None
+            if f_img is None and b_img is None:
+                continue
+            jobs[n] = _lib.CinPackJob(self.views["cin_f_%d" % k].data_ptr(), self.F, H, L, 1 if k == 0 else 0,
+                                      f_img.data_ptr() if f_img is not None else None,
+                                      b_img.data_ptr() if b_img is not None else None)
+            n += 1
+        for s0 in range(0, n, 8):
+            chunk = ctypes.cast(ctypes.byref(jobs, s0 * ctypes.sizeof(_lib.CinPackJob)), ctypes.c_void_p)
+            _lib.check(self.lib.xdfm_cin_pack(chunk, min(8, n - s0), B, self.D, self._stream()))
 
     def _branch_stream(self):
         """The DNN tower's stream, made to wait for everything enqueued so far on the current one."""
@@ -676,9 +714,11 @@ class XDeepFMEngine(object):
         self._done(ev)
 
     # ---------------------------------------------------------------- backward
-    def backward(self, batch):
+    def backward(self, batch, advance=False):
         """Gradients of the data loss w.r.t. every dense parameter (into dense_grad) and
-        w.r.t. emb_out (into ws['d_emb']).  forward(with_grad=True) must have run."""
+        w.r.t. emb_out (into ws['d_emb'] [+ d_emb2()]).  forward(with_grad=True) must have run.
+        advance: also move the optimizer's step scalars on (beside the backward pass when the DNN
+        tower has its own stream); returns True when that was done."""
         hp, lib, ws, st = self.hp, self.lib, self.ws, self._stream()
         B, F, D = batch.B, self.F, self.D
         g = ws["g_logit"]
@@ -712,6 +752,8 @@ class XDeepFMEngine(object):
                 if fused_head:
                     small_grads(ws["part_dnn"])
                 self._dnn_backward(B, (ws["d_emb_dnn"], 0))
+                if advance:
+                    self._advance_step()  # nothing reads the scalars before the join
                 dnn_done = torch.cuda.Event()
                 dnn_done.record(side)
             st = self._stream()
@@ -759,6 +801,14 @@ class XDeepFMEngine(object):
                                               _ptr(ws["part"]), st)
                     )
                     continue
+                if ("img_b_%d" % k) in ws:
+                    _lib.check(
+                        lib.xdfm_cin_bwd_packed(_ptr(x0), _ptr(xk), _ptr(ws["img_b_%d" % k]), B, F, H, D, L,
+                                                up_nh, 1 if k == 0 else 0, _ptr(d_xnext), _ptr(d_pool),
+                                                final_len, offs[k], _ptr(d_xk), _ptr(d_emb),
+                                                _ptr(gv["cin_f_%d" % k]), _ptr(ws["part"]), st)
+                    )
+                    continue
                 _lib.check(
                     lib.xdfm_cin_bwd(_ptr(x0), _ptr(xk), _ptr(self.views["cin_f_%d" % k]), B, F, H, D, L,
                                      up_nh, 1 if k == 0 else 0, _ptr(d_xnext), _ptr(d_pool),
@@ -768,6 +818,8 @@ class XDeepFMEngine(object):
             self._done(ev)
         if dnn_done is not None:
             torch.cuda.current_stream(self.device).wait_event(dnn_done)  # join
+            return bool(advance)
+        return False
 
     def d_emb2(self):
         """Second summand of the gradient w.r.t. emb_out (None when d_emb holds all of it)."""
@@ -788,10 +840,12 @@ class XDeepFMEngine(object):
             _lib.check(self.lib.xdfm_opt_advance(_ptr(self.opt_state), float(self.hp.learning_rate), 0.9, 0.999,
                                                  self._stream()))
 
-    def update(self, batch):
+    def update(self, batch, advanced=False):
         """apply_gradients (base_model.py:305-322) for every variable + regular_loss
-        (base_model.py:264-272, value before the update) into self.reg_loss."""
-        self._advance_step()
+        (base_model.py:264-272, value before the update) into self.reg_loss.
+        advanced: backward(advance=True) has moved the step scalars on already."""
+        if not advanced:
+            self._advance_step()
         first = self._update_embedding(batch)
         self._update_dense(first)
 
@@ -888,8 +942,8 @@ class XDeepFMEngine(object):
         """One optimisation step; returns (total_loss, data_loss) as 0-dim device tensors."""
         self.plan_async(batch)
         self.forward(batch, with_loss=True, with_grad=True)
-        self.backward(batch)
-        self.update(batch)
+        advanced = self.backward(batch, advance=True)
+        self.update(batch, advanced)
         tot = torch.cumsum(self._loss2, 0)  # one launch: [data, data + reg]
         return tot[1], tot[0]
 

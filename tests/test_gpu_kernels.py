@@ -239,6 +239,28 @@ def test_dropout_training_matches_oracle_given_the_masks():
     close(eng.ws["logit"][:50].cpu().numpy(), logit.numpy()[:, 0], rtol=2e-4, what="eval logit")
 
 
+@pytest.mark.parametrize("name", ["all_parts", "criteo_shape", "cross_act_cin"])
+def test_filters_packed_ahead_change_no_bit(name):
+    """xdfm_cin_pack + xdfm_cin_fwd_packed / xdfm_cin_bwd_packed against the per-call packing of
+    xdfm_cin_fwd / xdfm_cin_bwd: same kernels on the same images, so equality is exact."""
+    hp = make_hp(**CONFIGS[name])
+    rng = np.random.default_rng(3)
+    b = random_batch(rng, hp, 70)
+    p32 = X.init_params(hp, seed=2)
+    outs = []
+    for prepack in (True, False):
+        eng = load_engine(hp, p32)
+        eng.prepack = prepack
+        db = upload(eng, b)
+        eng.forward(db, with_loss=True, with_grad=True)
+        eng.backward(db)
+        torch.cuda.synchronize()
+        assert any(k.startswith("img_f_") for k in eng.ws) == prepack
+        outs.append((eng.ws["logit"][:70].clone(), eng.dense_grad.clone(), eng.ws["d_emb"][:70].clone()))
+    for x, y in zip(*outs):
+        assert torch.equal(x, y)
+
+
 def test_clip_by_norm_matches_oracle():
     hp = make_hp(is_clip_norm=1, max_grad_norm=0.05, optimizer="sgd", learning_rate=0.1, FEATURE_COUNT=200,
                  embed_l2=0.01)
