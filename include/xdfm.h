@@ -221,11 +221,22 @@ int xdfm_embed_clear_rows(float* grad_table, float* grad_lin, int32_t D,
  *   g^2 and their per-block partials); n_seg <= 32 per call
  *   reg_loss (device float, may be NULL): receives the regularisation loss of these
  *   segments (value BEFORE the update), base_model.py:264-272.
+ *   accumulate_reg_loss: 0 write, 1 add, XDFM_REG_PRECOMPUTED: `stats` already holds what a
+ *   preceding xdfm_dense_reg_loss over the same, unchanged parameters left there and reg_loss is
+ *   not touched: only the update runs, one launch (clip_norm must be 0).
  * ---------------------------------------------------------------------- */
+#define XDFM_REG_PRECOMPUTED 2
 int xdfm_dense_update(float* param, const float* grad, float* slot_m, float* slot_v,
                       int32_t n_seg, const int64_t* seg_off, const float* seg_l2,
                       const float* seg_l1, const float* seg_norm_l2, const xdfm_opt_args* opt,
                       float* stats, float* reg_loss, int32_t accumulate_reg_loss, void* stream);
+/* The regularisation loss of xdfm_dense_update alone (same kernels, same value).  It depends on
+ * the parameters only, so a step may compute it beside its forward pass and then call
+ * xdfm_dense_update with reg_loss = NULL: without clipping and norm_l2 terms the update is then
+ * one launch.  stats as above (a buffer of its own when the two calls can overlap). */
+int xdfm_dense_reg_loss(const float* param, int32_t n_seg, const int64_t* seg_off, const float* seg_l2,
+                        const float* seg_l1, const float* seg_norm_l2, float* stats, float* reg_loss,
+                        int32_t accumulate_reg_loss, void* stream);
 
 /* ------------------------------------------------------------------------
  * Compressed Interaction Network, one layer.   xDeepFM.py:191-267

@@ -103,6 +103,7 @@ SIGNATURES = {
     "xdfm_opt_advance": [_P, ctypes.c_float, ctypes.c_float, ctypes.c_float, _P],
     "xdfm_dense_update": [_P, _P, _P, _P, _I32, _P, _P, _P, _P, ctypes.POINTER(OptArgs), _P, _P,
                           _I32, _P],
+    "xdfm_dense_reg_loss": [_P, _I32, _P, _P, _P, _P, _P, _P, _I32, _P],
     "xdfm_cin_fwd_workspace_floats": [_I64, _I32, _I32, _I32, _I32, _PSZ],
     "xdfm_cin_fwd": [_P, _P, _P, _I64, _I32, _I32, _I32, _I32, _I32, _I32, _P, _P, _I32, _I32, _P, _P],
     "xdfm_cin_bwd_workspace_floats": [_I64, _I32, _I32, _I32, _I32, _PSZ],

@@ -308,15 +308,17 @@ struct HeadArgs {
   float *cin_out, *d_pooled;
 };
 
-__global__ __launch_bounds__(256) void head_loss_kernel(LossArgs a, HeadArgs h, float* __restrict__ partial,
+constexpr int kHeadThreads = 64;  // one wave per block: many short blocks, cheap barriers
+__global__ __launch_bounds__(kHeadThreads) void head_loss_kernel(LossArgs a, HeadArgs h, float* __restrict__ partial,
                                                         unsigned* __restrict__ counter,
                                                         float* __restrict__ loss_out) {
-  __shared__ float sh[256];
-  __shared__ float sh_g[256];
+  __shared__ float sh[kHeadThreads];
+  __shared__ float sh_g[kHeadThreads];
   __shared__ unsigned ticket;
   const float invB = 1.f / (float)a.mean_count;
   float acc = 0.f;
-  for (long long i0 = (long long)blockIdx.x * 256; i0 < a.B; i0 += (long long)gridDim.x * 256) {
+  for (long long i0 = (long long)blockIdx.x * kHeadThreads; i0 < a.B;
+       i0 += (long long)gridDim.x * kHeadThreads) {
     const long long i = i0 + threadIdx.x;
     float g = 0.f;
     if (i < a.B) {
@@ -361,9 +363,9 @@ __global__ __launch_bounds__(256) void head_loss_kernel(LossArgs a, HeadArgs h, 
       sh_g[threadIdx.x] = g;
       __syncthreads();
       const long long left = a.B - i0;
-      const int rows = (int)(left < 256 ? left : 256);
+      const int rows = (int)(left < kHeadThreads ? left : kHeadThreads);
       float* __restrict__ dp = h.d_pooled + i0 * h.n;
-      for (int idx = threadIdx.x; idx < rows * h.n; idx += 256) {
+      for (int idx = threadIdx.x; idx < rows * h.n; idx += kHeadThreads) {
         const int b = idx / h.n, k = idx - b * h.n;
         const float gb = sh_g[b];
         dp[idx] = gb + gb * h.w[k];
@@ -371,7 +373,7 @@ __global__ __launch_bounds__(256) void head_loss_kernel(LossArgs a, HeadArgs h, 
       __syncthreads();
     }
   }
-  acc = block_sum<float, 256>(acc, sh);
+  acc = block_sum<float, kHeadThreads>(acc, sh);
   if (threadIdx.x == 0) {
     partial[blockIdx.x] = acc;
     __threadfence();
@@ -382,8 +384,8 @@ __global__ __launch_bounds__(256) void head_loss_kernel(LossArgs a, HeadArgs h, 
   __threadfence();
   const volatile float* vp = partial;
   float s = 0.f;
-  for (int k = threadIdx.x; k < (int)gridDim.x; k += 256) s += vp[k];
-  s = block_sum<float, 256>(s, sh);
+  for (int k = threadIdx.x; k < (int)gridDim.x; k += kHeadThreads) s += vp[k];
+  s = block_sum<float, kHeadThreads>(s, sh);
   if (threadIdx.x == 0) {
     if (loss_out) *loss_out = s / (float)a.mean_count;
     *counter = 0u;  // ready for the next launch
@@ -533,6 +535,9 @@ extern "C" int xdfm_dense_update(float* param, const float* grad, float* slot_m,
   SegTable tab;
   memset(&tab, 0, sizeof(tab));
   tab.n = n_seg;
+  const bool precomputed = accumulate_reg_loss == XDFM_REG_PRECOMPUTED;
+  XDFM_REQUIRE(!precomputed || opt->clip_norm == 0.f,
+               "xdfm_dense_update: clipping needs the gradient statistics, which cannot be precomputed");
   bool need_stats = (reg_loss != nullptr) || opt->clip_norm > 0.f;
   for (int s = 0; s <= n_seg; ++s) {
     tab.off[s] = seg_off[s];
@@ -563,7 +568,7 @@ extern "C" int xdfm_dense_update(float* param, const float* grad, float* slot_m,
     return XDFM_OK;
   }
   float* partial = stats + (size_t)n_seg * 4;
-  if (need_stats) {
+  if (need_stats && !precomputed) {
     XDFM_LAUNCH("dense_stats_kernel", st, dense_stats_kernel, dim3(kStatBlocks, n_seg), dim3(256), 0, tab, param, grad,
                        stats, 0, partial);
     XDFM_LAUNCH("dense_stats_final_kernel", st, dense_stats_final_kernel, dim3(1), dim3(1024), 0, tab, partial, 0,
@@ -579,6 +584,38 @@ extern "C" int xdfm_dense_update(float* param, const float* grad, float* slot_m,
   if (blocks > 4096) blocks = 4096;
   XDFM_LAUNCH("dense_update_kernel", st, dense_update_kernel, dim3((unsigned)blocks), dim3(256), 0, tab, o, param, grad,
                      slot_m, slot_v, stats);
+  XDFM_LAUNCH_CHECK();
+  return XDFM_OK;
+}
+
+extern "C" int xdfm_dense_reg_loss(const float* param, int32_t n_seg, const int64_t* seg_off, const float* seg_l2,
+                                   const float* seg_l1, const float* seg_norm_l2, float* stats, float* reg_loss,
+                                   int32_t accumulate_reg_loss, void* stream) {
+  XDFM_REQUIRE(param && seg_off && stats && reg_loss, "xdfm_dense_reg_loss: null argument");
+  XDFM_REQUIRE(n_seg > 0 && n_seg <= kMaxSeg, "xdfm_dense_reg_loss: n_seg %d outside [1,%d]", n_seg, kMaxSeg);
+  XDFM_REQUIRE(seg_off[0] == 0, "xdfm_dense_reg_loss: seg_off[0] must be 0");
+  SegTable tab;
+  memset(&tab, 0, sizeof(tab));
+  tab.n = n_seg;
+  for (int s = 0; s <= n_seg; ++s) {
+    tab.off[s] = seg_off[s];
+    XDFM_REQUIRE(s == 0 || seg_off[s] >= seg_off[s - 1], "xdfm_dense_reg_loss: seg_off not ascending");
+  }
+  for (int s = 0; s < n_seg; ++s) {
+    tab.l2[s] = seg_l2 ? seg_l2[s] : 0.f;
+    tab.l1[s] = seg_l1 ? seg_l1[s] : 0.f;
+    tab.nl2[s] = seg_norm_l2 ? seg_norm_l2[s] : 0.f;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  if (tab.off[n_seg] == 0) {
+    if (!accumulate_reg_loss) XDFM_HIP(hipMemsetAsync(reg_loss, 0, sizeof(float), st));
+    return XDFM_OK;
+  }
+  float* partial = stats + (size_t)n_seg * 4;
+  XDFM_LAUNCH("dense_stats_kernel", st, dense_stats_kernel, dim3(kStatBlocks, n_seg), dim3(256), 0, tab, param, nullptr,
+              stats, 0, partial);
+  XDFM_LAUNCH("dense_stats_final_kernel", st, dense_stats_final_kernel, dim3(1), dim3(1024), 0, tab, partial, 0, stats,
+              reg_loss, accumulate_reg_loss);
   XDFM_LAUNCH_CHECK();
   return XDFM_OK;
 }
@@ -667,9 +704,10 @@ extern "C" int xdfm_head_loss(const float* part0, const float* part1, const floa
   a.pred = pred;
   a.g_logit = g_logit;
   const HeadArgs h{pooled, head_w, head_b, n, cin_out, d_pooled};
-  long long blocks = (B + 255) / 256;
+  long long blocks = (B + kHeadThreads - 1) / kHeadThreads;
   if (blocks > 1024) blocks = 1024;
-  XDFM_LAUNCH("head_loss_kernel", (hipStream_t)stream, head_loss_kernel, dim3((unsigned)blocks), dim3(256), 0, a, h,
+  XDFM_LAUNCH("head_loss_kernel", (hipStream_t)stream, head_loss_kernel, dim3((unsigned)blocks), dim3(kHeadThreads), 0,
+              a, h,
               scratch, reinterpret_cast<unsigned*>(scratch + 1024), loss);
   XDFM_LAUNCH_CHECK();
   return XDFM_OK;

@@ -204,9 +204,12 @@ class XDeepFMEngine(object):
         self._dnn_stream = None
         # with both towers on, the DNN tower (small, latency/HBM-bound launches) runs on a second
         # stream beside the CIN (matrix-core bound): the two share nothing but emb_out and d_emb
+        # regularisation loss (a function of the parameters alone) beside the forward pass
+        self.early_reg = (self.overlap_dnn_wanted(hp) and embedding_update == "sparse_rows" and not hp.is_clip_norm
+                          and 0 < len(self.dense_shapes) <= 32)
         self.prepack = os.environ.get("XDFM_CIN_PREPACK", "1") != "0"
         self._pack_jobs = None
-        self.overlap_dnn = bool(hp.use_CIN_part and hp.use_DNN_part) and os.environ.get("XDFM_OVERLAP_DNN", "1") != "0"
+        self.overlap_dnn = self.overlap_dnn_wanted(hp)
         self.mean_count = 0  # set by the sharded engine: global batch size of the step
         self.init_parameters(seed)
 
@@ -293,6 +296,21 @@ class XDeepFMEngine(object):
             self.b1p = np.float32(sd.get("b1p", 0.9 ** self.step))
             self.b2p = np.float32(sd.get("b2p", 0.999 ** self.step))
             self.opt_state.copy_(torch.tensor([float(self.b1p), float(self.b2p), 0.0, float(self.step)]))
+
+    @staticmethod
+    def overlap_dnn_wanted(hp):
+        return bool(hp.use_CIN_part and hp.use_DNN_part) and os.environ.get("XDFM_OVERLAP_DNN", "1") != "0"
+
+    def _reg_loss_early(self):
+        seg, n_seg = self._seg, len(self.dense_shapes)
+        _lib.check(
+            self.lib.xdfm_dense_reg_loss(
+                _ptr(self.dense), n_seg, seg["off"].ctypes.data_as(ctypes.c_void_p),
+                seg["l2"].ctypes.data_as(ctypes.c_void_p), seg["l1"].ctypes.data_as(ctypes.c_void_p),
+                seg["nl2"].ctypes.data_as(ctypes.c_void_p), _ptr(self.stats), _ptr(self.reg_loss), 0,
+                self._stream(),
+            )
+        )
 
     def _segment_tables(self):
         hp = self.hp
@@ -538,6 +556,8 @@ class XDeepFMEngine(object):
                 self._dnn_forward(B)
                 if with_grad:
                     ws["d_emb"][:B].zero_()  # the CIN backward accumulates into it
+                    if self.early_reg:
+                        self._reg_loss_early()
                 dnn_done = torch.cuda.Event()
                 dnn_done.record(side)
         # training step with a CIN: head, logit, loss, d(loss)/d(logit) and d_pooled in one launch
@@ -930,7 +950,8 @@ class XDeepFMEngine(object):
                         np.ascontiguousarray(seg["l2"][s0:s1]).ctypes.data_as(ctypes.c_void_p),
                         np.ascontiguousarray(seg["l1"][s0:s1]).ctypes.data_as(ctypes.c_void_p),
                         np.ascontiguousarray(seg["nl2"][s0:s1]).ctypes.data_as(ctypes.c_void_p),
-                        ctypes.byref(opt), _ptr(self.stats), _ptr(self.reg_loss), 0 if first else 1, st,
+                        ctypes.byref(opt), _ptr(self.stats), _ptr(self.reg_loss),
+                        2 if self.early_reg else (0 if first else 1), st,
                     )
                 )
                 first = False
