@@ -256,6 +256,9 @@ def main():
         _lib.check(_lib.lib.xdfm_prof_enable(1))
         if hasattr(eng, "graph_local"):
             eng.graph_local = False
+        # per-kernel durations are taken with every kernel alone on the device: the side-stream
+        # placement of the last filter gradient (beside the table update) is switched off here
+        eng.split_dw = False
         for i in range(prof_steps):
             eager_step(args.warmup + args.steps + i)
         fence()

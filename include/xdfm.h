@@ -277,7 +277,12 @@ int xdfm_cin_bwd(const float* x0, const float* xk, const float* w, int64_t B, in
  *     direction (use xdfm_cin_fwd / xdfm_cin_bwd).
  *   xdfm_cin_pack: up to 8 jobs per call; fwd_image / bwd_image may be NULL (skip).  Images are
  *     16-byte aligned device buffers, valid for batch size B and dim D until the filter changes.
- *   xdfm_cin_bwd_packed: dw_part sized by xdfm_cin_bwd_workspace_floats as for xdfm_cin_bwd. */
+ *   xdfm_cin_bwd_packed: dw_part sized by xdfm_cin_bwd_workspace_floats as for xdfm_cin_bwd.
+ *     phases: XDFM_CIN_BWD_DX (d_xk, d_x0), XDFM_CIN_BWD_DW (d_w) or both.  The two read the same
+ *     inputs and share no output, so a caller may run them on different streams (the filter
+ *     gradient beside whatever consumes d_x0 next). */
+#define XDFM_CIN_BWD_DX 1
+#define XDFM_CIN_BWD_DW 2
 typedef struct xdfm_cin_pack_job {
   const float* w;    /* [F*H, L] */
   int32_t F, H, L, masked;
@@ -294,7 +299,7 @@ int xdfm_cin_bwd_packed(const float* x0, const float* xk, const float* bwd_image
                         int32_t H, int32_t D, int32_t L, int32_t n_hidden, int32_t masked,
                         const float* d_xnext, const float* d_pooled, int32_t pool_stride,
                         int32_t pool_off, float* d_xk, float* d_x0, float* d_w, float* dw_part,
-                        void* stream);
+                        int32_t phases, void* stream);
 
 /* cross_activation (xDeepFM.py:242, :402): the activation between a CIN layer's product and its
  * split.  With a non-identity activation run the layer with n_hidden = L (raw curr[B,L,D] into a

@@ -411,7 +411,7 @@ extern "C" int xdfm_cin_bwd(const float* x0, const float* xk, const float* w, in
   }
   if (xdfm_cin::mfma_supported(B, F, H, D, L))
     return xdfm_cin::bwd_mfma(c, x0, xk, w, nullptr, d_xnext, d_pooled, pool_stride, pool_off, d_xk, d_x0, d_w,
-                              dw_part, st);
+                              dw_part, 3, st);
   float* dc_mn = dw_part;
   float* part = dw_part + (size_t)B * D * L;
   {
@@ -497,9 +497,10 @@ extern "C" int xdfm_cin_bwd_packed(const float* x0, const float* xk, const float
                                    int32_t H, int32_t D, int32_t L, int32_t n_hidden, int32_t masked,
                                    const float* d_xnext, const float* d_pooled, int32_t pool_stride,
                                    int32_t pool_off, float* d_xk, float* d_x0, float* d_w, float* dw_part,
-                                   void* stream) {
+                                   int32_t phases, void* stream) {
   int rc = check_dims("xdfm_cin_bwd_packed", B, F, H, D, L, n_hidden, masked);
   if (rc) return rc;
+  XDFM_REQUIRE(phases >= 1 && phases <= 3, "xdfm_cin_bwd_packed: phases must be 1, 2 or 3");
   XDFM_REQUIRE(x0 && xk && bwd_image && d_x0 && d_w && dw_part, "xdfm_cin_bwd_packed: null argument");
   XDFM_REQUIRE(n_hidden == 0 || d_xnext, "xdfm_cin_bwd_packed: d_xnext is null");
   XDFM_REQUIRE(n_hidden == L || d_pooled, "xdfm_cin_bwd_packed: d_pooled is null");
@@ -508,12 +509,12 @@ extern "C" int xdfm_cin_bwd_packed(const float* x0, const float* xk, const float
   XDFM_REQUIRE(xdfm_cin::mfma_supported(B, F, H, D, L), "xdfm_cin_bwd_packed: this shape has no packed path");
   hipStream_t st = (hipStream_t)stream;
   if (B == 0) {
-    XDFM_HIP(hipMemsetAsync(d_w, 0, (size_t)F * H * L * sizeof(float), st));
+    if (phases & XDFM_CIN_BWD_DW) XDFM_HIP(hipMemsetAsync(d_w, 0, (size_t)F * H * L * sizeof(float), st));
     return XDFM_OK;
   }
   CinDims c{B, F, H, D, L, n_hidden, masked};
   return xdfm_cin::bwd_mfma(c, x0, xk, nullptr, bwd_image, d_xnext, d_pooled, pool_stride, pool_off, d_xk, d_x0,
-                            d_w, dw_part, st);
+                            d_w, dw_part, phases, st);
 }
 
 // ------------------------------------------------------------------ cross_activation

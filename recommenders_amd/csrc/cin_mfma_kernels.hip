@@ -1165,7 +1165,7 @@ static bool dx2_applies(int F, int H, int L, bool shared_x) {
 // w == nullptr: `packed_dx` holds the input-gradient image (xdfm_cin_pack)
 int bwd_mfma(const CinDims& c, const float* x0, const float* xk, const float* w, const float* packed_dx,
              const float* d_xnext, const float* d_pooled, int pool_stride, int pool_off, float* d_xk,
-             float* d_x0, float* d_w, float* ws, hipStream_t st) {
+             float* d_x0, float* d_w, float* ws, int phases, hipStream_t st) {
   float* dc_mn = ws;
   float* wpk = ws + (((size_t)c.B * c.D * c.L + 3) & ~(size_t)3);  // 16-byte aligned: staged as float4
   const size_t wpk_floats = (size_t)((c.F + 3) / 4) * 4 * ((c.H + 3) & ~3) * (4 * smax_for((c.L + 3) / 4) + 1);
@@ -1196,7 +1196,10 @@ int bwd_mfma(const CinDims& c, const float* x0, const float* xk, const float* w,
   const size_t dx2_lds = (size_t)(Hp + (shared_x ? 0 : Fp)) * (256 + kPad) * sizeof(float);
   XDFM_REQUIRE(w || (packed_dx && dx2_applies(c.F, c.H, c.L, shared_x)),
                "xdfm_cin_bwd_packed: this shape has no packed input-gradient path");
-  if (nft <= 10 && S <= 5 && dx2_lds <= kLdsLimit) {
+  XDFM_REQUIRE(phases == 3 || !w, "xdfm_cin_bwd: the phases split needs the packed path");
+  if (!(phases & 1)) {
+    // filter gradient only
+  } else if (nft <= 10 && S <= 5 && dx2_lds <= kLdsLimit) {
     const int SPB = 256 / c.D;
     const int ntiles = n_tiles(nft, nht, c.masked);
     const int n_dx = (int)((c.B + SPB - 1) / SPB);
@@ -1281,6 +1284,10 @@ int bwd_mfma(const CinDims& c, const float* x0, const float* xk, const float* w,
 #undef BY_S
 #undef CALL_S
 #undef CALL_P
+  }
+  if (!(phases & 2)) {
+    XDFM_LAUNCH_CHECK();
+    return XDFM_OK;
   }
   // ---- filter gradient
   {

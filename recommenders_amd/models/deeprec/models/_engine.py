@@ -208,6 +208,8 @@ class XDeepFMEngine(object):
         self.early_reg = (self.overlap_dnn_wanted(hp) and embedding_update == "sparse_rows" and not hp.is_clip_norm
                           and 0 < len(self.dense_shapes) <= 32)
         self.prepack = os.environ.get("XDFM_CIN_PREPACK", "1") != "0"
+        self.split_dw = os.environ.get("XDFM_SPLIT_DW", "1") != "0"
+        self._late_event = None
         self._pack_jobs = None
         self.overlap_dnn = self.overlap_dnn_wanted(hp)
         self.mean_count = 0  # set by the sharded engine: global batch size of the step
@@ -822,12 +824,28 @@ class XDeepFMEngine(object):
                     )
                     continue
                 if ("img_b_%d" % k) in ws:
-                    _lib.check(
-                        lib.xdfm_cin_bwd_packed(_ptr(x0), _ptr(xk), _ptr(ws["img_b_%d" % k]), B, F, H, D, L,
-                                                up_nh, 1 if k == 0 else 0, _ptr(d_xnext), _ptr(d_pool),
-                                                final_len, offs[k], _ptr(d_xk), _ptr(d_emb),
-                                                _ptr(gv["cin_f_%d" % k]), _ptr(ws["part"]), st)
-                    )
+                    def layer_bwd(phases, stream):
+                        _lib.check(
+                            lib.xdfm_cin_bwd_packed(_ptr(x0), _ptr(xk), _ptr(ws["img_b_%d" % k]), B, F, H, D, L,
+                                                    up_nh, 1 if k == 0 else 0, _ptr(d_xnext), _ptr(d_pool),
+                                                    final_len, offs[k], _ptr(d_xk), _ptr(d_emb),
+                                                    _ptr(gv["cin_f_%d" % k]), _ptr(ws["part"]), phases, stream)
+                        )
+
+                    if k == 0 and dnn_done is not None and self.split_dw:
+                        # the last layer's filter gradient (matrix-core bound) leaves the critical
+                        # path: it runs on the side stream beside the table gradient / update
+                        # (latency bound), which only needs d_emb
+                        layer_bwd(1, st)
+                        dx_done = torch.cuda.Event()
+                        dx_done.record(torch.cuda.current_stream(self.device))
+                        side.wait_event(dx_done)
+                        with torch.cuda.stream(side):
+                            layer_bwd(2, self._stream())
+                            self._late_event = torch.cuda.Event()
+                            self._late_event.record(side)
+                    else:
+                        layer_bwd(3, st)
                     continue
                 _lib.check(
                     lib.xdfm_cin_bwd(_ptr(x0), _ptr(xk), _ptr(self.views["cin_f_%d" % k]), B, F, H, D, L,
@@ -840,6 +858,13 @@ class XDeepFMEngine(object):
             torch.cuda.current_stream(self.device).wait_event(dnn_done)  # join
             return bool(advance)
         return False
+
+    def join_late(self):
+        """Make the current stream wait for the filter gradient that backward() left running on
+        the side stream (dense_grad is complete only after this)."""
+        if self._late_event is not None:
+            torch.cuda.current_stream(self.device).wait_event(self._late_event)
+            self._late_event = None
 
     def d_emb2(self):
         """Second summand of the gradient w.r.t. emb_out (None when d_emb holds all of it)."""
@@ -929,6 +954,7 @@ class XDeepFMEngine(object):
 
     def _update_dense(self, first=True):
         """Optimizer step of the dense (replicated) parameters from self.dense_grad."""
+        self.join_late()
         hp, lib, st = self.hp, self.lib, self._stream()
         clip = float(hp.max_grad_norm) if hp.is_clip_norm else 0.0
         ev_upd = self._mark("dense_update")

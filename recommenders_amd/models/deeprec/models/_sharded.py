@@ -369,6 +369,7 @@ class ShardedXDeepFMEngine(XDeepFMEngine):
             self.backward(batch)
             self._advance_step()
             self._update_embedding(batch)
+        self.join_late()
         if self.world > 1:
             ev = self._mark("dense_allreduce")
             self.exchange.all_reduce(self.dense_grad)
@@ -463,6 +464,7 @@ class _LocalGraph(object):
         eng.forward(self.batch, with_loss=True, with_grad=True)
         eng.backward(self.batch)
         eng._token_grads(self.batch, self.order32, self.send_g, self.send_gl)
+        eng.join_late()  # every fork is joined before a capture ends
 
     def load(self, batch):
         """Copy the per-batch arrays (and the partition order) into the graph's inputs."""
