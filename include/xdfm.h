@@ -367,6 +367,28 @@ int xdfm_dropout_act_bwd(const float* y, const float* dy, const float* mask_scal
                          int32_t act, float* dz, void* stream);
 
 /* ------------------------------------------------------------------------
+ * Batch normalisation (hparams.enable_BN): tf.compat.v1.layers.batch_normalization(momentum 0.95,
+ * epsilon 1e-4, training = is_train_stage) after a CIN layer's product (xDeepFM.py:234-240,
+ * :394-400) and after a DNN layer's xw_plus_b (xDeepFM.py:497-503).
+ *   x, y: [B, C, I] with the channel in the middle: I = 1 for the DNN ([B, n]), I = dim for the CIN
+ *   (curr lives as [B, L, dim] here).  gamma[C], beta[C]; moving_mean[C], moving_var[C].
+ *   training != 0: batch moments (biased variance), the moving statistics are moved by
+ *   v -= (v - batch) * (1 - momentum); else the moving statistics normalise.
+ *   stats[2C] receives (mean, 1/sqrt(var + eps)) as used: the backward needs it.
+ *   y = act((x - mean) * inv * gamma + beta), act = XDFM_ACT_* (identity when something else,
+ *   e.g. dropout, sits between the normalisation and the activation).  y may alias x only when
+ *   no backward pass follows (the backward needs x).
+ * Backward (training statistics): g = dy * act'(y); dgamma[C] = sum g*xhat, dbeta[C] = sum g,
+ *   dx = gamma*inv*(g - dbeta/n - xhat*dgamma/n), n = B*I.  dx may alias dy.
+ * ---------------------------------------------------------------------- */
+int xdfm_bn_fwd(const float* x, int64_t B, int32_t C, int32_t I, const float* gamma, const float* beta,
+                float* moving_mean, float* moving_var, float momentum, float eps, int32_t training,
+                int32_t act, float* stats, float* y, void* stream);
+int xdfm_bn_bwd(const float* x, const float* y, const float* dy, int64_t B, int32_t C, int32_t I,
+                const float* gamma, const float* stats, int32_t act, float* dx, float* dgamma,
+                float* dbeta, void* stream);
+
+/* ------------------------------------------------------------------------
  * CIN output head with the residual connection (res=True):
  *   exFM_out[b] = sum_n r[b,n] + (sum_n r[b,n]*w[n] + bias)        xDeepFM.py:269-293
  *   pooled r[B,n], w[n], bias[1], out[B].

@@ -52,6 +52,11 @@ def param_shapes(hp):
                     shapes["fcin_v_%d" % k] = (H, hp.fast_CIN_d * L)
             else:
                 shapes["cin_f_%d" % k] = (H * hp.FIELD_COUNT, L)  # :202-206 ([1, H*F, L] squeezed)
+            if hp.enable_BN is True:  # tf.layers.batch_normalization variables (:235-240, :395-400)
+                for part in ("g", "o"):  # gamma, beta (offset): trainable
+                    shapes["bn_cin_%s_%d" % (part, k)] = (L,)
+                for part in ("mm", "mv"):  # moving mean / variance: not trainable
+                    shapes["bnstat_cin_%s_%d" % (part, k)] = (L,)
         shapes["cin_w_out"] = (cin_final_len(hp), 1)  # :279-281
         shapes["cin_b_out"] = (1,)  # :282-287
     if hp.use_DNN_part:
@@ -59,6 +64,11 @@ def param_shapes(hp):
         for k, size in enumerate(hp.layer_sizes):
             shapes["dnn_w_%d" % k] = (last, size)  # :474-478
             shapes["dnn_b_%d" % k] = (size,)  # :479-484
+            if hp.enable_BN is True:  # :498-503
+                for part in ("g", "o"):
+                    shapes["bn_dnn_%s_%d" % (part, k)] = (size,)
+                for part in ("mm", "mv"):
+                    shapes["bnstat_dnn_%s_%d" % (part, k)] = (size,)
             last = size
         shapes["dnn_w_out"] = (last, 1)  # :514-516
         shapes["dnn_b_out"] = (1,)  # :517-522
@@ -71,7 +81,8 @@ def param_groups(hp):
     names = list(param_shapes(hp))
     embed = ["embedding"]
     cross = [n for n in names if n.startswith(("cin_f_", "fcin_"))]  # also :336, :364-365
-    layer = [n for n in names if n not in embed and n not in cross]
+    # batch-norm variables are created by tf.layers, never appended to a params list: no regulariser
+    layer = [n for n in names if n not in embed and n not in cross and not n.startswith("bn")]
     return embed, layer, cross
 
 
@@ -82,7 +93,10 @@ def init_params(hp, seed=0, dtype=torch.float32):
     gen = torch.Generator().manual_seed(seed)
     params = {}
     for name, shape in param_shapes(hp).items():
-        if name.endswith("_b") or "_b_" in name:
+        if name.startswith("bn"):  # gamma = 1, beta = 0, moving mean = 0, moving variance = 1
+            one = name.startswith(("bn_cin_g_", "bn_dnn_g_", "bnstat_cin_mv_", "bnstat_dnn_mv_"))
+            t = torch.ones(shape, dtype=torch.float64) if one else torch.zeros(shape, dtype=torch.float64)
+        elif name.endswith("_b") or "_b_" in name:
             t = torch.zeros(shape, dtype=torch.float64)
         else:
             t = _init_tensor(hp, shape, gen)
@@ -184,7 +198,30 @@ def _activate(x, name):
     raise ValueError("this activations not defined {0}".format(name))
 
 
-def forward(params, batch, hp, embedding_rows=None, dropout_masks=None):
+BN_MOMENTUM, BN_EPS = 0.95, 0.0001  # the constants at every call site (xDeepFM.py:237-238, :397-398, :500-501)
+
+
+def _batch_norm(x, params, where, k, training, moving_out):
+    """tf.compat.v1.layers.batch_normalization over the last axis, non-fused path (inputs of rank
+    2 and 3): batch moments with the biased variance in training, the moving statistics
+    otherwise; training records the moved statistics (the UPDATE_OPS of base_model.py:62-64,
+    run with the train op at :381-382) in moving_out."""
+    gamma, beta = params["bn_%s_g_%d" % (where, k)], params["bn_%s_o_%d" % (where, k)]
+    mm, mv = params["bnstat_%s_mm_%d" % (where, k)], params["bnstat_%s_mv_%d" % (where, k)]
+    if training:
+        red = tuple(range(x.dim() - 1))
+        mean = x.mean(red)
+        var = ((x - mean) ** 2).mean(red)
+        if moving_out is not None:
+            with torch.no_grad():
+                moving_out["bnstat_%s_mm_%d" % (where, k)] = mm - (mm - mean) * (1 - BN_MOMENTUM)
+                moving_out["bnstat_%s_mv_%d" % (where, k)] = mv - (mv - var) * (1 - BN_MOMENTUM)
+    else:
+        mean, var = mm, mv
+    return (x - mean) / torch.sqrt(var + BN_EPS) * gamma + beta
+
+
+def forward(params, batch, hp, embedding_rows=None, dropout_masks=None, training=False, moving_out=None):
     """Logit [B,1] of XDeepFMModel._build_graph (xDeepFM.py:24-71).
 
     batch: dict with the iterator's arrays (labels, dnn_feat_*, fm_feat_*) as numpy.
@@ -253,8 +290,8 @@ def forward(params, batch, hp, embedding_rows=None, dropout_masks=None):
                     mask = torch.triu(torch.ones(F, F, dtype=dt), diagonal=1).reshape(1, 1, F * F)
                     z = z * mask * 2
                 curr = torch.matmul(z, params["cin_f_%d" % k])  # conv1d width 1 (:220-222) [B,D,L]
-            if hp.enable_BN is True:
-                raise NotImplementedError("batch norm (xDeepFM.py:234-240, :394-400) is not restated yet")
+            if hp.enable_BN is True:  # :234-240 / :394-400, on [B,D,L]: channels = L
+                curr = _batch_norm(curr, params, "cin", k, training, moving_out)
             curr = _activate(curr, hp.cross_activation)  # :242 / :402
             curr = curr.permute(0, 2, 1)  # [B,L,D]  (:244; the fast branch splits axis 2 of [B,D,L], :412-414)
             if k != n_layers - 1:
@@ -274,8 +311,8 @@ def forward(params, batch, hp, embedding_rows=None, dropout_masks=None):
         h = embed_out
         for k in range(len(hp.layer_sizes)):
             h = h @ params["dnn_w_%d" % k] + params["dnn_b_%d" % k]
-            if hp.enable_BN is True:
-                raise NotImplementedError("batch norm (xDeepFM.py:497-503) is not restated yet")
+            if hp.enable_BN is True:  # :497-503
+                h = _batch_norm(h, params, "dnn", k, training, moving_out)
             if hp.user_dropout and dropout_masks is not None:
                 # _active_layer (base_model.py:335-336): tf.nn.dropout on the pre-activation.  TF's
                 # random stream is not reproducible: the caller supplies m / keep per layer
@@ -421,6 +458,7 @@ def train_step(params, st, batch, hp, mode="dense_exact", dropout_masks=None):
 
     sparse = mode == "sparse_rows"
     leaves = {}
+    moving = {}  # batch-norm moving statistics after this step
     if sparse:
         ids_all = torch.as_tensor(np.asarray(batch["dnn_feat_values"]).copy())
         uniq = torch.unique(ids_all)  # sorted
@@ -437,15 +475,19 @@ def train_step(params, st, batch, hp, mode="dense_exact", dropout_masks=None):
             leaves["lin_w"] = lin_sub
             work["lin_rows"] = lin_sub
         for n, p in params.items():
-            if n not in ("embedding", "lin_w"):
+            if n not in ("embedding", "lin_w") and not n.startswith("bnstat_"):
                 leaves[n] = p.clone().requires_grad_(True)
                 work[n] = leaves[n]
-        logit, aux = forward(work, batch, hp, embedding_rows=(sub, remap), dropout_masks=dropout_masks)
+        logit, aux = forward(work, batch, hp, embedding_rows=(sub, remap), dropout_masks=dropout_masks,
+                             training=True, moving_out=moving)
         reg_params = {n: leaves[n] for n in leaves if n not in ("embedding", "lin_w")}
     else:
+        work = dict(params)
         for n, p in params.items():
-            leaves[n] = p.clone().requires_grad_(True)
-        logit, aux = forward(leaves, batch, hp, dropout_masks=dropout_masks)
+            if not n.startswith("bnstat_"):
+                leaves[n] = p.clone().requires_grad_(True)
+                work[n] = leaves[n]
+        logit, aux = forward(work, batch, hp, dropout_masks=dropout_masks, training=True, moving_out=moving)
         reg_params = leaves
 
     pred = pred_from_logit(logit, hp)
@@ -469,6 +511,8 @@ def train_step(params, st, batch, hp, mode="dense_exact", dropout_masks=None):
                 _apply(n, params[n], g, st, hp, rows=uniq)
             else:
                 _apply(n, params[n], g, st, hp)
+    for n, t in moving.items():
+        params[n].copy_(t)
     return float(loss.detach()), float(dl.detach()), grads, aux
 
 
@@ -476,6 +520,8 @@ def _regular_loss_subset(params, hp):
     """regular_loss over the dense parameters only (sparse_rows mode)."""
     total = 0
     for n, p in params.items():
+        if n.startswith("bn"):
+            continue
         if n.startswith(("cin_f_", "fcin_")):
             total = total + hp.cross_l1 * p.abs().sum() + hp.cross_l2 * torch.sqrt((p**2).sum())
         else:

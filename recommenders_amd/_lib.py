@@ -114,6 +114,8 @@ SIGNATURES = {
     "xdfm_cin_fwd_packed": [_P, _P, _P, _I64, _I32, _I32, _I32, _I32, _I32, _I32, _P, _P, _I32, _I32, _P],
     "xdfm_cin_bwd_packed": [_P, _P, _P, _I64, _I32, _I32, _I32, _I32, _I32, _I32, _P, _P, _I32, _I32, _P,
                             _P, _P, _P, _I32, _P],
+    "xdfm_bn_fwd": [_P, _I64, _I32, _I32, _P, _P, _P, _P, ctypes.c_float, ctypes.c_float, _I32, _I32, _P, _P, _P],
+    "xdfm_bn_bwd": [_P, _P, _P, _I64, _I32, _I32, _P, _P, _I32, _P, _P, _P, _P],
     "xdfm_dense_fwd": [_P, _P, _P, _I64, _I32, _I32, _I32, _P, _P],
     "xdfm_dense_bwd_workspace_floats": [_I64, _I32, _I32, _PSZ],
     "xdfm_dense_bwd": [_P, _P, _P, _P, _I64, _I32, _I32, _I32, _P, _I32, _P, _P, _P, _P],

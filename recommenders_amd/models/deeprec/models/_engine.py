@@ -51,6 +51,24 @@ def cin_shapes(hp):
     return out
 
 
+BN_MOMENTUM, BN_EPS = 0.95, 0.0001  # xDeepFM.py:237-238, :397-398, :500-501
+
+
+def bn_state_shapes(hp):
+    """Moving mean / variance of every batch-norm layer (not trainable), named like the oracle."""
+    shapes = {}
+    if hp.enable_BN is True:
+        if hp.use_CIN_part:
+            for k, (_, L, _) in enumerate(cin_shapes(hp)):
+                shapes["bnstat_cin_mm_%d" % k] = (L,)
+                shapes["bnstat_cin_mv_%d" % k] = (L,)
+        if hp.use_DNN_part:
+            for k, size in enumerate(hp.layer_sizes):
+                shapes["bnstat_dnn_mm_%d" % k] = (int(size),)
+                shapes["bnstat_dnn_mv_%d" % k] = (int(size),)
+    return shapes
+
+
 def dense_param_shapes(hp):
     """Ordered name -> shape of every dense (non table-sized) variable of the graph."""
     shapes = {}
@@ -64,6 +82,9 @@ def dense_param_shapes(hp):
                     shapes["fcin_v_%d" % k] = (H, int(hp.fast_CIN_d) * L)
             else:
                 shapes["cin_f_%d" % k] = (H * hp.FIELD_COUNT, L)
+            if hp.enable_BN is True:  # gamma, beta of tf.layers.batch_normalization (xDeepFM.py:235-240)
+                shapes["bn_cin_g_%d" % k] = (L,)
+                shapes["bn_cin_o_%d" % k] = (L,)
         shapes["cin_w_out"] = (sum(L - nh for (_, L, nh) in cin_shapes(hp)), 1)
         shapes["cin_b_out"] = (1,)
     if hp.use_DNN_part:
@@ -71,6 +92,9 @@ def dense_param_shapes(hp):
         for k, size in enumerate(hp.layer_sizes):
             shapes["dnn_w_%d" % k] = (last, int(size))
             shapes["dnn_b_%d" % k] = (int(size),)
+            if hp.enable_BN is True:  # xDeepFM.py:498-503
+                shapes["bn_dnn_g_%d" % k] = (int(size),)
+                shapes["bn_dnn_o_%d" % k] = (int(size),)
             last = int(size)
         shapes["dnn_w_out"] = (last, 1)
         shapes["dnn_b_out"] = (1,)
@@ -101,8 +125,8 @@ class XDeepFMEngine(object):
         self.N = int(hp.FEATURE_COUNT) if table_rows is None else int(table_rows)
         self.F, self.D = int(hp.FIELD_COUNT), int(hp.dim)
         self.fast_d = int(hp.fast_CIN_d) if hp.fast_CIN_d > 0 else 0
-        if hp.enable_BN is True:
-            raise NotImplementedError("enable_BN (xDeepFM.py:234-240, :497-503) is not built yet")
+        self.use_bn = hp.enable_BN is True
+        self._training = False  # batch statistics (train) or moving statistics (eval / infer)
         # dropout of the DNN layers (base_model.py:335-336): keep = 1 - hparams.dropout[k] in training
         self.use_dropout = bool(hp.user_dropout and hp.use_DNN_part)
         if self.use_dropout and len(hp.dropout) < len(hp.layer_sizes):
@@ -110,12 +134,16 @@ class XDeepFMEngine(object):
         self.dropout_seed = 0x5DEECE66D ^ (0 if seed is None else int(seed))
         self._dropout_live = False  # set by a training forward pass, read by the backward pass
         self.cross_act = 0
+        self.cross_path = False
         if hp.use_CIN_part:
             if hp.cross_activation == "softmax":
                 raise NotImplementedError("cross_activation softmax is not built yet")
             if hp.cross_activation not in _ACT:
                 raise ValueError("this activations not defined {0}".format(hp.cross_activation))
             self.cross_act = _ACT[hp.cross_activation]
+        # activation and / or batch norm between a CIN layer's product and its split: the layer
+        # kernels then write raw curr for every channel and elementwise kernels do the rest
+        self.cross_path = bool(self.cross_act or (self.use_bn and hp.use_CIN_part))
         if hp.loss not in _LOSS:
             raise ValueError("this loss not defined {0}".format(hp.loss))
         if hp.method not in ("classification", "regression"):
@@ -162,6 +190,8 @@ class XDeepFMEngine(object):
         for i, (name, shape) in enumerate(self.dense_shapes.items()):
             self.views[name] = self.dense[offs[i] : offs[i + 1]].view(shape)
             self.grad_views[name] = self.dense_grad[offs[i] : offs[i + 1]].view(shape)
+        self.bn_state = {name: torch.zeros(shape, dtype=f32, device=dev)
+                         for name, shape in bn_state_shapes(hp).items()}
         # ---- optimizer slots
         need_m = self.opt_kind != 0
         need_v = self.opt_kind in (1, 4, 5)  # Adam v, Adadelta accum_update, FTRL linear
@@ -248,10 +278,14 @@ class XDeepFMEngine(object):
         if self.lin_w is not None:
             draw(self.lin_w, (self.N, 1))
         for name, shape in self.dense_shapes.items():
-            if name.endswith("_b") or "_b_" in name:
+            if name.startswith("bn_"):
+                self.views[name].fill_(1.0 if "_g_" in name else 0.0)  # gamma = 1, beta = 0
+            elif name.endswith("_b") or "_b_" in name:
                 self.views[name].zero_()
             else:
                 draw(self.views[name], shape)
+        for name, t in self.bn_state.items():
+            t.fill_(1.0 if "_mv_" in name else 0.0)  # moving mean = 0, moving variance = 1
 
     def state_dict(self):
         if self.opt_kind == 1:  # the device copy is authoritative (graph replays do not run Python)
@@ -262,6 +296,7 @@ class XDeepFMEngine(object):
             sd["lin_w"] = self.lin_w.view(-1, 1)
         for name in self.dense_shapes:
             sd[name] = self.views[name]
+        sd.update(self.bn_state)
         for key, t in (("slot/table_m", self.table_m), ("slot/table_v", self.table_v),
                        ("slot/lin_m", self.lin_m), ("slot/lin_v", self.lin_v),
                        ("slot/dense_m", self.dense_m), ("slot/dense_v", self.dense_v)):
@@ -276,7 +311,8 @@ class XDeepFMEngine(object):
             src = torch.as_tensor(np.asarray(src) if not torch.is_tensor(src) else src)
             dst.copy_(src.to(torch.float32).reshape(dst.shape))
 
-        names = ["embedding"] + (["lin_w"] if self.lin_w is not None else []) + list(self.dense_shapes)
+        names = (["embedding"] + (["lin_w"] if self.lin_w is not None else []) + list(self.dense_shapes)
+                 + list(self.bn_state))
         for name in names:
             if name not in sd:
                 if strict:
@@ -286,6 +322,8 @@ class XDeepFMEngine(object):
                 put(self.table, sd[name])
             elif name == "lin_w":
                 put(self.lin_w, sd[name])
+            elif name in self.bn_state:
+                put(self.bn_state[name], sd[name])
             else:
                 put(self.views[name], sd[name])
         for key, t in (("slot/table_m", self.table_m), ("slot/table_v", self.table_v),
@@ -321,6 +359,8 @@ class XDeepFMEngine(object):
         l1 = np.zeros(max(n, 1), dtype=np.float32)
         nl2 = np.zeros(max(n, 1), dtype=np.float32)
         for i, name in enumerate(self.dense_shapes):
+            if name.startswith("bn_"):  # tf.layers variables: in no params list, no regulariser
+                continue
             if name.startswith(("cin_f_", "fcin_")):  # cross_params (base_model.py:158-166)
                 l1[i] = hp.cross_l1
                 nl2[i] = hp.cross_l2
@@ -383,10 +423,14 @@ class XDeepFMEngine(object):
                 if nh > 0:
                     buf("hid_%d" % k, B, nh * D)
                     buf("d_hid_%d" % k, B, nh * D)
-                if self.cross_act:
-                    # a non-identity cross_activation: raw / activated curr of every channel is kept
+                if self.cross_path:
+                    # a non-identity cross_activation / batch norm: raw / activated curr of every
+                    # channel is kept
                     buf("cur_%d" % k, B, L * D)
-            if self.cross_act:
+                    if self.use_bn:
+                        buf("cbn_%d" % k, B, L * D)
+                        buf("bn_stats_cin_%d" % k, 2 * L)
+            if self.cross_path:
                 buf("d_cur", B, max(L for (_, L, _) in shapes) * D)
             for k, (H, L, nh) in enumerate(shapes):
                 if self.fast_d:
@@ -415,6 +459,9 @@ class XDeepFMEngine(object):
             for k, size in enumerate(hp.layer_sizes):
                 buf("h_%d" % k, B, int(size))
                 buf("d_h_%d" % k, B, int(size))
+                if self.use_bn:
+                    buf("z_%d" % k, B, int(size))
+                    buf("bn_stats_dnn_%d" % k, 2 * int(size))
                 if self.use_dropout:
                     buf("drop_%d" % k, B, int(size))
                 _lib.check(self.lib.xdfm_dense_bwd_workspace_floats(B, last, int(size), ctypes.byref(sz)))
@@ -530,6 +577,7 @@ class XDeepFMEngine(object):
         hp, lib, ws, st = self.hp, self.lib, None, self._stream()
         # layer_keeps = keep_prob_train only under train() (base_model.py:377); eval / infer feed ones
         self._dropout_live = self.use_dropout and with_grad
+        self._training = bool(with_grad)  # is_train_stage (base_model.py:378, :401, :415)
         self._ensure_ws(batch.B, batch.nnz)
         ws = self.ws
         B, F, D = batch.B, self.F, self.D
@@ -576,7 +624,7 @@ class XDeepFMEngine(object):
                 xnext = ws["hid_%d" % k] if nh > 0 else None
                 # with a cross_activation the layer writes raw curr for all L channels; the
                 # activation kernel then produces the hidden / pooled split
-                out_h, out_nh = (ws["cur_%d" % k], L) if self.cross_act else (xnext, nh)
+                out_h, out_nh = (ws["cur_%d" % k], L) if self.cross_path else (xnext, nh)
                 if self.fast_d:
                     _lib.check(
                         lib.xdfm_fast_cin_fwd(_ptr(x0), _ptr(xk), _ptr(self.views["fcin_w_%d" % k]),
@@ -596,9 +644,13 @@ class XDeepFMEngine(object):
                                          L, out_nh, 1 if k == 0 else 0, _ptr(out_h), _ptr(ws["pooled"]),
                                          final_len, off, _ptr(ws["part"]), st)
                     )
-                if self.cross_act:
+                if self.cross_path:
+                    act_in = ws["cur_%d" % k]
+                    if self.use_bn:
+                        act_in = ws["cbn_%d" % k]
+                        self._bn_fwd(ws["cur_%d" % k], act_in, "cin", k, B, L, D, 0)
                     _lib.check(
-                        lib.xdfm_cin_act_fwd(_ptr(ws["cur_%d" % k]), B, L, D, nh, self.cross_act, _ptr(xnext),
+                        lib.xdfm_cin_act_fwd(_ptr(act_in), B, L, D, nh, self.cross_act, _ptr(xnext),
                                              _ptr(ws["pooled"]), final_len, off, st)
                     )
                 off += L - nh
@@ -645,6 +697,26 @@ class XDeepFMEngine(object):
         self._done(ev)
         return ws["pred"][:B]
 
+    def _bn_fwd(self, x, y, where, k, B, C, inner, act):
+        _lib.check(
+            self.lib.xdfm_bn_fwd(_ptr(x), B, C, inner, _ptr(self.views["bn_%s_g_%d" % (where, k)]),
+                                 _ptr(self.views["bn_%s_o_%d" % (where, k)]),
+                                 _ptr(self.bn_state["bnstat_%s_mm_%d" % (where, k)]),
+                                 _ptr(self.bn_state["bnstat_%s_mv_%d" % (where, k)]), BN_MOMENTUM, BN_EPS,
+                                 1 if self._training else 0, act, _ptr(self.ws["bn_stats_%s_%d" % (where, k)]),
+                                 _ptr(y), self._stream())
+        )
+
+    def _bn_bwd(self, x, y, dy, where, k, B, C, inner, act):
+        """dy <- gradient w.r.t. the batch norm's input (in place); gamma / beta gradients."""
+        _lib.check(
+            self.lib.xdfm_bn_bwd(_ptr(x), _ptr(y), _ptr(dy), B, C, inner,
+                                 _ptr(self.views["bn_%s_g_%d" % (where, k)]),
+                                 _ptr(self.ws["bn_stats_%s_%d" % (where, k)]), act, _ptr(dy),
+                                 _ptr(self.grad_views["bn_%s_g_%d" % (where, k)]),
+                                 _ptr(self.grad_views["bn_%s_o_%d" % (where, k)]), self._stream())
+        )
+
     def _pack_filters(self, B, with_grad):
         """One launch packs the filter images of every CIN layer for this step."""
         ws = self.ws
@@ -683,8 +755,12 @@ class XDeepFMEngine(object):
             _lib.check(
                 lib.xdfm_dense_fwd(_ptr(x), _ptr(self.views["dnn_w_%d" % k]),
                                    _ptr(self.views["dnn_b_%d" % k]), B, K, int(size),
-                                   0 if self._dropout_live else act, _ptr(ws["h_%d" % k]), st)
+                                   0 if (self._dropout_live or self.use_bn) else act,
+                                   _ptr(ws["z_%d" % k] if self.use_bn else ws["h_%d" % k]), st)
             )
+            if self.use_bn:  # xw_plus_b -> batch norm -> (dropout ->) activation
+                self._bn_fwd(ws["z_%d" % k], ws["h_%d" % k], "dnn", k, B, int(size), 1,
+                             0 if self._dropout_live else act)
             if self._dropout_live:
                 _lib.check(
                     lib.xdfm_dropout_act_fwd(_ptr(ws["h_%d" % k]), _ptr(ws["drop_%d" % k]), B, int(size),
@@ -726,6 +802,9 @@ class XDeepFMEngine(object):
                     lib.xdfm_dropout_act_bwd(_ptr(acts[k + 1]), _ptr(d_acts[k + 1]), _ptr(ws["drop_%d" % k]), B,
                                              sizes[k + 1], act, _ptr(d_acts[k + 1]), st)
                 )
+                act = 0
+            if self.use_bn:
+                self._bn_bwd(ws["z_%d" % k], acts[k + 1], d_acts[k + 1], "dnn", k, B, sizes[k + 1], 1, act)
                 act = 0
             _lib.check(
                 lib.xdfm_dense_bwd(_ptr(acts[k]), _ptr(self.views["dnn_w_%d" % k]), _ptr(acts[k + 1]),
@@ -805,12 +884,15 @@ class XDeepFMEngine(object):
                 d_xnext = ws["d_hid_%d" % k] if nh > 0 else None
                 d_xk = None if k == 0 else ws["d_hid_%d" % (k - 1)]
                 d_pool, up_nh = ws["d_pooled"], nh
-                if self.cross_act:
+                if self.cross_path:
                     _lib.check(
-                        lib.xdfm_cin_act_bwd(_ptr(ws["cur_%d" % k]), _ptr(d_xnext), _ptr(ws["d_pooled"]),
+                        lib.xdfm_cin_act_bwd(_ptr(ws["cbn_%d" % k] if self.use_bn else ws["cur_%d" % k]),
+                                             _ptr(d_xnext), _ptr(ws["d_pooled"]),
                                              final_len, offs[k], B, L, D, nh, self.cross_act,
                                              _ptr(ws["d_cur"]), st)
                     )
+                    if self.use_bn:
+                        self._bn_bwd(ws["cur_%d" % k], ws["cbn_%d" % k], ws["d_cur"], "cin", k, B, L, D, 0)
                     d_xnext, d_pool, up_nh = ws["d_cur"], None, L
                 if self.fast_d:
                     _lib.check(

@@ -152,6 +152,8 @@ class ShardedXDeepFMEngine(XDeepFMEngine):
         self.world, self.rank = self.exchange.world, self.exchange.rank
         if hp.loss == "square_loss":
             raise ValueError("square_loss (a root of a mean) cannot be split over ranks")
+        if hp.enable_BN is True:
+            raise NotImplementedError("batch statistics over a batch split between ranks are not built")
         self.global_rows = int(hp.FEATURE_COUNT)
         rows = local_rows(self.global_rows, self.rank, self.world)
         XDeepFMEngine.__init__(self, hp, device=device, seed=None if seed is None else seed + 7919 * self.rank,

@@ -261,6 +261,106 @@ def test_filters_packed_ahead_change_no_bit(name):
         assert torch.equal(x, y)
 
 
+@pytest.mark.parametrize("inner", [1, 8])
+def test_batch_norm_kernels_match_torch(inner):
+    """xdfm_bn_fwd / xdfm_bn_bwd against torch's batch_norm in float64 (training statistics, moving
+    averages with momentum 0.95 and the biased variance, inference with the moving statistics)."""
+    import torch.nn.functional as Fn
+
+    B, C = 333, 12
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(B, C, inner, generator=g) * 2 + 0.5
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g)
+    mm, mv = torch.randn(C, generator=g), torch.rand(C, generator=g) + 0.5
+    dy = torch.randn(B, C, inner, generator=g)
+    lib = _lib.lib
+    dev = "cuda"
+    xd, gd, bd, mmd, mvd, dyd = (t.to(dev).contiguous() for t in (x, gamma, beta, mm.clone(), mv.clone(), dy))
+    stats = torch.zeros(2 * C, device=dev)
+    y = torch.empty_like(xd)
+    _lib.check(lib.xdfm_bn_fwd(_ptr(xd), B, C, inner, _ptr(gd), _ptr(bd), _ptr(mmd), _ptr(mvd), 0.95, 1e-4, 1, 3,
+                               _ptr(stats), _ptr(y), None))
+    dx, dg, db = torch.empty_like(xd), torch.empty(C, device=dev), torch.empty(C, device=dev)
+    _lib.check(lib.xdfm_bn_bwd(_ptr(xd), _ptr(y), _ptr(dyd), B, C, inner, _ptr(gd), _ptr(stats), 3, _ptr(dx),
+                               _ptr(dg), _ptr(db), None))
+    torch.cuda.synchronize()
+    x64 = x.double().requires_grad_(True)
+    g64, b64 = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    rm, rv = mm.double().clone(), mv.double().clone()
+    ref = torch.tanh(Fn.batch_norm(x64, None, None, g64, b64, True, 0.0, 1e-4))  # act 3 = XDFM_ACT_TANH
+    ref.backward(dy.double())
+    mean = x.double().mean((0, 2))
+    var = x.double().var((0, 2), unbiased=False)
+    rm -= (rm - mean) * 0.05
+    rv -= (rv - var) * 0.05
+    close(y.cpu().numpy(), ref.detach().numpy(), what="bn y")
+    close(dx.cpu().numpy(), x64.grad.numpy(), rtol=5e-5, what="bn dx")
+    close(dg.cpu().numpy(), g64.grad.numpy(), rtol=5e-5, what="bn dgamma")
+    close(db.cpu().numpy(), b64.grad.numpy(), rtol=5e-5, what="bn dbeta")
+    close(mmd.cpu().numpy(), rm.numpy(), what="moving mean")
+    close(mvd.cpu().numpy(), rv.numpy(), what="moving variance")
+    # inference: the (just moved) moving statistics, which stay as they are
+    keep = mmd.clone()
+    _lib.check(lib.xdfm_bn_fwd(_ptr(xd), B, C, inner, _ptr(gd), _ptr(bd), _ptr(mmd), _ptr(mvd), 0.95, 1e-4, 0, 0,
+                               _ptr(stats), _ptr(y), None))
+    torch.cuda.synchronize()
+    ref = Fn.batch_norm(x.double(), rm, rv, gamma.double(), beta.double(), False, 0.0, 1e-4)
+    close(y.cpu().numpy(), ref.numpy(), what="bn inference")
+    assert torch.equal(keep, mmd)
+
+
+@pytest.mark.parametrize("variant", ["plain", "fast_cin", "cross_act_dropout"])
+def test_batch_norm_training_matches_oracle(variant):
+    """enable_BN (xDeepFM.py:234-240, :394-400, :497-503): three steps on batch statistics, the
+    moving statistics, then scoring on the moving statistics.  Parity unpinned (the oracle
+    restates tf.layers.batch_normalization from its documented non-fused behaviour)."""
+    # cross_entropy_loss: normalised activations drive the logits to +-10, where log_loss's
+    # log(1 - p + eps) (base_model.py:251-257) loses three digits in fp32 on either side
+    kw = dict(enable_BN=True, optimizer="adam", learning_rate=0.01, FEATURE_COUNT=300, layer_l2=0.01,
+              cross_l2=0.01, loss="cross_entropy_loss")
+    if variant == "fast_cin":
+        kw["fast_CIN_d"] = 2
+    if variant == "cross_act_dropout":
+        kw.update(cross_activation="tanh", user_dropout=True, dropout=[0.2, 0.3])
+    hp = make_hp(**kw)
+    rng = np.random.default_rng(15)
+    p32 = X.init_params(hp, seed=6)
+    for k in p32:
+        if k.startswith("bn_"):
+            p32[k] = p32[k] + 0.1 * torch.randn(p32[k].shape, generator=torch.Generator().manual_seed(1))
+    eng = load_engine(hp, p32)
+    p64 = {k: v.double() for k, v in p32.items()}
+    st = X.new_opt_state(p64, hp)
+    n_layers = len(hp.layer_sizes)
+    for step in range(3):
+        B = 128 if step != 1 else 77
+        b = random_batch(rng, hp, B)
+        loss, dloss = eng.train_step(upload(eng, b))
+        masks = None
+        if hp.user_dropout:
+            masks = [eng.ws["drop_%d" % k][:B].cpu().numpy().astype(np.float64) for k in range(n_layers)]
+        o_loss, o_dl, _, _ = X.train_step(p64, st, b, hp, dropout_masks=masks)
+        close(float(dloss), o_dl, rtol=2e-5, what="data loss step %d" % step)
+        close(float(loss), o_loss, rtol=2e-5, what="total loss step %d" % step)
+    sd = eng.state_dict()
+    for k, v in p64.items():
+        if (k.startswith("dnn_b_") and k != "dnn_b_out") or k.startswith("bnstat_dnn_mm_"):
+            # a bias in front of a batch norm has a zero gradient: Adam turns its rounding noise
+            # (1e-17 here, 1e-9 there) into +-lr steps that the normalisation removes again (the
+            # moving mean of that layer's input follows the bias)
+            continue
+        close(sd[k].cpu().numpy().reshape(v.shape), v.numpy(), rtol=5e-4, what="param " + k)
+    # scoring on the moving statistics, from the engine's own state (the noise-walked biases are
+    # not normalised away here: the moving mean follows them at 5% per step only)
+    b = random_batch(rng, hp, 50)
+    eng.forward(upload(eng, b), with_loss=False, with_grad=False)
+    own = {k: sd[k].detach().cpu().double().reshape(v.shape) for k, v in p64.items()}
+    logit, _ = X.forward(own, b, hp)
+    close(eng.ws["logit"][:50].cpu().numpy(), logit.numpy()[:, 0], what="eval logit")
+    after = eng.state_dict()
+    assert all(torch.equal(after[k], sd[k]) for k in after if k.startswith("bnstat_"))  # scoring moves nothing
+
+
 def test_clip_by_norm_matches_oracle():
     hp = make_hp(is_clip_norm=1, max_grad_norm=0.05, optimizer="sgd", learning_rate=0.1, FEATURE_COUNT=200,
                  embed_l2=0.01)
