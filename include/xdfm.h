@@ -388,6 +388,14 @@ int xdfm_bn_bwd(const float* x, const float* y, const float* dy, int64_t B, int3
                 const float* gamma, const float* stats, int32_t act, float* dx, float* dgamma,
                 float* dbeta, void* stream);
 
+/* softmax activation (`_activate`, base_model.py:343-344: tf.nn.softmax over the last axis), the
+ * one activation the fused forms above do not carry: run the layer with the identity and then
+ *   y[b,:,i] = softmax(x[b,:,i])            x, y: [B, C, I] as for xdfm_bn_fwd; y may alias x
+ *   dx = y * (dy - sum_c y*dy)              dx may alias dy */
+int xdfm_softmax_fwd(const float* x, int64_t B, int32_t C, int32_t I, float* y, void* stream);
+int xdfm_softmax_bwd(const float* y, const float* dy, int64_t B, int32_t C, int32_t I, float* dx,
+                     void* stream);
+
 /* ------------------------------------------------------------------------
  * CIN output head with the residual connection (res=True):
  *   exFM_out[b] = sum_n r[b,n] + (sum_n r[b,n]*w[n] + bias)        xDeepFM.py:269-293

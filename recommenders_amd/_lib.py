@@ -115,6 +115,8 @@ SIGNATURES = {
     "xdfm_cin_bwd_packed": [_P, _P, _P, _I64, _I32, _I32, _I32, _I32, _I32, _I32, _P, _P, _I32, _I32, _P,
                             _P, _P, _P, _I32, _P],
     "xdfm_bn_fwd": [_P, _I64, _I32, _I32, _P, _P, _P, _P, ctypes.c_float, ctypes.c_float, _I32, _I32, _P, _P, _P],
+    "xdfm_softmax_fwd": [_P, _I64, _I32, _I32, _P, _P],
+    "xdfm_softmax_bwd": [_P, _P, _I64, _I32, _I32, _P, _P],
     "xdfm_bn_bwd": [_P, _P, _P, _I64, _I32, _I32, _P, _P, _I32, _P, _P, _P, _P],
     "xdfm_dense_fwd": [_P, _P, _P, _I64, _I32, _I32, _I32, _P, _P],
     "xdfm_dense_bwd_workspace_floats": [_I64, _I32, _I32, _PSZ],

@@ -168,3 +168,60 @@ extern "C" int xdfm_bn_bwd(const float* x, const float* y, const float* dy, int6
   XDFM_LAUNCH_CHECK();
   return XDFM_OK;
 }
+
+// ------------------------------------------------------------------------ softmax
+// `_activate(..., "softmax")` (base_model.py:343-344): tf.nn.softmax over the last axis -- the
+// units of a DNN layer ([B, n]: C = n, I = 1) or the channels of a CIN layer's curr ([B, D, L]
+// there, [B, L, D] here: C = L, I = D).  One lane per (b, i).
+namespace {
+
+__global__ __launch_bounds__(256) void softmax_fwd_kernel(const float* x, int64_t rows, int C, int I, float* y) {
+  const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;  // (b, i)
+  if (r >= rows) return;
+  const int64_t b = r / I;
+  const int64_t base = b * C * I + (r - b * I);
+  float m = x[base];
+  for (int c = 1; c < C; ++c) m = fmaxf(m, x[base + (int64_t)c * I]);
+  float s = 0.f;
+  for (int c = 0; c < C; ++c) s += expf(x[base + (int64_t)c * I] - m);
+  const float inv = 1.f / s;
+  for (int c = 0; c < C; ++c) y[base + (int64_t)c * I] = expf(x[base + (int64_t)c * I] - m) * inv;
+}
+
+// dx = y * (dy - sum_c y*dy)
+__global__ __launch_bounds__(256) void softmax_bwd_kernel(const float* __restrict__ y, const float* dy,
+                                                          int64_t rows, int C, int I, float* dx) {
+  const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (r >= rows) return;
+  const int64_t b = r / I;
+  const int64_t base = b * C * I + (r - b * I);
+  float dot = 0.f;
+  for (int c = 0; c < C; ++c) dot = fmaf(y[base + (int64_t)c * I], dy[base + (int64_t)c * I], dot);
+  for (int c = 0; c < C; ++c) {
+    const int64_t e = base + (int64_t)c * I;
+    dx[e] = y[e] * (dy[e] - dot);
+  }
+}
+
+}  // namespace
+
+extern "C" int xdfm_softmax_fwd(const float* x, int64_t B, int32_t C, int32_t I, float* y, void* stream) {
+  XDFM_REQUIRE(x && y && B >= 0 && C > 0 && I > 0, "xdfm_softmax_fwd: bad argument");
+  if (B == 0) return XDFM_OK;
+  const int64_t rows = B * I;
+  XDFM_LAUNCH("softmax_fwd_kernel", (hipStream_t)stream, softmax_fwd_kernel, dim3((unsigned)((rows + 255) / 256)),
+              dim3(256), 0, x, rows, C, I, y);
+  XDFM_LAUNCH_CHECK();
+  return XDFM_OK;
+}
+
+extern "C" int xdfm_softmax_bwd(const float* y, const float* dy, int64_t B, int32_t C, int32_t I, float* dx,
+                                void* stream) {
+  XDFM_REQUIRE(y && dy && dx && B >= 0 && C > 0 && I > 0, "xdfm_softmax_bwd: bad argument");
+  if (B == 0) return XDFM_OK;
+  const int64_t rows = B * I;
+  XDFM_LAUNCH("softmax_bwd_kernel", (hipStream_t)stream, softmax_bwd_kernel, dim3((unsigned)((rows + 255) / 256)),
+              dim3(256), 0, y, dy, rows, C, I, dx);
+  XDFM_LAUNCH_CHECK();
+  return XDFM_OK;
+}

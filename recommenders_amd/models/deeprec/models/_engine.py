@@ -16,7 +16,8 @@ import torch
 
 from recommenders_amd import _lib
 
-_ACT = {"identity": 0, "relu": 1, "sigmoid": 2, "tanh": 3, "elu": 4}
+_ACT = {"identity": 0, "relu": 1, "sigmoid": 2, "tanh": 3, "elu": 4, "softmax": 5}
+_SOFTMAX = 5  # engine-level code: the kernels get the identity and xdfm_softmax_fwd/bwd follow
 _LOSS = {"log_loss": 0, "cross_entropy_loss": 1, "square_loss": 2}
 # base_model.py:283-302.  ProximalAdagrad / ProximalGradientDescent are built with l1 = l2 = 0
 # there, which makes their updates Adagrad's / plain gradient descent's.
@@ -136,14 +137,15 @@ class XDeepFMEngine(object):
         self.cross_act = 0
         self.cross_path = False
         if hp.use_CIN_part:
-            if hp.cross_activation == "softmax":
-                raise NotImplementedError("cross_activation softmax is not built yet")
             if hp.cross_activation not in _ACT:
                 raise ValueError("this activations not defined {0}".format(hp.cross_activation))
             self.cross_act = _ACT[hp.cross_activation]
+        self.cross_soft = self.cross_act == _SOFTMAX
+        if self.cross_soft:
+            self.cross_act = 0
         # activation and / or batch norm between a CIN layer's product and its split: the layer
         # kernels then write raw curr for every channel and elementwise kernels do the rest
-        self.cross_path = bool(self.cross_act or (self.use_bn and hp.use_CIN_part))
+        self.cross_path = bool(self.cross_act or self.cross_soft or (self.use_bn and hp.use_CIN_part))
         if hp.loss not in _LOSS:
             raise ValueError("this loss not defined {0}".format(hp.loss))
         if hp.method not in ("classification", "regression"):
@@ -649,6 +651,8 @@ class XDeepFMEngine(object):
                     if self.use_bn:
                         act_in = ws["cbn_%d" % k]
                         self._bn_fwd(ws["cur_%d" % k], act_in, "cin", k, B, L, D, 0)
+                    if self.cross_soft:  # over the channels of every (sample, d)
+                        _lib.check(lib.xdfm_softmax_fwd(_ptr(act_in), B, L, D, _ptr(act_in), st))
                     _lib.check(
                         lib.xdfm_cin_act_fwd(_ptr(act_in), B, L, D, nh, self.cross_act, _ptr(xnext),
                                              _ptr(ws["pooled"]), final_len, off, st)
@@ -752,6 +756,9 @@ class XDeepFMEngine(object):
         x, K = ws["emb_out"], self.F * self.D
         for k, size in enumerate(hp.layer_sizes):
             act = _ACT[hp.activation[k]]
+            soft = act == _SOFTMAX
+            if soft:
+                act = 0
             _lib.check(
                 lib.xdfm_dense_fwd(_ptr(x), _ptr(self.views["dnn_w_%d" % k]),
                                    _ptr(self.views["dnn_b_%d" % k]), B, K, int(size),
@@ -768,6 +775,8 @@ class XDeepFMEngine(object):
                                              (self.dropout_seed + 0x9E3779B97F4A7C15 * (k + 1)) & (2 ** 64 - 1),
                                              _ptr(self.opt_state[3:]), st)
                 )
+            if soft:
+                _lib.check(lib.xdfm_softmax_fwd(_ptr(ws["h_%d" % k]), B, int(size), 1, _ptr(ws["h_%d" % k]), st))
             x, K = ws["h_%d" % k], int(size)
         _lib.check(
             lib.xdfm_dense_fwd(_ptr(x), _ptr(self.views["dnn_w_out"]), _ptr(self.views["dnn_b_out"]),
@@ -796,6 +805,10 @@ class XDeepFMEngine(object):
             else:
                 dx, acc = d_acts[k], 0
             act = _ACT[hp.activation[k]]
+            if act == _SOFTMAX:
+                _lib.check(lib.xdfm_softmax_bwd(_ptr(acts[k + 1]), _ptr(d_acts[k + 1]), B, sizes[k + 1], 1,
+                                                _ptr(d_acts[k + 1]), st))
+                act = 0
             if self._dropout_live:
                 # dz = dy * act'(y) * mask/keep in place; the layer itself is then linear
                 _lib.check(
@@ -891,6 +904,11 @@ class XDeepFMEngine(object):
                                              final_len, offs[k], B, L, D, nh, self.cross_act,
                                              _ptr(ws["d_cur"]), st)
                     )
+                    if self.cross_soft:
+                        _lib.check(
+                            lib.xdfm_softmax_bwd(_ptr(ws["cbn_%d" % k] if self.use_bn else ws["cur_%d" % k]),
+                                                 _ptr(ws["d_cur"]), B, L, D, _ptr(ws["d_cur"]), st)
+                        )
                     if self.use_bn:
                         self._bn_bwd(ws["cur_%d" % k], ws["cbn_%d" % k], ws["d_cur"], "cin", k, B, L, D, 0)
                     d_xnext, d_pool, up_nh = ws["d_cur"], None, L

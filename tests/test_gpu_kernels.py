@@ -109,6 +109,11 @@ CONFIGS = {
     "cross_act_cin": dict(cross_activation="sigmoid", FIELD_COUNT=9, dim=8, cross_layer_sizes=[12, 8, 6]),
     "cross_act_fast": dict(cross_activation="tanh", FIELD_COUNT=9, dim=6, fast_CIN_d=2,
                            cross_layer_sizes=[10, 6], layer_sizes=[8], activation=["relu"], dropout=[0.0]),
+    # softmax (base_model.py:343-344) as the CIN's cross_activation and as a DNN activation
+    # (pooled softmax channels add up to logits near +12: cross_entropy_loss, which is computed from
+    # the logit, instead of log_loss's log(1 - p + eps), which keeps four digits there in fp32)
+    "softmax_acts": dict(cross_activation="softmax", FIELD_COUNT=9, dim=8, cross_layer_sizes=[12, 8, 6],
+                         layer_sizes=[10, 7], activation=["softmax", "relu"], loss="cross_entropy_loss"),
     # more than 40 fields: the input-gradient kernel's first form and the wide staging of the filter gradient
     "many_fields": dict(FIELD_COUNT=45, dim=4, FEATURE_COUNT=2000, cross_layer_sizes=[8, 4],
                         layer_sizes=[16], activation=["relu"], dropout=[0.0]),
@@ -121,7 +126,7 @@ def test_forward_and_gradients_match_oracle(name, loss):
     if loss != "log_loss" and name not in ("all_parts", "cin_only_odd"):
         pytest.skip("loss variants are covered on two configs")
     rng = np.random.default_rng(11)
-    hp = make_hp(loss=loss, **CONFIGS[name])
+    hp = make_hp(**{"loss": loss, **CONFIGS[name]})
     B = 97
     b = random_batch(rng, hp, B)
     p32 = X.init_params(hp, seed=7)
