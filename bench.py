@@ -54,9 +54,11 @@ F32_MATRIX_PEAK_TFLOPS = 157.3  # same guide: fp32 MFMA / vector peak
 
 
 def workload_hparams(args):
+    wide = getattr(args, "workload", "criteo") == "wide"
     return prepare_hparams(
         None, model_type="xDeepFM", data_format="ffm", FEATURE_COUNT=args.features, FIELD_COUNT=39,
-        dim=args.dim, layer_sizes=[20, 20], cross_layer_sizes=[20, 10], activation=["relu", "relu"],
+        dim=64 if wide else args.dim, layer_sizes=[1024, 512] if wide else [20, 20],
+        cross_layer_sizes=[256, 256, 256] if wide else [20, 10], activation=["relu", "relu"],
         dropout=[0.0, 0.0], loss="log_loss", method="classification", metrics=["auc", "logloss"],
         use_Linear_part=True, use_FM_part=True, use_CIN_part=True, use_DNN_part=True,
         init_method="tnormal", init_value=0.1, learning_rate=0.002, optimizer="adam",
@@ -158,6 +160,9 @@ def main():
     ap.add_argument("--batch", type=int, default=8192)
     ap.add_argument("--dim", type=int, default=16)
     ap.add_argument("--features", type=int, default=1 << 25)
+    ap.add_argument("--workload", choices=["criteo", "wide"], default="criteo",
+                    help="criteo = BASELINE configs[2] (the bench line); wide = configs[4]'s layer sizes "
+                         "(dim 64, CIN [256,256,256], DNN [1024,512]) at --batch per GPU, a side measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly in the timed region")
     ap.add_argument("--sharded", action="store_true",
@@ -318,8 +323,11 @@ def main():
             "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[2]: Criteo-shape synthetic, 39 fields, 2^25 rows, dim %d, "
-                                   "batch %d per GPU, linear+FM+CIN[20,10]+DNN[20,20], sparse-row Adam" % (hp.dim, hp.batch_size),
+            "config": {"workload": ("BASELINE configs[2]: Criteo-shape synthetic, 39 fields, 2^25 rows, dim %d, "
+                                    "batch %d per GPU, linear+FM+CIN[20,10]+DNN[20,20], sparse-row Adam"
+                                    if args.workload == "criteo" else
+                                    "SIDE MEASUREMENT, layer sizes of BASELINE configs[4] in fp32: 39 fields, dim %d, "
+                                    "batch %d per GPU, CIN[256,256,256]+DNN[1024,512]") % (hp.dim, hp.batch_size),
                        "FEATURE_COUNT": hp.FEATURE_COUNT, "FIELD_COUNT": 39, "dim": hp.dim,
                        "global_batch": world * hp.batch_size,
                        "parallelism": "single GPU" if world == 1 else "table row-sharded x%d (all-to-all) + dense all-reduce%s" % (

@@ -131,11 +131,12 @@ __global__ __launch_bounds__(256) void dense_fwd_mfma_kernel(
 template <int SMAX>
 __global__ __launch_bounds__(256) void dense_bwd_dx_mfma_kernel(
     const float* __restrict__ w, const float* __restrict__ y, const float* __restrict__ dy,
-    int64_t B, int K, int Nout, int act, int accumulate, float* __restrict__ dx) {
+    int64_t B, int K, int Nout, int n0, int n1, int act, int accumulate, float* __restrict__ dx) {
+  // channels [n0, n1) of the layer's Nout: wide layers are summed over several launches
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i = lane & 15, kk = lane >> 4;
   const int64_t row0 = (int64_t)blockIdx.x * 16;
-  const int S = (Nout + 3) >> 2;
+  const int S = (n1 - n0 + 3) >> 2;
   float dzA[SMAX];
   {
     int64_t arow = row0 + i;
@@ -143,10 +144,10 @@ __global__ __launch_bounds__(256) void dense_bwd_dx_mfma_kernel(
     if (!ok) arow = B - 1;
 #pragma unroll
     for (int s = 0; s < SMAX; ++s) {
-      const int n = 4 * s + kk;
-      const int nc = n < Nout ? n : Nout - 1;
+      const int n = n0 + 4 * s + kk;
+      const int nc = n < n1 ? n : n1 - 1;
       const float g = dy[arow * Nout + nc] * act_grad(y[arow * Nout + nc], act);
-      dzA[s] = (ok && s < S && n < Nout) ? g : 0.f;
+      dzA[s] = (ok && s < S && n < n1) ? g : 0.f;
     }
   }
   const int ntile = (K + 15) / 16;
@@ -156,8 +157,8 @@ __global__ __launch_bounds__(256) void dense_bwd_dx_mfma_kernel(
     float bv[SMAX];
 #pragma unroll
     for (int s = 0; s < SMAX; ++s) {
-      const int n = 4 * s + kk;
-      bv[s] = w[(unsigned)(colc * Nout + (n < Nout ? n : Nout - 1))];  // dzA is zero past Nout
+      const int n = n0 + 4 * s + kk;
+      bv[s] = w[(unsigned)(colc * Nout + (n < n1 ? n : n1 - 1))];  // dzA is zero past n1
     }
     f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -427,22 +428,25 @@ extern "C" int xdfm_dense_bwd(const float* x, const float* w, const float* y, co
                 dim3(256), 0, part, n_splits, K, Nout, dw, db);
   }
   if (dx) {
-    const int S = (Nout + 3) / 4;
     dim3 grid((unsigned)((B + 15) / 16));
+    // 256 channels per launch; the launches of a wider layer add up in channel order
+    for (int n0 = 0; n0 < Nout; n0 += 256) {
+      const int n1 = n0 + 256 < Nout ? n0 + 256 : Nout;
+      const int S = (n1 - n0 + 3) / 4;
+      const int acc = (n0 > 0) ? 1 : accumulate_dx;
 #define CALL(SM)                                                                                       \
   XDFM_LAUNCH("dense_bwd_dx_mfma_kernel<" #SM ">", st, dense_bwd_dx_mfma_kernel<SM>, grid, dim3(256), 0, w, \
-              y, dy, B, K, Nout, act, accumulate_dx, dx)
-    if (S <= 1)
-      CALL(1);
-    else if (S <= 5)
-      CALL(5);
-    else if (S <= 16)
-      CALL(16);
-    else if (S <= 64)
-      CALL(64);
-    else
-      return xdfm::fail(XDFM_E_INVALID, "xdfm_dense_bwd: layer width %d not supported (max 256)", Nout);
+              y, dy, B, K, Nout, n0, n1, act, acc, dx)
+      if (S <= 1)
+        CALL(1);
+      else if (S <= 5)
+        CALL(5);
+      else if (S <= 16)
+        CALL(16);
+      else
+        CALL(64);
 #undef CALL
+    }
   }
   XDFM_LAUNCH_CHECK();
   return XDFM_OK;

@@ -109,6 +109,10 @@ CONFIGS = {
     "cross_act_cin": dict(cross_activation="sigmoid", FIELD_COUNT=9, dim=8, cross_layer_sizes=[12, 8, 6]),
     "cross_act_fast": dict(cross_activation="tanh", FIELD_COUNT=9, dim=6, fast_CIN_d=2,
                            cross_layer_sizes=[10, 6], layer_sizes=[8], activation=["relu"], dropout=[0.0]),
+    # BASELINE configs[4] "wide" shapes (dim 64, CIN [256,256,256], DNN [1024,512]) at a small batch:
+    # H = 128 maps do not fit the matrix-core CIN tiles, the generic kernels serve these layers
+    "wide_shape": dict(FIELD_COUNT=39, dim=64, FEATURE_COUNT=4000, cross_layer_sizes=[256, 256, 256],
+                       layer_sizes=[1024, 512], activation=["relu", "relu"], init_value=0.02),
     # softmax (base_model.py:343-344) as the CIN's cross_activation and as a DNN activation
     # (pooled softmax channels add up to logits near +12: cross_entropy_loss, which is computed from
     # the logit, instead of log_loss's log(1 - p + eps), which keeps four digits there in fp32)
