@@ -252,46 +252,56 @@ struct OptDev {
   const float* state;  // device {b1^t, b2^t, step size, t} or null
 };
 
+// One row's optimizer step in three parts, so that a caller can request the row early (the
+// loads of a row that is about to be finished travel with the gather of its gradient).
+__device__ __forceinline__ bool opt_uses_m(int kind) { return kind != XDFM_OPT_SGD; }
+__device__ __forceinline__ bool opt_uses_v(int kind) {
+  return kind == XDFM_OPT_ADAM || kind == XDFM_OPT_ADADELTA || kind == XDFM_OPT_FTRL;
+}
+
 template <int VEC>
-__device__ __forceinline__ void apply_row(const OptDev& o, float* p, float* m, float* v,
-                                          const float (&g)[VEC]) {
-  float pv[VEC];
-  load_vec<VEC>(p, pv);
+struct RowVals {
+  float p[VEC], m[VEC], v[VEC];
+};
+
+template <int VEC>
+__device__ __forceinline__ void row_load(const OptDev& o, const float* p, const float* m, const float* v,
+                                         RowVals<VEC>& r) {
+  load_vec<VEC>(p, r.p);
+  if (opt_uses_m(o.kind)) load_vec<VEC>(m, r.m);
+  if (opt_uses_v(o.kind)) load_vec<VEC>(v, r.v);
+}
+
+template <int VEC>
+__device__ __forceinline__ void row_update(const OptDev& o, RowVals<VEC>& r, const float (&g)[VEC]) {
+  float(&pv)[VEC] = r.p;
   if (o.kind == XDFM_OPT_ADAM) {
     const float alpha = o.state ? o.state[2] : o.alpha;
-    float mv[VEC], vv[VEC];
-    load_vec<VEC>(m, mv);
-    load_vec<VEC>(v, vv);
+    float(&mv)[VEC] = r.m;
+    float(&vv)[VEC] = r.v;
 #pragma unroll
     for (int i = 0; i < VEC; ++i) {
       mv[i] = mv[i] + (g[i] - mv[i]) * o.one_minus_b1;
       vv[i] = vv[i] + (g[i] * g[i] - vv[i]) * o.one_minus_b2;
       pv[i] = pv[i] - (mv[i] * alpha) / (sqrtf(vv[i]) + o.eps);
     }
-    store_vec<VEC>(m, mv);
-    store_vec<VEC>(v, vv);
   } else if (o.kind == XDFM_OPT_ADAGRAD) {
-    float av[VEC];
-    load_vec<VEC>(m, av);
+    float(&av)[VEC] = r.m;
 #pragma unroll
     for (int i = 0; i < VEC; ++i) {
       av[i] = av[i] + g[i] * g[i];
       pv[i] = pv[i] - (g[i] * o.lr) / sqrtf(av[i]);
     }
-    store_vec<VEC>(m, av);
   } else if (o.kind == XDFM_OPT_RMSPROP) {
-    float av[VEC];
-    load_vec<VEC>(m, av);
+    float(&av)[VEC] = r.m;
 #pragma unroll
     for (int i = 0; i < VEC; ++i) {
       av[i] = av[i] + (g[i] * g[i] - av[i]) * o.one_minus_b2;
       pv[i] = pv[i] - (g[i] * o.lr) / sqrtf(av[i] + o.eps);
     }
-    store_vec<VEC>(m, av);
   } else if (o.kind == XDFM_OPT_ADADELTA) {
-    float av[VEC], uv[VEC];
-    load_vec<VEC>(m, av);
-    load_vec<VEC>(v, uv);
+    float(&av)[VEC] = r.m;
+    float(&uv)[VEC] = r.v;
 #pragma unroll
     for (int i = 0; i < VEC; ++i) {
       av[i] = av[i] * (1.f - o.one_minus_b2) + g[i] * g[i] * o.one_minus_b2;
@@ -299,12 +309,9 @@ __device__ __forceinline__ void apply_row(const OptDev& o, float* p, float* m, f
       uv[i] = uv[i] * (1.f - o.one_minus_b2) + upd * upd * o.one_minus_b2;
       pv[i] = pv[i] - upd * o.lr;
     }
-    store_vec<VEC>(m, av);
-    store_vec<VEC>(v, uv);
   } else if (o.kind == XDFM_OPT_FTRL) {
-    float av[VEC], lv[VEC];
-    load_vec<VEC>(m, av);
-    load_vec<VEC>(v, lv);
+    float(&av)[VEC] = r.m;
+    float(&lv)[VEC] = r.v;
 #pragma unroll
     for (int i = 0; i < VEC; ++i) {
       const float nw = av[i] + g[i] * g[i];
@@ -312,13 +319,26 @@ __device__ __forceinline__ void apply_row(const OptDev& o, float* p, float* m, f
       pv[i] = -lv[i] / (sqrtf(nw) / o.lr);
       av[i] = nw;
     }
-    store_vec<VEC>(m, av);
-    store_vec<VEC>(v, lv);
   } else {
 #pragma unroll
     for (int i = 0; i < VEC; ++i) pv[i] = pv[i] - g[i] * o.lr;
   }
-  store_vec<VEC>(p, pv);
+}
+
+template <int VEC>
+__device__ __forceinline__ void row_store(const OptDev& o, float* p, float* m, float* v, const RowVals<VEC>& r) {
+  if (opt_uses_m(o.kind)) store_vec<VEC>(m, r.m);
+  if (opt_uses_v(o.kind)) store_vec<VEC>(v, r.v);
+  store_vec<VEC>(p, r.p);
+}
+
+template <int VEC>
+__device__ __forceinline__ void apply_row(const OptDev& o, float* p, float* m, float* v,
+                                          const float (&g)[VEC]) {
+  RowVals<VEC> r;
+  row_load<VEC>(o, p, m, v, r);
+  row_update<VEC>(o, r, g);
+  row_store<VEC>(o, p, m, v, r);
 }
 
 struct BwdArgs {
@@ -430,6 +450,20 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(BwdArgs a) {
     const float gw_q = __shfl(gw, qs);
     const int keyn_q = __shfl(key_after, qs);
     const float lsum_q = __shfl(lsum, qs);
+    // what becomes of this position's running sum is known from the keys alone: a row that will
+    // be finished in this pass is requested now, together with the gather of its gradient
+    const bool chunk_end = q == nvalid - 1;
+    const bool seg_end = on && (chunk_end || keyn_q != key_q);
+    const bool to_head = cont_prev && key_q == first_key;
+    const bool to_tail = chunk_end && cont_next;
+    const bool finish = seg_end && !to_head && !to_tail;
+    RowVals<VEC> rv;
+    RowVals<1> rl;
+    if (MODE == 0 && finish) {
+      const int64_t off = (int64_t)key_q * a.D + c * VEC;
+      row_load<VEC>(a.opt, a.table + off, a.slot_m + off, a.slot_v + off, rv);
+      if (a.lin_w && c == 0) row_load<1>(a.opt, a.lin_w + key_q, a.lin_m + key_q, a.lin_v + key_q, rl);
+    }
     float v[VEC];
 #pragma unroll
     for (int k = 0; k < VEC; ++k) v[k] = 0.f;
@@ -473,19 +507,24 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(BwdArgs a) {
       shfl_vec<VEC>(v, src < 64 ? src : lane, carry);
       carry_key = __shfl(key_q, (R - 1) * LPR);
     }
-    if (on) {
-      const bool chunk_end = q == nvalid - 1;
-      const bool seg_end = chunk_end || keyn_q != key_q;
-      if (seg_end) {
-        if (cont_prev && key_q == first_key) {
-          store_vec<VEC>(head_vec + chunk * a.D + c * VEC, v);
-          if (c == 0) head_lin[chunk] = lsum_q;
-        } else if (chunk_end && cont_next) {
-          store_vec<VEC>(tail_vec + chunk * a.D + c * VEC, v);
-          if (c == 0) tail_lin[chunk] = lsum_q;
-        } else {
-          finish_row<VEC, MODE>(a, key_q, c, v, lsum_q);
+    if (seg_end) {
+      if (to_head) {
+        store_vec<VEC>(head_vec + chunk * a.D + c * VEC, v);
+        if (c == 0) head_lin[chunk] = lsum_q;
+      } else if (to_tail) {
+        store_vec<VEC>(tail_vec + chunk * a.D + c * VEC, v);
+        if (c == 0) tail_lin[chunk] = lsum_q;
+      } else if (MODE == 0) {
+        const int64_t off = (int64_t)key_q * a.D + c * VEC;
+        row_update<VEC>(a.opt, rv, v);
+        row_store<VEC>(a.opt, a.table + off, a.slot_m + off, a.slot_v + off, rv);
+        if (a.lin_w && c == 0) {
+          const float g1[1] = {lsum_q};
+          row_update<1>(a.opt, rl, g1);
+          row_store<1>(a.opt, a.lin_w + key_q, a.lin_m + key_q, a.lin_v + key_q, rl);
         }
+      } else {
+        finish_row<VEC, MODE>(a, key_q, c, v, lsum_q);
       }
     }
   }
