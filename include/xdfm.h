@@ -133,6 +133,11 @@ int xdfm_build_row_ptr(const int64_t* dnn_feat_indices, int64_t nnz, int64_t n_r
  *   sparse_dense_matmul(x, w)                            xDeepFM.py:128   (bias added by the caller)
  *   0.5*sum((xE)^2 - (x^2)(E^2))                         xDeepFM.py:153-158
  *   table[N,D], lin_w[N] (NULL: no linear part)
+ *   table_stride / lin_stride: floats between consecutive rows of table / entries of lin_w;
+ *     0 = dense (D and 1).  A caller may interleave a row's parameter, its linear weight and their
+ *     optimizer slots in one record (the sparse-row update then touches two cache lines per row
+ *     instead of six); every xdfm_embed_* call takes the same two strides, which also apply to the
+ *     slot arrays.
  *   row_ptr[B*F+1] int32, ids[nnz] int64, weights[nnz] float32 : the dnn view
  *   emb_out[B,F,D]           out[r,:] = sum_j w_j*table[id_j,:] in column order; rows
  *                            without a token are zero (also trailing ones)
@@ -140,8 +145,8 @@ int xdfm_build_row_ptr(const int64_t* dnn_feat_indices, int64_t nnz, int64_t n_r
  *   fm_out[B]   (NULL ok)    FM second-order term
  *   fm_sum[B,D] (NULL ok)    s[b,d] = sum_j w_j*table[id_j,d]   (kept for the backward)
  * ---------------------------------------------------------------------- */
-int xdfm_embed_fwd(const float* table, const float* lin_w, int64_t N, int32_t D, int32_t F,
-                   int64_t B, const int32_t* row_ptr, const int64_t* ids, const float* weights,
+int xdfm_embed_fwd(const float* table, const float* lin_w, int64_t table_stride, int64_t lin_stride,
+                   int64_t N, int32_t D, int32_t F, int64_t B, const int32_t* row_ptr, const int64_t* ids, const float* weights,
                    int64_t nnz, float* emb_out, float* lin_out, float* fm_out, float* fm_sum,
                    int32_t* err_flag, void* stream);
 
@@ -149,8 +154,8 @@ int xdfm_embed_fwd(const float* table, const float* lin_w, int64_t N, int32_t D,
  * No counterpart in the reference (one device, one table): it is the owner-side lookup of the
  * row-sharded table ("owners run K1 locally"), the same copy xdfm_embed_fwd
  * does with one token of weight 1 per row, without spending a wave per row. */
-int xdfm_embed_gather(const float* table, const float* lin_w, int64_t N, int32_t D,
-                      const int64_t* rows, int64_t n, float* out, float* lin_out,
+int xdfm_embed_gather(const float* table, const float* lin_w, int64_t table_stride,
+                      int64_t lin_stride, int64_t N, int32_t D, const int64_t* rows, int64_t n, float* out, float* lin_out,
                       int32_t* err_flag, void* stream);
 
 /* ------------------------------------------------------------------------
@@ -192,6 +197,8 @@ int xdfm_opt_advance(float* opt_state, float lr, float beta1, float beta2, void*
  *     l_j = g[b_j]*w_j                                                            (linear, optional)
  * over equal ids in sorted order, then
  *   mode 0 (sparse_rows): apply `opt` to the touched rows of table (+slots) and lin_w in place;
+ *   (table_stride / lin_stride as for xdfm_embed_fwd: they address table, slot_m, slot_v and
+ *   lin_w, lin_m, lin_v; grad_table / grad_lin are always dense)
  *   mode 1 (scatter)    : store the sums into grad_table[N,D] / grad_lin[N] (rows of untouched
  *                         ids are left as they are: the caller keeps them zero).
  *   pieces: float scratch of 2*(nnz/64 + 1)*(D + 1) elements (partial sums of the segments that
@@ -200,7 +207,8 @@ int xdfm_opt_advance(float* opt_state, float lr, float beta1, float beta2, void*
  *   producers, e.g. the CIN and the DNN tower, then need no common accumulator);
  *   g_logit[B] and fm_sum[B,D] only when the FM / linear parts are on. */
 int xdfm_embed_bwd(int32_t mode, float* table, float* slot_m, float* slot_v, float* lin_w,
-                   float* lin_m, float* lin_v, float* grad_table, float* grad_lin, int64_t N,
+                   float* lin_m, float* lin_v, int64_t table_stride, int64_t lin_stride,
+                   float* grad_table, float* grad_lin, int64_t N,
                    int32_t D, int32_t F, int64_t B, const int32_t* sorted_ids,
                    const int32_t* sorted_tok, const int32_t* tok_row, const float* weights,
                    int64_t nnz, const float* d_emb, const float* g_logit, const float* fm_sum,

@@ -76,8 +76,8 @@ __global__ void build_row_ptr_kernel(const int64_t* __restrict__ idx, int64_t nn
 // fixed order, so the result does not depend on scheduling.
 template <int VEC>
 __global__ __launch_bounds__(256) void embed_fwd_kernel(
-    const float* __restrict__ table, const float* __restrict__ lin_w, int64_t N, int D, int F,
-    int64_t B, const int32_t* __restrict__ row_ptr, const int64_t* __restrict__ ids,
+    const float* __restrict__ table, const float* __restrict__ lin_w, int64_t TS, int64_t LS, int64_t N,
+    int D, int F, int64_t B, const int32_t* __restrict__ row_ptr, const int64_t* __restrict__ ids,
     const float* __restrict__ weights, float* __restrict__ emb_out, float* __restrict__ lin_out,
     float* __restrict__ fm_out, float* __restrict__ fm_sum, int32_t* err_flag) {
   __shared__ float red_s[4][kWave][VEC];
@@ -132,8 +132,8 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(
       for (int u = 0; u < PU; ++u) {
         ok0[u] = has[u] && (uint64_t)id0[u] < (uint64_t)N;
         const int64_t idc = ok0[u] ? id0[u] : 0;
-        load_vec<VEC>(table + idc * D + c * VEC, e0[u]);
-        l0[u] = (c == 0 && lin_w) ? lin_w[idc] : 0.f;
+        load_vec<VEC>(table + idc * TS + c * VEC, e0[u]);
+        l0[u] = (c == 0 && lin_w) ? lin_w[idc * LS] : 0.f;
       }
 #pragma unroll
       for (int u = 0; u < PU; ++u) {
@@ -165,7 +165,7 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(
             continue;
           }
           float e[VEC];
-          load_vec<VEC>(table + id * D + c * VEC, e);
+          load_vec<VEC>(table + id * TS + c * VEC, e);
 #pragma unroll
           for (int v = 0; v < VEC; ++v) {
             const float t = w * e[v];
@@ -173,7 +173,7 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(
             q_acc[v] += t * t;
           }
           first = false;
-          if (c == 0 && lin_w) lin_acc += w * lin_w[id];
+          if (c == 0 && lin_w) lin_acc += w * lin_w[id * LS];
         }
         store_vec<VEC>(emb_out + r * D + c * VEC, acc);
 #pragma unroll
@@ -344,6 +344,7 @@ __device__ __forceinline__ void apply_row(const OptDev& o, float* p, float* m, f
 struct BwdArgs {
   float *table, *slot_m, *slot_v, *lin_w, *lin_m, *lin_v, *grad_table, *grad_lin;
   int64_t N, B, nnz;
+  int64_t TS, LS;  // row strides (floats) of table / slots and of lin_w / its slots
   int D, F;
   const int32_t *sorted_ids, *sorted_tok, *tok_row;
   const float *weights, *d_emb, *d_emb2, *g_logit, *fm_sum;
@@ -355,14 +356,16 @@ struct BwdArgs {
 template <int VEC, int MODE>
 __device__ __forceinline__ void finish_row(const BwdArgs& a, int id, int c, const float (&acc)[VEC],
                                            float lacc) {
-  const int64_t off = (int64_t)id * a.D + c * VEC;
   if (MODE == 0) {
+    const int64_t off = (int64_t)id * a.TS + c * VEC;
     apply_row<VEC>(a.opt, a.table + off, a.slot_m + off, a.slot_v + off, acc);
     if (a.lin_w && c == 0) {
       float g1[1] = {lacc};
-      apply_row<1>(a.opt, a.lin_w + id, a.lin_m + id, a.lin_v + id, g1);
+      const int64_t lo = (int64_t)id * a.LS;
+      apply_row<1>(a.opt, a.lin_w + lo, a.lin_m + lo, a.lin_v + lo, g1);
     }
   } else {
+    const int64_t off = (int64_t)id * a.D + c * VEC;  // the gradient image is always [N][D]
     store_vec<VEC>(a.grad_table + off, acc);
     if (a.grad_lin && c == 0) a.grad_lin[id] = lacc;
   }
@@ -460,9 +463,10 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(BwdArgs a) {
     RowVals<VEC> rv;
     RowVals<1> rl;
     if (MODE == 0 && finish) {
-      const int64_t off = (int64_t)key_q * a.D + c * VEC;
+      const int64_t off = (int64_t)key_q * a.TS + c * VEC;
+      const int64_t lo = (int64_t)key_q * a.LS;
       row_load<VEC>(a.opt, a.table + off, a.slot_m + off, a.slot_v + off, rv);
-      if (a.lin_w && c == 0) row_load<1>(a.opt, a.lin_w + key_q, a.lin_m + key_q, a.lin_v + key_q, rl);
+      if (a.lin_w && c == 0) row_load<1>(a.opt, a.lin_w + lo, a.lin_m + lo, a.lin_v + lo, rl);
     }
     float v[VEC];
 #pragma unroll
@@ -480,7 +484,7 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(BwdArgs a) {
       for (int k = 0; k < VEC; ++k) v[k] = w_q * de[k];
       if (a.use_fm) {
         float e[VEC], sfm[VEC];
-        load_vec<VEC>(a.table + (int64_t)key_q * a.D + c * VEC, e);
+        load_vec<VEC>(a.table + (int64_t)key_q * a.TS + c * VEC, e);
         load_vec<VEC>(a.fm_sum + (int64_t)(row_q / a.F) * a.D + c * VEC, sfm);
 #pragma unroll
         for (int k = 0; k < VEC; ++k) v[k] = fmaf(gw_q, sfm[k] - w_q * e[k], v[k]);
@@ -515,13 +519,14 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(BwdArgs a) {
         store_vec<VEC>(tail_vec + chunk * a.D + c * VEC, v);
         if (c == 0) tail_lin[chunk] = lsum_q;
       } else if (MODE == 0) {
-        const int64_t off = (int64_t)key_q * a.D + c * VEC;
+        const int64_t off = (int64_t)key_q * a.TS + c * VEC;
         row_update<VEC>(a.opt, rv, v);
         row_store<VEC>(a.opt, a.table + off, a.slot_m + off, a.slot_v + off, rv);
         if (a.lin_w && c == 0) {
           const float g1[1] = {lsum_q};
+          const int64_t lo = (int64_t)key_q * a.LS;
           row_update<1>(a.opt, rl, g1);
-          row_store<1>(a.opt, a.lin_w + key_q, a.lin_m + key_q, a.lin_v + key_q, rl);
+          row_store<1>(a.opt, a.lin_w + lo, a.lin_m + lo, a.lin_v + lo, rl);
         }
       } else {
         finish_row<VEC, MODE>(a, key_q, c, v, lsum_q);
@@ -644,7 +649,15 @@ extern "C" int xdfm_build_row_ptr(const int64_t* dnn_feat_indices, int64_t nnz, 
   return XDFM_OK;
 }
 
-extern "C" int xdfm_embed_fwd(const float* table, const float* lin_w, int64_t N, int32_t D,
+// row strides in floats; 0 = the dense layouts table[N][D], lin_w[N]
+static bool strides_ok(int64_t* ts, int64_t* ls, int D, int vec) {
+  if (*ts == 0) *ts = D;
+  if (*ls == 0) *ls = 1;
+  return *ts >= D && *ls >= 1 && (*ts % vec) == 0;
+}
+
+extern "C" int xdfm_embed_fwd(const float* table, const float* lin_w, int64_t table_stride,
+                              int64_t lin_stride, int64_t N, int32_t D,
                               int32_t F, int64_t B, const int32_t* row_ptr, const int64_t* ids,
                               const float* weights, int64_t nnz, float* emb_out, float* lin_out,
                               float* fm_out, float* fm_sum, int32_t* err_flag, void* stream) {
@@ -654,12 +667,13 @@ extern "C" int xdfm_embed_fwd(const float* table, const float* lin_w, int64_t N,
   XDFM_REQUIRE(!lin_out || lin_w, "xdfm_embed_fwd: lin_out needs lin_w");
   const int vec = pick_vec(D);
   XDFM_REQUIRE(D / vec <= kWave, "xdfm_embed_fwd: dim %d not supported (needs D/%d <= 64)", D, vec);
+  XDFM_REQUIRE(strides_ok(&table_stride, &lin_stride, D, vec), "xdfm_embed_fwd: bad row strides");
   if (B == 0) return XDFM_OK;
   const unsigned blocks = (unsigned)((B + 3) / 4);
 #define LAUNCH(V)                                                                               \
   XDFM_LAUNCH("embed_fwd_kernel<" #V ">", stream, embed_fwd_kernel<V>, dim3(blocks), dim3(256), 0, table, \
-                     lin_out ? lin_w : nullptr, N, D, F, B, row_ptr, ids, weights, emb_out,      \
-                     lin_out, fm_out, fm_sum, err_flag)
+                     lin_out ? lin_w : nullptr, table_stride, lin_stride, N, D, F, B, row_ptr, ids,    \
+                     weights, emb_out, lin_out, fm_out, fm_sum, err_flag)
   if (vec == 4)
     LAUNCH(4);
   else if (vec == 2)
@@ -674,8 +688,9 @@ extern "C" int xdfm_embed_fwd(const float* table, const float* lin_w, int64_t N,
 // plain row gather (owner side of the row-sharded table): D/VEC lanes per row
 template <int VEC>
 __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ table,
-                                                          const float* __restrict__ lin_w, int64_t N,
-                                                          int D, const int64_t* __restrict__ rows,
+                                                          const float* __restrict__ lin_w, int64_t TS,
+                                                          int64_t LS, int64_t N, int D,
+                                                          const int64_t* __restrict__ rows,
                                                           int64_t n, float* __restrict__ out,
                                                           float* __restrict__ lin_out, int32_t* err_flag) {
   const int LPR = D / VEC;
@@ -689,12 +704,13 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restric
     id = 0;
   }
   float e[VEC];
-  load_vec<VEC>(table + id * D + c * VEC, e);
+  load_vec<VEC>(table + id * TS + c * VEC, e);
   store_vec<VEC>(out + r * D + c * VEC, e);
-  if (lin_out && c == 0) lin_out[r] = lin_w[id];
+  if (lin_out && c == 0) lin_out[r] = lin_w[id * LS];
 }
 
-extern "C" int xdfm_embed_gather(const float* table, const float* lin_w, int64_t N, int32_t D,
+extern "C" int xdfm_embed_gather(const float* table, const float* lin_w, int64_t table_stride,
+                                 int64_t lin_stride, int64_t N, int32_t D,
                                  const int64_t* rows, int64_t n, float* out, float* lin_out,
                                  int32_t* err_flag, void* stream) {
   XDFM_REQUIRE(table && out && err_flag, "xdfm_embed_gather: null argument");
@@ -703,11 +719,12 @@ extern "C" int xdfm_embed_gather(const float* table, const float* lin_w, int64_t
   if (n == 0) return XDFM_OK;
   XDFM_REQUIRE(rows, "xdfm_embed_gather: null rows");
   const int vec = pick_vec(D);
+  XDFM_REQUIRE(strides_ok(&table_stride, &lin_stride, D, vec), "xdfm_embed_gather: bad row strides");
   const int64_t threads = n * (D / vec);
   const unsigned blocks = (unsigned)((threads + 255) / 256);
 #define LAUNCH(V)                                                                                          \
   XDFM_LAUNCH("gather_rows_kernel<" #V ">", stream, gather_rows_kernel<V>, dim3(blocks), dim3(256), 0, table, \
-              lin_out ? lin_w : nullptr, N, D, rows, n, out, lin_out, err_flag)
+              lin_out ? lin_w : nullptr, table_stride, lin_stride, N, D, rows, n, out, lin_out, err_flag)
   if (vec == 4)
     LAUNCH(4);
   else if (vec == 2)
@@ -761,7 +778,8 @@ extern "C" int xdfm_embed_plan(const int64_t* ids, int64_t nnz, int64_t N, int32
 }
 
 extern "C" int xdfm_embed_bwd(int32_t mode, float* table, float* slot_m, float* slot_v,
-                              float* lin_w, float* lin_m, float* lin_v, float* grad_table,
+                              float* lin_w, float* lin_m, float* lin_v, int64_t table_stride,
+                              int64_t lin_stride, float* grad_table,
                               float* grad_lin, int64_t N, int32_t D, int32_t F, int64_t B,
                               const int32_t* sorted_ids, const int32_t* sorted_tok,
                               const int32_t* tok_row, const float* weights, int64_t nnz,
@@ -806,6 +824,8 @@ extern "C" int xdfm_embed_bwd(int32_t mode, float* table, float* slot_m, float* 
   a.B = B;
   a.nnz = nnz;
   a.D = D;
+  a.TS = table_stride;
+  a.LS = lin_stride;
   a.F = F;
   a.sorted_ids = sorted_ids;
   a.sorted_tok = sorted_tok;
@@ -821,6 +841,9 @@ extern "C" int xdfm_embed_bwd(int32_t mode, float* table, float* slot_m, float* 
   const int vec = pick_vec(D);
   const int lpr = D / vec;
   XDFM_REQUIRE(lpr <= 64, "xdfm_embed_bwd: dim %d not supported (needs D/%d <= 64)", D, vec);
+  XDFM_REQUIRE(strides_ok(&table_stride, &lin_stride, D, vec), "xdfm_embed_bwd: bad row strides");
+  a.TS = table_stride;
+  a.LS = lin_stride;
   hipStream_t st = (hipStream_t)stream;
   const int64_t nchunks = (nnz + kChunk - 1) / kChunk;
   const unsigned blocks = (unsigned)((nchunks + 3) / 4);

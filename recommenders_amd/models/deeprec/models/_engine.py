@@ -178,8 +178,34 @@ class XDeepFMEngine(object):
         dev = self.device
         f32 = torch.float32
         # ---- parameters (values are set by load_state / init)
-        self.table = torch.zeros((self.N, self.D), dtype=f32, device=dev)
-        self.lin_w = torch.zeros((self.N,), dtype=f32, device=dev) if hp.use_Linear_part else None
+        need_m = self.opt_kind != 0
+        need_v = self.opt_kind in (1, 4, 5)  # Adam v, Adadelta accum_update, FTRL linear
+        m0 = _SLOT_M_INIT.get(self.opt_kind, 0.0)
+        # sparse_rows keeps everything a row's update touches in one record of whole 128-byte
+        # lines: [row | lin w, m, v | pad] [slot m | slot v | pad]; the forward gather reads the
+        # first line only, the update two lines instead of six scattered ones.  The tensors
+        # below are strided views into it (row strides go to the kernels).
+        self.interleaved = (embedding_update == "sparse_rows"
+                            and os.environ.get("XDFM_TABLE_RECORDS", "1") != "0")
+        if self.interleaved:
+            D = self.D
+            line0 = (D + 3 + 31) // 32 * 32
+            self.table_stride = self.lin_stride = line0 + (2 * D + 31) // 32 * 32
+            self._records = torch.zeros((self.N, self.table_stride), dtype=f32, device=dev)
+            rec = self._records
+            self.table = rec[:, 0:D]
+            self.lin_w = rec[:, D] if hp.use_Linear_part else None
+            self.table_m = rec[:, line0:line0 + D] if need_m else None
+            self.table_v = rec[:, line0 + D:line0 + 2 * D] if need_v else None
+            self.lin_m = rec[:, D + 1] if (need_m and hp.use_Linear_part) else None
+            self.lin_v = rec[:, D + 2] if (need_v and hp.use_Linear_part) else None
+            for t in (self.table_m, self.lin_m):
+                if t is not None and m0 != 0.0:
+                    t.fill_(m0)
+        else:
+            self.table_stride, self.lin_stride = self.D, 1
+            self.table = torch.zeros((self.N, self.D), dtype=f32, device=dev)
+            self.lin_w = torch.zeros((self.N,), dtype=f32, device=dev) if hp.use_Linear_part else None
         self.dense_shapes = dense_param_shapes(hp)
         offs = [0]
         for shape in self.dense_shapes.values():
@@ -195,16 +221,13 @@ class XDeepFMEngine(object):
         self.bn_state = {name: torch.zeros(shape, dtype=f32, device=dev)
                          for name, shape in bn_state_shapes(hp).items()}
         # ---- optimizer slots
-        need_m = self.opt_kind != 0
-        need_v = self.opt_kind in (1, 4, 5)  # Adam v, Adadelta accum_update, FTRL linear
-
         def slot(like, on, value=0.0):
             return torch.full_like(like, value) if on else None
 
-        m0 = _SLOT_M_INIT.get(self.opt_kind, 0.0)
-        self.table_m, self.table_v = slot(self.table, need_m, m0), slot(self.table, need_v)
-        self.lin_m = slot(self.lin_w, need_m, m0) if self.lin_w is not None else None
-        self.lin_v = slot(self.lin_w, need_v) if self.lin_w is not None else None
+        if not self.interleaved:
+            self.table_m, self.table_v = slot(self.table, need_m, m0), slot(self.table, need_v)
+            self.lin_m = slot(self.lin_w, need_m, m0) if self.lin_w is not None else None
+            self.lin_v = slot(self.lin_w, need_v) if self.lin_w is not None else None
         self.dense_m, self.dense_v = slot(self.dense, need_m, m0), slot(self.dense, need_v)
         self.step = 0
         self.b1p = np.float32(1.0)
@@ -591,6 +614,8 @@ class XDeepFMEngine(object):
             lib.xdfm_embed_fwd(
                 _ptr(batch.src_table if batch.src_table is not None else self.table),
                 _ptr(batch.src_lin if batch.src_table is not None else self.lin_w) if use_lin else None,
+                0 if batch.src_table is not None else self.table_stride,
+                0 if batch.src_table is not None else self.lin_stride,
                 batch.src_N if batch.src_table is not None else self.N, D, F, B,
                 _ptr(batch.row_ptr), _ptr(batch.src_ids if batch.src_table is not None else batch.ids),
                 _ptr(batch.weights), batch.nnz,
@@ -1011,7 +1036,8 @@ class XDeepFMEngine(object):
             lib.xdfm_embed_bwd(
                 0 if sparse else 1, _ptr(self.table), _ptr(self.table_m), _ptr(self.table_v),
                 _ptr(self.lin_w) if use_lin else None, _ptr(self.lin_m) if use_lin else None,
-                _ptr(self.lin_v) if use_lin else None, _ptr(self.grad_table),
+                _ptr(self.lin_v) if use_lin else None, self.table_stride, self.lin_stride,
+                _ptr(self.grad_table),
                 _ptr(self.grad_lin) if use_lin else None, self.N, self.D, self.F, batch.B,
                 _ptr(batch.sorted_ids), _ptr(batch.sorted_tok), _ptr(batch.tok_row),
                 _ptr(batch.weights), batch.nnz, _ptr(ws["d_emb"]),

@@ -206,7 +206,8 @@ class ShardedXDeepFMEngine(XDeepFMEngine):
             ev = self._mark("owner_gather")
             _lib.check(
                 lib.xdfm_embed_gather(
-                    _ptr(self.table), _ptr(self.lin_w) if use_lin else None, self.N, D, _ptr(plan.recv_rows),
+                    _ptr(self.table), _ptr(self.lin_w) if use_lin else None, self.table_stride, self.lin_stride,
+                    self.N, D, _ptr(plan.recv_rows),
                     n_recv, _ptr(rows_out), _ptr(lin_out) if use_lin else None, _ptr(self.err_flag), st,
                 )
             )
@@ -274,7 +275,7 @@ class ShardedXDeepFMEngine(XDeepFMEngine):
         ev = self._mark("token_grads")
         _lib.check(
             lib.xdfm_embed_bwd(
-                1, _ptr(batch.src_table), None, None, None, None, None, _ptr(send_g),
+                1, _ptr(batch.src_table), None, None, None, None, None, 0, 0, _ptr(send_g),
                 _ptr(send_gl) if use_lin else None, max(nnz, 1), D, self.F, batch.B,
                 _ptr(self._arange32(nnz)), _ptr(order32), _ptr(batch.tok_row), _ptr(batch.weights), nnz,
                 _ptr(ws["d_emb"]), _ptr(ws["g_logit"]) if (use_lin or use_fm) else None,
@@ -304,7 +305,8 @@ class ShardedXDeepFMEngine(XDeepFMEngine):
                 lib.xdfm_embed_bwd(
                     0, _ptr(self.table), _ptr(self.table_m), _ptr(self.table_v),
                     _ptr(self.lin_w) if use_lin else None, _ptr(self.lin_m) if use_lin else None,
-                    _ptr(self.lin_v) if use_lin else None, None, None, self.N, D, 1, n,
+                    _ptr(self.lin_v) if use_lin else None, self.table_stride, self.lin_stride, None, None,
+                    self.N, D, 1, n,
                     _ptr(batch.owner_sorted_ids), _ptr(batch.owner_sorted_tok), _ptr(self._arange32(n)),
                     _ptr(self._ones(n)), n, _ptr(recv_g), _ptr(recv_gl) if use_lin else None, None, 0,
                     ctypes.byref(opt), _ptr(pieces), None, st,

@@ -41,7 +41,7 @@ def test_abi_version_and_error_channel():
     rc = _lib.lib.xdfm_dense_bwd_workspace_floats(-1, 0, 0, ctypes.byref(sz))
     assert rc == -1
     assert b"bad argument" in _lib.lib.xdfm_last_error()
-    rc = _lib.lib.xdfm_embed_fwd(None, None, 10, 4, 2, 1, None, None, None, 0, None, None, None,
+    rc = _lib.lib.xdfm_embed_fwd(None, None, 0, 0, 10, 4, 2, 1, None, None, None, 0, None, None, None,
                                  None, None, None)
     assert rc == -1 and b"null" in _lib.lib.xdfm_last_error()
 

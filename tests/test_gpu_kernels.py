@@ -146,7 +146,7 @@ def test_forward_and_gradients_match_oracle(name, loss):
     use_lin, use_fm = bool(hp.use_Linear_part), bool(hp.use_FM_part)
     opt = eng._opt_args()
     _lib.check(eng.lib.xdfm_embed_bwd(
-        1, _ptr(eng.table), None, None, None, None, None, _ptr(eng.grad_table),
+        1, _ptr(eng.table), None, None, None, None, None, eng.table_stride, eng.lin_stride, _ptr(eng.grad_table),
         _ptr(eng.grad_lin) if use_lin else None, eng.N, eng.D, eng.F, db.B, _ptr(db.sorted_ids),
         _ptr(db.sorted_tok), _ptr(db.tok_row), _ptr(db.weights), db.nnz, _ptr(eng.ws["d_emb"]),
         _ptr(eng.ws["g_logit"]) if (use_lin or use_fm) else None,
