@@ -216,7 +216,11 @@ def main():
     def eager_step(i):
         labels, idx, ids, w = resident[i % n_batches]
         batch = eng.make_batch(labels, idx, ids, w)  # CSR offsets built on the device
-        return eng.train_step(batch)  # N > 1: includes the all-to-all exchanges and the all-reduce
+        if world > 1 or args.sharded:
+            # N > 1: the all-to-all exchanges and the all-reduce are in the step; the routing of
+            # the next batch's ids starts beside this step's compute
+            return eng.train_step(batch, next_ids=resident[(i + 1) % n_batches][2])
+        return eng.train_step(batch)
 
     graphed = None
     if world == 1 and not args.no_graph and not args.sharded:

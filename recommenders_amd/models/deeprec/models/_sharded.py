@@ -110,8 +110,9 @@ class RowShardExchange(object):
         send_counts = torch.bincount(dest, minlength=G)
         recv_counts = torch.empty_like(send_counts)
         self._a2a(recv_counts, send_counts)
-        plan.send_counts = [int(v) for v in send_counts.tolist()]
-        plan.recv_counts = [int(v) for v in recv_counts.tolist()]  # host sync: sizes of the exchange
+        both = torch.stack([send_counts, recv_counts]).tolist()  # the step's one host sync: exchange sizes
+        plan.send_counts = [int(v) for v in both[0]]
+        plan.recv_counts = [int(v) for v in both[1]]
         plan.order = order
         inverse = torch.empty_like(order)
         inverse[order] = torch.arange(n, dtype=order.dtype, device=order.device)
@@ -163,6 +164,8 @@ class ShardedXDeepFMEngine(XDeepFMEngine):
         self.dropout_seed ^= (0x632BE59BD9B4E019 * self.rank) & (2 ** 64 - 1)  # ranks draw different masks
         self._consts = {}
         self._owner_ws = {}
+        self._route_stream = None
+        self._route_pre = None
         # forward + backward + per-token gradients have fixed shapes once the rows are fetched:
         # they replay as one HIP graph between the (variable-size) exchanges
         self.graph_local = True
@@ -198,7 +201,9 @@ class ShardedXDeepFMEngine(XDeepFMEngine):
         hp, lib, st = self.hp, self.lib, self._stream()
         D = self.D
         use_lin = bool(hp.use_Linear_part)
-        plan = self.exchange.route(batch.ids)
+        plan = self._take_prefetched_route(batch.ids)
+        if plan is None:
+            plan = self.exchange.route(batch.ids)
         n_recv = plan.n_recv
         rows_out = torch.empty((n_recv, D), dtype=torch.float32, device=self.device)
         lin_out = torch.empty((n_recv,), dtype=torch.float32, device=self.device) if use_lin else None
@@ -228,6 +233,35 @@ class ShardedXDeepFMEngine(XDeepFMEngine):
         else:
             batch.src_ids = plan.inverse
         batch.src_N = max(batch.nnz, 1)
+
+    def prefetch_route(self, ids):
+        """Route the ids of the NEXT batch (ids to their owners, exchange sizes to the host) on a
+        stream of its own while this step computes: the one host synchronisation of a step then
+        waits for a few small kernels instead of for everything enqueued before it, and the host
+        can enqueue the next step while the GPU still works on this one.  Every rank must call
+        it at the same point of its step (it issues collectives)."""
+        if ids is None or (self.world == 1 and self.exchange.virtual_world == 1):
+            return
+        if self._route_stream is None:
+            self._route_stream = torch.cuda.Stream(device=self.device)
+        rs = self._route_stream
+        with torch.cuda.stream(rs):  # the ids of a later batch do not depend on this step
+            plan = self.exchange.route(ids)
+            done = torch.cuda.Event()
+            done.record(rs)
+        self._route_pre = (ids, plan, done)
+
+    def _take_prefetched_route(self, ids):
+        pre, self._route_pre = self._route_pre, None
+        if pre is None or pre[0] is not ids:
+            return None
+        _, plan, done = pre
+        main = torch.cuda.current_stream(self.device)
+        main.wait_event(done)
+        for t in (plan.order, plan.inverse, plan.recv_rows):
+            if torch.is_tensor(t) and t.is_cuda:
+                t.record_stream(main)  # allocated on the route stream, read on this one
+        return plan
 
     def _arange64(self, n):
         t = self._consts.get("arange64")
@@ -334,10 +368,12 @@ class ShardedXDeepFMEngine(XDeepFMEngine):
             self._local_graphs[key] = g
         return g
 
-    def train_step(self, batch):
+    def train_step(self, batch, next_ids=None):
         """One optimisation step on this rank's share of the global batch.  Returns this
         rank's (total_loss share, data_loss share) as device scalars: their sum over the ranks
-        is the global mean loss (regularisation counted once, on rank 0's share)."""
+        is the global mean loss (regularisation counted once, on rank 0's share).
+        next_ids: the ids tensor of the batch the next call will get (the same object as its
+        batch.ids): its routing is started beside this step's compute (prefetch_route)."""
         self.mean_count = batch.B * self.world
         g = None
         if self.graph_local and self.kernel_events is None and batch.nnz > 0:
@@ -357,6 +393,7 @@ class ShardedXDeepFMEngine(XDeepFMEngine):
                     g.graph = None
             if g.graph is not None:
                 g.graph.replay()
+                self.prefetch_route(next_ids)
                 self._advance_step()
                 self._owner_update(batch, g.send_g, g.send_gl)
             else:
@@ -365,12 +402,14 @@ class ShardedXDeepFMEngine(XDeepFMEngine):
                 batch.src_N = max(batch.nnz, 1)
                 self.forward(batch, with_loss=True, with_grad=True)
                 self.backward(batch)
+                self.prefetch_route(next_ids)
                 self._advance_step()
                 self._update_embedding(batch)
         else:
             self.fetch_rows(batch)
             self.forward(batch, with_loss=True, with_grad=True)
             self.backward(batch)
+            self.prefetch_route(next_ids)
             self._advance_step()
             self._update_embedding(batch)
         self.join_late()

@@ -92,12 +92,18 @@ def _two_rank_worker(rank, world, port, optimizer, out):
         st = X.new_opt_state(p64, hp)
         rng = np.random.default_rng(21)  # every rank draws the same global batches
         per = 48
+        steps = []
         for step in range(3):
             labels, feats = random_features(rng, per * world, F, N)
             for toks in feats[:8]:
                 toks.append([0, 5, 1.0])  # a row that several ranks touch in one step
             mine = O.convert(labels[rank * per:(rank + 1) * per], feats[rank * per:(rank + 1) * per], F, N)
-            loss, dloss = eng.train_step(_upload(eng, mine))
+            steps.append((labels, feats, _upload(eng, mine)))
+        for step, (labels, feats, dev_batch) in enumerate(steps):
+            # the next batch's ids are routed beside this step (prefetch_route), except the last one's
+            nxt = steps[step + 1][2].ids if step + 1 < len(steps) else None
+            loss, dloss = eng.train_step(dev_batch, next_ids=nxt)
+            assert (eng._route_pre is not None) == (nxt is not None)
             tot = torch.stack([loss, dloss]).double().cpu()
             dist.all_reduce(tot)
             o_loss, o_dl, _, _ = X.train_step(p64, st, O.convert(labels, feats, F, N), hp, mode="sparse_rows")
