@@ -19,6 +19,7 @@ arrays it yields have the reference's dtypes, shapes and ordering.
 
 import abc
 import ctypes
+import os
 
 import numpy as np
 
@@ -82,6 +83,8 @@ class FFMTextIterator(BaseIterator):
         self.ID_spliter = ID_spliter
         self.batch_size = hparams.batch_size
         self.graph = graph
+        self._parsed = {}        # (path, size, mtime, batch size, F, N) -> [(feed_dict, impressions, n)]
+        self._parsed_bytes = {}
 
         self.labels = Placeholder(np.float32, [None, 1], "label")
         self.fm_feat_indices = Placeholder(np.int64, [None, 2], "fm_feat_indices")
@@ -120,9 +123,47 @@ class FFMTextIterator(BaseIterator):
         shuffled.  Malformed text raises ``ValueError`` (with the line number).
         """
         if len(self.col_spliter) == 1 and len(self.ID_spliter) == 1:
-            yield from self._load_native(infile)
+            yield from self._load_cached(infile)
         else:
             yield from self._load_python(infile)
+
+    def _load_cached(self, infile):
+        """The native reader behind a cache of parsed batches: `fit()` reads its files once per
+        epoch, and parsing text is an order of magnitude slower than the training step, so the
+        batches of a file that fits the budget (XDFM_FFM_CACHE_MB of host memory, default 4096,
+        0 = off) are kept and yielded again while the file is unchanged (same size and mtime).
+        The feed dicts themselves are kept, so whatever the model attached to them (the batch in
+        device memory, its sort plan) is reused as well."""
+        budget = int(os.environ.get("XDFM_FFM_CACHE_MB", "4096")) << 20
+        if budget <= 0:
+            yield from self._load_native(infile)
+            return
+        try:
+            st = os.stat(infile)
+        except OSError:
+            yield from self._load_native(infile)  # raises the reader's own error
+            return
+        key = (os.path.abspath(str(infile)), st.st_size, st.st_mtime_ns, int(self.batch_size),
+               int(self.field_cnt), int(self.feature_cnt))
+        hit = self._parsed.get(key)
+        if hit is not None:
+            yield from hit
+            return
+        kept, held, size = [], sum(self._parsed_bytes.values()), 0
+        for item in self._load_native(infile):
+            if kept is not None:
+                size += sum(v.nbytes for v in item[0].values() if isinstance(v, np.ndarray))
+                if held + size > budget:
+                    kept = None  # too large: stream it, as the reference does
+                else:
+                    kept.append(item)
+            yield item
+        if kept is not None:
+            for k in [k for k in self._parsed if k[0] == key[0]]:  # older versions of this file
+                del self._parsed[k]
+                del self._parsed_bytes[k]
+            self._parsed[key] = kept
+            self._parsed_bytes[key] = size
 
     def _load_python(self, infile):
         label_list, features_list, impression_id_list = [], [], []

@@ -133,3 +133,40 @@ def test_field_out_of_range_aliases_like_reference(tmp_path):
     for k in KEYS:
         assert np.array_equal(feed[getattr(it, k)], arrays[k]), k
     assert feed.row_ptr is None or len(feed.row_ptr) == n * 3 + 1
+
+
+def test_parsed_batches_are_kept_while_the_file_is_unchanged(tmp_path, monkeypatch):
+    """Second pass over an unchanged file: the very same feed dicts (nothing is parsed again);
+    a rewritten file is parsed again; XDFM_FFM_CACHE_MB=0 streams every time."""
+    import os
+
+    from recommenders_amd.models.deeprec.io.iterator import FFMTextIterator
+    from tests.util import make_hp, random_features, write_libffm
+
+    hp = make_hp(batch_size=16)
+    rng = np.random.default_rng(3)
+    labels, feats = random_features(rng, 40, hp.FIELD_COUNT, hp.FEATURE_COUNT)
+    path = write_libffm(str(tmp_path / "a.ffm"), labels, feats)
+    it = FFMTextIterator(hp, None)
+    first = list(it.load_data_from_file(path))
+    second = list(it.load_data_from_file(path))
+    assert [n for (_, _, n) in first] == [16, 16, 8]
+    assert all(a[0] is b[0] for a, b in zip(first, second)) and len(first) == len(second)
+    # same content as an iterator that never saw the file
+    fresh = list(FFMTextIterator(hp, None).load_data_from_file(path))
+    for (fa, ia, na), (fb, ib, nb) in zip(second, fresh):
+        assert na == nb and ia == ib
+        for (ka, va), (kb, vb) in zip(sorted(fa.items(), key=lambda kv: kv[0].name),
+                                      sorted(fb.items(), key=lambda kv: kv[0].name)):
+            assert ka.name == kb.name and np.array_equal(va, vb)
+    # the file changes: parsed again
+    labels2, feats2 = random_features(rng, 20, hp.FIELD_COUNT, hp.FEATURE_COUNT)
+    write_libffm(path, labels2, feats2)
+    os.utime(path, ns=(1, 1))
+    third = list(it.load_data_from_file(path))
+    assert [n for (_, _, n) in third] == [16, 4] and third[0][0] is not first[0][0]
+    monkeypatch.setenv("XDFM_FFM_CACHE_MB", "0")
+    it2 = FFMTextIterator(hp, None)
+    a = list(it2.load_data_from_file(path))
+    b = list(it2.load_data_from_file(path))
+    assert a[0][0] is not b[0][0] and not it2._parsed

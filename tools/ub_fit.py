@@ -37,23 +37,28 @@ if __name__ == "__main__":
     train = write("/tmp/ub_fit_train.ffm", n_train, 0)
     valid = write("/tmp/ub_fit_valid.ffm", 8192 * 2, 1)
     print("train file: %d lines, %.1f MB" % (n_train, os.path.getsize(train) / 1e6), flush=True)
-    hp = prepare_hparams(
-        None, model_type="xDeepFM", data_format="ffm", FEATURE_COUNT=1 << 25, FIELD_COUNT=39, dim=16,
-        layer_sizes=[20, 20], cross_layer_sizes=[20, 10], activation=["relu", "relu"], dropout=[0.0, 0.0],
-        loss="log_loss", method="classification", metrics=["auc", "logloss"], use_Linear_part=True,
-        use_FM_part=True, use_CIN_part=True, use_DNN_part=True, init_method="tnormal", init_value=0.1,
-        learning_rate=0.002, optimizer="adam", embed_l2=0.0, layer_l2=0.0, cross_l2=0.01, batch_size=B,
-        epochs=3, save_model=False, show_step=1000000, embedding_update="sparse_rows")
-    model = XDeepFMModel(hp, FFMTextIterator, seed=3)
-    buf = io.StringIO()
-    t0 = time.perf_counter()
-    with redirect_stdout(buf):
-        model.fit(train, valid)
-    total = time.perf_counter() - t0
-    out = buf.getvalue()
-    times = [float(x) for x in re.findall(r"train time: ([0-9.]+)", out)]
-    print(out.strip().splitlines()[-1])
-    print("fit(): %d epochs in %.2f s; train time per epoch %s s" % (hp.epochs, total, times))
-    lines = hp.epochs * (n_train + 8192 * 2)  # every epoch trains on the train file and scores the valid file
-    print("fit() on text: %.0f lines/s over the whole call (reader + H2D + train step / scoring + metrics)"
-          % (lines / total))
+    def run(epochs):
+        hp = prepare_hparams(
+            None, model_type="xDeepFM", data_format="ffm", FEATURE_COUNT=1 << 25, FIELD_COUNT=39, dim=16,
+            layer_sizes=[20, 20], cross_layer_sizes=[20, 10], activation=["relu", "relu"], dropout=[0.0, 0.0],
+            loss="log_loss", method="classification", metrics=["auc", "logloss"], use_Linear_part=True,
+            use_FM_part=True, use_CIN_part=True, use_DNN_part=True, init_method="tnormal", init_value=0.1,
+            learning_rate=0.002, optimizer="adam", embed_l2=0.0, layer_l2=0.0, cross_l2=0.01, batch_size=B,
+            epochs=epochs, save_model=False, show_step=1000000, embedding_update="sparse_rows")
+        model = XDeepFMModel(hp, FFMTextIterator, seed=3)
+        buf = io.StringIO()
+        t0 = time.perf_counter()
+        with redirect_stdout(buf):
+            model.fit(train, valid)
+        return time.perf_counter() - t0, buf.getvalue().strip().splitlines()[-1]
+
+    per_epoch = n_train + 8192 * 2  # every epoch trains on the train file and scores the valid file
+    run(1)  # warm the page cache and the library
+    t1, _ = run(1)
+    t10, last = run(10)
+    print(last)
+    print("fit(), 1 epoch : %.3f s = %.0f lines/s (text parsed: reader + H2D + step / scoring + metrics)"
+          % (t1, per_epoch / t1))
+    later = (t10 - t1) / 9
+    print("fit(), 10 epochs: %.3f s; epochs 2..10: %.4f s each = %.0f lines/s (parsed batches and their device "
+          "copies kept by the iterator, XDFM_FFM_CACHE_MB)" % (t10, later, per_epoch / later))
