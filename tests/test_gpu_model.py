@@ -131,6 +131,23 @@ def test_fit_auc_logloss_parity_with_oracle(resources, parts):
     assert np.abs(preds - exp_preds).max() < 2e-3
 
 
+def test_fit_with_kept_batches_equals_fit_that_parses_every_epoch(resources, monkeypatch):
+    """The iterator's parsed-batch cache (and the device batches / sort plans attached to its feed
+    dicts) must not change a bit of the result."""
+    yaml_file, data_file, d = resources
+    hp = prepare_hparams(yaml_file, epochs=3)
+    outs = []
+    for budget in ("4096", "0"):
+        monkeypatch.setenv("XDFM_FFM_CACHE_MB", budget)
+        model = XDeepFMModel(hp, FFMTextIterator, seed=11)
+        model.fit(data_file, data_file)
+        assert bool(model.iterator._parsed) == (budget != "0")
+        out = str(d / ("pred_cache_%s.txt" % budget))
+        model.predict(data_file, out)
+        outs.append(open(out).read())
+    assert outs[0] == outs[1]
+
+
 def test_save_and_load_model(resources):
     yaml_file, data_file, d = resources
     hp = prepare_hparams(yaml_file, epochs=2, save_model=True, save_epoch=1, MODEL_DIR=str(d / "ckpt"))
