@@ -136,7 +136,7 @@ class FFMTextIterator(BaseIterator):
         device memory, its sort plan) is reused as well."""
         budget = int(os.environ.get("XDFM_FFM_CACHE_MB", "4096")) << 20
         if budget <= 0:
-            yield from self._load_native(infile)
+            yield from self._read_ahead(self._load_native(infile))
             return
         try:
             st = os.stat(infile)
@@ -150,7 +150,7 @@ class FFMTextIterator(BaseIterator):
             yield from hit
             return
         kept, held, size = [], sum(self._parsed_bytes.values()), 0
-        for item in self._load_native(infile):
+        for item in self._read_ahead(self._load_native(infile)):
             if kept is not None:
                 size += sum(v.nbytes for v in item[0].values() if isinstance(v, np.ndarray))
                 if held + size > budget:
@@ -164,6 +164,51 @@ class FFMTextIterator(BaseIterator):
                 del self._parsed_bytes[k]
             self._parsed[key] = kept
             self._parsed_bytes[key] = size
+
+    @staticmethod
+    def _read_ahead(gen, depth=2):
+        """Run a batch generator in a thread, `depth` batches ahead of its consumer: the native
+        reader parses (outside the GIL) while the caller uploads and enqueues the previous batch."""
+        import queue
+        import threading
+
+        q = queue.Queue(maxsize=depth)
+        stop = threading.Event()
+        end = object()
+
+        def put(item):
+            while not stop.is_set():
+                try:
+                    q.put(item, timeout=0.1)
+                    return True
+                except queue.Full:
+                    continue
+            return False
+
+        def work():
+            try:
+                for item in gen:
+                    if not put((item, None)):
+                        return
+                put((end, None))
+            except BaseException as exc:  # noqa: BLE001 -- handed to the consumer
+                put((end, exc))
+            finally:
+                gen.close()
+
+        t = threading.Thread(target=work, name="xdfm-ffm-reader", daemon=True)
+        t.start()
+        try:
+            while True:
+                item, exc = q.get()
+                if item is end:
+                    if exc is not None:
+                        raise exc
+                    return
+                yield item
+        finally:
+            stop.set()
+            t.join(timeout=5)
 
     def _load_python(self, infile):
         label_list, features_list, impression_id_list = [], [], []
