@@ -493,6 +493,25 @@ extern "C" int xdfm_ffm_next(xdfm_ffm_reader* r, int64_t batch_size, xdfm_ffm_ba
   return XDFM_OK;
 }
 
+// fn(lo, hi) over [0, n) on up to T threads (the arrays of a batch are tens of megabytes: one
+// core's store bandwidth is what the fill is bound by)
+template <typename Fn>
+static void par_ranges(size_t n, int T, Fn fn) {
+  if (T > 8) T = 8;
+  if (T <= 1 || n < ((size_t)1 << 16)) {
+    fn((size_t)0, n);
+    return;
+  }
+  std::vector<std::thread> pool;
+  const size_t per = (n + (size_t)T - 1) / (size_t)T;
+  for (int t = 0; t < T; ++t) {
+    const size_t lo = (size_t)t * per, hi = std::min(n, lo + per);
+    if (lo >= hi) break;
+    pool.emplace_back([fn, lo, hi]() { fn(lo, hi); });
+  }
+  for (auto& th : pool) th.join();
+}
+
 extern "C" int xdfm_ffm_fill(xdfm_ffm_reader* r, float* labels, int64_t* fm_feat_indices,
                              float* fm_feat_values, int64_t* dnn_feat_indices,
                              int64_t* dnn_feat_values, float* dnn_feat_weights,
@@ -502,21 +521,23 @@ extern "C" int xdfm_ffm_fill(xdfm_ffm_reader* r, float* labels, int64_t* fm_feat
   const size_t n = r->st.labels.size();
   const size_t nnz = r->st.dnn_row.size();
   if (labels) memcpy(labels, r->st.labels.data(), n * sizeof(float));
-  if (fm_feat_indices)
-    for (size_t k = 0; k < nnz; ++k) {
-      fm_feat_indices[2 * k] = r->st.tok_sample[k];
-      fm_feat_indices[2 * k + 1] = r->st.tok_feat[k];
+  par_ranges(nnz, r->threads, [=](size_t lo, size_t hi) {
+    if (fm_feat_indices)
+      for (size_t k = lo; k < hi; ++k) {
+        fm_feat_indices[2 * k] = r->st.tok_sample[k];
+        fm_feat_indices[2 * k + 1] = r->st.tok_feat[k];
+      }
+    if (fm_feat_values) memcpy(fm_feat_values + lo, r->st.tok_val.data() + lo, (hi - lo) * sizeof(float));
+    for (size_t k = lo; k < hi; ++k) {
+      const uint32_t s = r->order[k];
+      if (dnn_feat_indices) {
+        dnn_feat_indices[2 * k] = r->st.dnn_row[s];
+        dnn_feat_indices[2 * k + 1] = r->st.dnn_col[s];
+      }
+      if (dnn_feat_values) dnn_feat_values[k] = r->st.tok_feat[s];
+      if (dnn_feat_weights) dnn_feat_weights[k] = r->st.tok_val[s];
     }
-  if (fm_feat_values) memcpy(fm_feat_values, r->st.tok_val.data(), nnz * sizeof(float));
-  for (size_t k = 0; k < nnz; ++k) {
-    const uint32_t s = r->order[k];
-    if (dnn_feat_indices) {
-      dnn_feat_indices[2 * k] = r->st.dnn_row[s];
-      dnn_feat_indices[2 * k + 1] = r->st.dnn_col[s];
-    }
-    if (dnn_feat_values) dnn_feat_values[k] = r->st.tok_feat[s];
-    if (dnn_feat_weights) dnn_feat_weights[k] = r->st.tok_val[s];
-  }
+  });
   if (row_ptr) {
     const int64_t rows = (int64_t)n * r->F;
     XDFM_REQUIRE(rows + 1 < (int64_t)1 << 31 && nnz < ((size_t)1 << 31),

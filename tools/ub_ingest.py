@@ -49,6 +49,7 @@ if __name__ == "__main__":
     print("file: %d lines, %.1f MB" % (n, os.path.getsize(path) / 1e6))
     for t in ("1", "4", "16", None):
         env = dict(os.environ)
+        env["XDFM_FFM_CACHE_MB"] = "0"  # the reader itself: no kept batches
         if t is None:
             env.pop("XDFM_PARSE_THREADS", None)
         else:
