@@ -265,7 +265,6 @@ class XDeepFMEngine(object):
         self.prepack = os.environ.get("XDFM_CIN_PREPACK", "1") != "0"
         self.split_dw = os.environ.get("XDFM_SPLIT_DW", "1") != "0"
         self._late_event = None
-        self._pack_jobs = None
         self.overlap_dnn = self.overlap_dnn_wanted(hp)
         self.mean_count = 0  # set by the sharded engine: global batch size of the step
         self.init_parameters(seed)
