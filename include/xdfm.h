@@ -288,9 +288,15 @@ int xdfm_cin_bwd(const float* x0, const float* xk, const float* w, int64_t B, in
  *   xdfm_cin_bwd_packed: dw_part sized by xdfm_cin_bwd_workspace_floats as for xdfm_cin_bwd.
  *     phases: XDFM_CIN_BWD_DX (d_xk, d_x0), XDFM_CIN_BWD_DW (d_w) or both.  The two read the same
  *     inputs and share no output, so a caller may run them on different streams (the filter
- *     gradient beside whatever consumes d_x0 next). */
+ *     gradient beside whatever consumes d_x0 next).
+ *     XDFM_CIN_BWD_DW = XDFM_CIN_BWD_DW_PARTIAL (per-split partial sums into dw_part) followed by
+ *     XDFM_CIN_BWD_DW_REDUCE (dw_part -> d_w); the reduction is a short kernel that nothing but
+ *     the optimizer waits for, so a caller may give it to another stream as well (dw_part must
+ *     stay untouched in between). */
 #define XDFM_CIN_BWD_DX 1
 #define XDFM_CIN_BWD_DW 2
+#define XDFM_CIN_BWD_DW_PARTIAL 4
+#define XDFM_CIN_BWD_DW_REDUCE 8
 typedef struct xdfm_cin_pack_job {
   const float* w;    /* [F*H, L] */
   int32_t F, H, L, masked;

@@ -500,7 +500,7 @@ extern "C" int xdfm_cin_bwd_packed(const float* x0, const float* xk, const float
                                    int32_t phases, void* stream) {
   int rc = check_dims("xdfm_cin_bwd_packed", B, F, H, D, L, n_hidden, masked);
   if (rc) return rc;
-  XDFM_REQUIRE(phases >= 1 && phases <= 3, "xdfm_cin_bwd_packed: phases must be 1, 2 or 3");
+  XDFM_REQUIRE(phases >= 1 && phases <= 15, "xdfm_cin_bwd_packed: phases is a mask of XDFM_CIN_BWD_*");
   XDFM_REQUIRE(x0 && xk && bwd_image && d_x0 && d_w && dw_part, "xdfm_cin_bwd_packed: null argument");
   XDFM_REQUIRE(n_hidden == 0 || d_xnext, "xdfm_cin_bwd_packed: d_xnext is null");
   XDFM_REQUIRE(n_hidden == L || d_pooled, "xdfm_cin_bwd_packed: d_pooled is null");
@@ -509,7 +509,8 @@ extern "C" int xdfm_cin_bwd_packed(const float* x0, const float* xk, const float
   XDFM_REQUIRE(xdfm_cin::mfma_supported(B, F, H, D, L), "xdfm_cin_bwd_packed: this shape has no packed path");
   hipStream_t st = (hipStream_t)stream;
   if (B == 0) {
-    if (phases & XDFM_CIN_BWD_DW) XDFM_HIP(hipMemsetAsync(d_w, 0, (size_t)F * H * L * sizeof(float), st));
+    if (phases & (XDFM_CIN_BWD_DW | XDFM_CIN_BWD_DW_REDUCE))
+      XDFM_HIP(hipMemsetAsync(d_w, 0, (size_t)F * H * L * sizeof(float), st));
     return XDFM_OK;
   }
   CinDims c{B, F, H, D, L, n_hidden, masked};

@@ -1197,6 +1197,8 @@ int bwd_mfma(const CinDims& c, const float* x0, const float* xk, const float* w,
   XDFM_REQUIRE(w || (packed_dx && dx2_applies(c.F, c.H, c.L, shared_x)),
                "xdfm_cin_bwd_packed: this shape has no packed input-gradient path");
   XDFM_REQUIRE(phases == 3 || !w, "xdfm_cin_bwd: the phases split needs the packed path");
+  const bool dw_partial = (phases & (XDFM_CIN_BWD_DW | XDFM_CIN_BWD_DW_PARTIAL)) != 0;
+  const bool dw_reduce = (phases & (XDFM_CIN_BWD_DW | XDFM_CIN_BWD_DW_REDUCE)) != 0;
   if (!(phases & 1)) {
     // filter gradient only
   } else if (nft <= 10 && S <= 5 && dx2_lds <= kLdsLimit) {
@@ -1285,12 +1287,8 @@ int bwd_mfma(const CinDims& c, const float* x0, const float* xk, const float* w,
 #undef CALL_S
 #undef CALL_P
   }
-  if (!(phases & 2)) {
-    XDFM_LAUNCH_CHECK();
-    return XDFM_OK;
-  }
   // ---- filter gradient
-  {
+  if (dw_partial) {
 #define CALLW(PTV, NTV, XUV)                                                                          \
   do {                                                                                                \
     int rc = allow_lds(cin_bwd_dw_mfma_kernel<PTV, NTV, XUV>, dw_lds);                                \
@@ -1315,7 +1313,7 @@ int bwd_mfma(const CinDims& c, const float* x0, const float* xk, const float* w,
     }
 #undef CALLW
   }
-  {
+  if (dw_reduce) {
     const int64_t total = (int64_t)c.F * c.H * c.L;
     XDFM_LAUNCH("cin_dw_unpack_kernel", st, cin_dw_unpack_kernel, dim3((unsigned)((total + 31) / 32)),
                 dim3(256), 0, c, part, n_splits, d_w);

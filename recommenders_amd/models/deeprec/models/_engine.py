@@ -956,7 +956,18 @@ class XDeepFMEngine(object):
                                                     _ptr(gv["cin_f_%d" % k]), _ptr(ws["part"]), phases, stream)
                         )
 
-                    if k == 0 and dnn_done is not None and self.split_dw:
+                    side_dw = dnn_done is not None and self.split_dw
+                    if k == 1 and side_dw and "img_b_0" in ws:
+                        # the reduction of this layer's filter-gradient partials is a short kernel
+                        # that only the optimizer waits for: the side stream runs it (and is the
+                        # next writer of the partials' buffer, with the first layer's gradient)
+                        layer_bwd(1 | 4, st)
+                        part_done = torch.cuda.Event()
+                        part_done.record(torch.cuda.current_stream(self.device))
+                        side.wait_event(part_done)
+                        with torch.cuda.stream(side):
+                            layer_bwd(8, self._stream())
+                    elif k == 0 and side_dw:
                         # the last layer's filter gradient (matrix-core bound) leaves the critical
                         # path: it runs on the side stream beside the table gradient / update
                         # (latency bound), which only needs d_emb
