@@ -447,12 +447,18 @@ int xdfm_logit_loss(const float* part0, const float* part1, const float* part2,
  * computed here from pooled[B,n], head_w[n], head_b[1]; writes cin_out[B], logit, pred, g_logit,
  * d_pooled[B,n] and the mean loss.  part0 / part1 / part3 and bias as in xdfm_logit_loss.
  *   scratch: 1025 floats; element 1024 (a block counter) must be zero before the first call and
- *   is left zero by every call.  square_loss runs the separate kernels (it needs the mean first). */
+ *   is left zero by every call.  square_loss runs the separate kernels (it needs the mean first).
+ *   loss = NULL defers the mean: the call leaves its per-block partial sums in scratch and
+ *   xdfm_loss_finish(scratch, B, mean_count, loss_kind, loss, stream), with the same B, mean_count and
+ *   loss_kind, adds them up in the same order -- on any stream ordered after this call and before
+ *   the next one that uses scratch; nothing in a training step waits for the loss value. */
 int xdfm_head_loss(const float* part0, const float* part1, const float* part3, const float* bias,
                    const float* pooled, const float* head_w, const float* head_b, int32_t n,
                    const float* labels, int64_t B, int64_t mean_count, int32_t classification,
                    int32_t loss_kind, float* logit, float* pred, float* cin_out, float* g_logit,
                    float* d_pooled, float* loss, float* scratch, void* stream);
+int xdfm_loss_finish(const float* scratch, int64_t B, int64_t mean_count, int32_t loss_kind, float* loss,
+                     void* stream);
 
 /* ------------------------------------------------------------------------
  * Fused evaluation: AUC (ties grouped, == sklearn.roc_auc_score) and logloss

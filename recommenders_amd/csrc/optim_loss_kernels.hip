@@ -374,6 +374,10 @@ __global__ __launch_bounds__(kHeadThreads) void head_loss_kernel(LossArgs a, Hea
     }
   }
   acc = block_sum<float, kHeadThreads>(acc, sh);
+  if (!counter) {  // the caller finishes the mean elsewhere (xdfm_loss_finish)
+    if (threadIdx.x == 0) partial[blockIdx.x] = acc;
+    return;
+  }
   if (threadIdx.x == 0) {
     partial[blockIdx.x] = acc;
     __threadfence();
@@ -389,6 +393,20 @@ __global__ __launch_bounds__(kHeadThreads) void head_loss_kernel(LossArgs a, Hea
   if (threadIdx.x == 0) {
     if (loss_out) *loss_out = s / (float)a.mean_count;
     *counter = 0u;  // ready for the next launch
+  }
+}
+
+// the mean of a deferred xdfm_head_loss: partials in index order, as its last block would add them
+__global__ __launch_bounds__(kHeadThreads) void loss_finish_kernel(const float* __restrict__ partial, int n,
+                                                                   float count, int root,
+                                                                   float* __restrict__ loss_out) {
+  __shared__ float sh[kHeadThreads];
+  float s = 0.f;
+  for (int k = threadIdx.x; k < n; k += kHeadThreads) s += partial[k];
+  s = block_sum<float, kHeadThreads>(s, sh);
+  if (threadIdx.x == 0) {
+    const float mean = s / count;
+    *loss_out = root ? sqrtf(mean) : mean;
   }
 }
 
@@ -708,7 +726,22 @@ extern "C" int xdfm_head_loss(const float* part0, const float* part1, const floa
   if (blocks > 1024) blocks = 1024;
   XDFM_LAUNCH("head_loss_kernel", (hipStream_t)stream, head_loss_kernel, dim3((unsigned)blocks), dim3(kHeadThreads), 0,
               a, h,
-              scratch, reinterpret_cast<unsigned*>(scratch + 1024), loss);
+              scratch, loss ? reinterpret_cast<unsigned*>(scratch + 1024) : nullptr, loss);
+  XDFM_LAUNCH_CHECK();
+  return XDFM_OK;
+}
+
+extern "C" int xdfm_loss_finish(const float* scratch, int64_t B, int64_t mean_count, int32_t loss_kind,
+                                float* loss, void* stream) {
+  XDFM_REQUIRE(scratch && loss && B > 0, "xdfm_loss_finish: bad argument");
+  XDFM_REQUIRE(loss_kind >= XDFM_LOSS_LOG && loss_kind <= XDFM_LOSS_SQUARE, "xdfm_loss_finish: unknown loss %d",
+               loss_kind);
+  // as many partial sums as the call being finished wrote: one per block of its first pass
+  const int per = loss_kind == XDFM_LOSS_SQUARE ? 256 : kHeadThreads;
+  long long blocks = (B + per - 1) / per;
+  if (blocks > 1024) blocks = 1024;
+  XDFM_LAUNCH("loss_finish_kernel", (hipStream_t)stream, loss_finish_kernel, dim3(1), dim3(kHeadThreads), 0, scratch,
+              (int)blocks, (float)(mean_count > 0 ? mean_count : B), loss_kind == XDFM_LOSS_SQUARE ? 1 : 0, loss);
   XDFM_LAUNCH_CHECK();
   return XDFM_OK;
 }

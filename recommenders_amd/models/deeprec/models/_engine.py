@@ -705,9 +705,12 @@ class XDeepFMEngine(object):
                     ws["pooled"].shape[1], _ptr(batch.labels), B, int(self.mean_count or 0),
                     1 if hp.method == "classification" else 0, _LOSS[hp.loss], _ptr(ws["logit"]),
                     _ptr(ws["pred"]), _ptr(ws["cin_out"]), _ptr(ws["g_logit"]), _ptr(ws["d_pooled"]),
-                    _ptr(self.data_loss), _ptr(self.loss_scratch), st,
+                    None if self.overlap_dnn else _ptr(self.data_loss), _ptr(self.loss_scratch), st,
                 )
             )
+            # with a side stream the mean of the loss is finished there (backward()): no kernel
+            # of the step waits for that value
+            self._loss_deferred = self.overlap_dnn
             self._done(ev)
             return ws["pred"][:B]
         _lib.check(
@@ -887,6 +890,10 @@ class XDeepFMEngine(object):
             side = self._branch_stream()
             with torch.cuda.stream(side):
                 st = self._stream()
+                if getattr(self, "_loss_deferred", False):
+                    _lib.check(lib.xdfm_loss_finish(_ptr(self.loss_scratch), B, int(self.mean_count or 0),
+                                                    _LOSS[hp.loss], _ptr(self.data_loss), st))
+                    self._loss_deferred = False
                 if fused_head:
                     small_grads(ws["part_dnn"])
                 self._dnn_backward(B, (ws["d_emb_dnn"], 0))
