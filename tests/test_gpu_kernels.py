@@ -436,13 +436,13 @@ def test_eval_auc_logloss_matches_cal_metric(golden):
         assert abs(auc - exact) < 1e-15
 
 
-@pytest.mark.parametrize("dropout", [False, True])
+@pytest.mark.parametrize("dropout", [False, True, "bn"])
 def test_graph_replay_equals_eager_steps(dropout):
     """A step captured into a HIP graph (device-side Adam scalars, side-stream sort joined
     inside the capture) must reproduce the eager launches bit for bit.  With dropout the masks
     are a function of (seed, device-side step count, element): replays draw the eager masks."""
     hp = make_hp(optimizer="adam", learning_rate=0.01, FEATURE_COUNT=400, cross_l2=0.01,
-                 user_dropout=dropout, dropout=[0.2, 0.4])
+                 user_dropout=(dropout is True), dropout=[0.2, 0.4], enable_BN=(dropout == "bn"))
     rng = np.random.default_rng(12)
     p32 = X.init_params(hp, seed=4)
     from oracle import ffm_iterator_oracle as O
@@ -469,4 +469,5 @@ def test_graph_replay_equals_eager_steps(dropout):
     assert losses_g == losses_e[1:]
     assert torch.equal(eager.table, graph.table) and torch.equal(eager.dense, graph.dense)
     assert torch.equal(eager.table_m, graph.table_m) and torch.equal(eager.lin_w, graph.lin_w)
+    assert all(torch.equal(eager.bn_state[k], graph.bn_state[k]) for k in eager.bn_state)  # moving statistics
     assert graph.state_dict()["step"] == 3 and abs(graph.state_dict()["b1p"] - 0.9 ** 3) < 1e-6
