@@ -7,9 +7,13 @@
 //   xDeepFM.py:153-158  FM second order term
 //   base_model.py:290/:286/:288 + :314-322  Adam / Adagrad / SGD apply_gradients on the table
 //
-// HBM layout: table[N][D] fp32 row-major (one shared table for all fields), lin_w[N],
-// optimizer slots with the same shapes.  emb_out[B][F][D].  The dnn view of a batch is
-// CSR: row_ptr[B*F+1] over tokens (ids int64, weights fp32), rows = sample*F+field.
+// HBM layout: one shared table for all fields, fp32; row id at table + id*TS, its linear weight at
+// lin_w + id*LS, optimizer slots at the same offsets from their own base pointers.  TS = D, LS = 1
+// are the dense arrays table[N][D], lin_w[N]; a caller that updates sparse rows keeps a row, its
+// linear weight and their slots in one record of whole 128-byte lines and passes pointers into
+// it with TS = LS = the record length (every random row access costs a whole line: two lines
+// per updated row instead of six).  emb_out[B][F][D].  The dnn view of a batch is CSR:
+// row_ptr[B*F+1] over tokens (ids int64, weights fp32), rows = sample*F+field.
 #include <hip/hip_runtime.h>
 
 #include <cstring>
