@@ -183,8 +183,15 @@ class BaseModel:
 
         Prints the same per-epoch lines as the reference (:513-535).  Returns ``self``.
         """
+        # write_tfevents (:448-450, :467-468, :537-538): the reference hands its merged summary (the
+        # scalars data_loss, regular_loss, loss of _add_summaries) to a TF FileWriter every step.
+        # Without TensorFlow the same scalars go to SUMMARIES_DIR/events.jsonl, one JSON object per
+        # step (the step count restarts every epoch there as well, so the epoch is recorded too);
+        # they are fetched from the device once per epoch, not once per step.
+        events = None
         if self.hparams.write_tfevents:
-            raise NotImplementedError("write_tfevents needs TensorFlow summaries; not supported")
+            os.makedirs(self.hparams.SUMMARIES_DIR, exist_ok=True)
+            events = open(join(self.hparams.SUMMARIES_DIR, "events.jsonl"), "a")
 
         train_sess = self.sess
         for epoch in range(1, self.hparams.epochs + 1):
@@ -192,12 +199,15 @@ class BaseModel:
             self.hparams.current_epoch = epoch
 
             epoch_loss = 0
+            logged = []
             train_start = time.time()
             for batch_data_input, impression, data_size in self.iterator.load_data_from_file(train_file):
                 step_result = self.train(train_sess, batch_data_input)
                 (_, _, step_loss, step_data_loss, summary) = step_result
                 epoch_loss = epoch_loss + step_loss
                 step += 1
+                if events is not None:
+                    logged.append(torch.stack([step_loss, step_data_loss]))
                 if step % self.hparams.show_step == 0:
                     print(
                         "step {0:d} , total_loss: {1:.4f}, data_loss: {2:.4f}".format(
@@ -206,6 +216,13 @@ class BaseModel:
                     )
             epoch_loss = float(epoch_loss)  # synchronises once per epoch
             self.engine.check_errors()
+            if events is not None and logged:
+                import json
+
+                for k, (tot, dat) in enumerate(torch.stack(logged).cpu().tolist(), 1):
+                    events.write(json.dumps({"epoch": epoch, "step": k, "loss": tot, "data_loss": dat,
+                                             "regular_loss": tot - dat}) + "\n")
+                events.flush()
             train_end = time.time()
             train_time = train_end - train_start
 
@@ -250,6 +267,8 @@ class BaseModel:
                     epoch, train_time, eval_time
                 )
             )
+        if events is not None:
+            events.close()
         return self
 
     def group_labels(self, labels, preds, group_keys):

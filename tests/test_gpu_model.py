@@ -148,6 +148,24 @@ def test_fit_with_kept_batches_equals_fit_that_parses_every_epoch(resources, mon
     assert outs[0] == outs[1]
 
 
+def test_write_tfevents_writes_the_summary_scalars_without_tensorflow(resources):
+    """write_tfevents (base_model.py:448-450, :467-468): the merged summary's scalars, one record per
+    training step, in SUMMARIES_DIR/events.jsonl."""
+    import json
+
+    yaml_file, data_file, d = resources
+    hp = prepare_hparams(yaml_file, epochs=2, write_tfevents=True, SUMMARIES_DIR=str(d / "events"))
+    model = XDeepFMModel(hp, FFMTextIterator, seed=2)
+    model.fit(data_file, data_file)
+    recs = [json.loads(line) for line in open(str(d / "events" / "events.jsonl"))]
+    n_steps = sum(1 for _ in model.iterator.load_data_from_file(data_file))
+    assert len(recs) == 2 * n_steps
+    assert [r["epoch"] for r in recs] == [1] * n_steps + [2] * n_steps
+    assert [r["step"] for r in recs[:n_steps]] == list(range(1, n_steps + 1))
+    assert all(np.isfinite(r["loss"]) and r["loss"] >= r["data_loss"] - 1e-7 for r in recs)
+    assert recs[-1]["data_loss"] < recs[0]["data_loss"]  # it trains
+
+
 def test_save_and_load_model(resources):
     yaml_file, data_file, d = resources
     hp = prepare_hparams(yaml_file, epochs=2, save_model=True, save_epoch=1, MODEL_DIR=str(d / "ckpt"))
