@@ -78,6 +78,14 @@ def test_sparse_sgd_update_checksums_and_untouched_rows(setup):
     eng.update(db)
     torch.cuda.synchronize()
     eng.check_errors()
+    # the id sort behind the segment sum: keys ascending, tokens a permutation that carries the ids,
+    # equal keys in token order (stable)
+    sk, st_ = db.sorted_ids[:db.nnz].long(), db.sorted_tok[:db.nnz].long()
+    assert bool((sk[1:] >= sk[:-1]).all())
+    assert torch.equal(torch.sort(st_).values, torch.arange(db.nnz, device="cuda"))
+    assert torch.equal(ids[st_], sk)
+    same = sk[1:] == sk[:-1]
+    assert bool((st_[1:][same] > st_[:-1][same]).all())
     delta = (eng.table.double() - before.double())
     exp = -hp.learning_rate * contrib.sum(0)
     got = delta.sum(0)
