@@ -153,10 +153,13 @@ int xdfm_embed_fwd(const float* table, const float* lin_w, int64_t table_stride,
 /* Plain row gather: out[i,:] = table[rows[i],:], lin_out[i] = lin_w[rows[i]] (NULL ok).
  * No counterpart in the reference (one device, one table): it is the owner-side lookup of the
  * row-sharded table ("owners run K1 locally"), the same copy xdfm_embed_fwd
- * does with one token of weight 1 per row, without spending a wave per row. */
+ * does with one token of weight 1 per row, without spending a wave per row.
+ * out_stride: floats between consecutive rows of `out` and between consecutive entries of
+ * `lin_out` (0 = dense D / 1): with out and lin_out pointing into one buffer of
+ * [row | linear weight | pad] records, rows and weights travel in one all-to-all. */
 int xdfm_embed_gather(const float* table, const float* lin_w, int64_t table_stride,
-                      int64_t lin_stride, int64_t N, int32_t D, const int64_t* rows, int64_t n, float* out, float* lin_out,
-                      int32_t* err_flag, void* stream);
+                      int64_t lin_stride, int64_t N, int32_t D, const int64_t* rows, int64_t n, float* out,
+                      float* lin_out, int64_t out_stride, int32_t* err_flag, void* stream);
 
 /* ------------------------------------------------------------------------
  * Embedding backward: deterministic sorted-key segment sum (+ row update).

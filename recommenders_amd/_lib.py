@@ -94,7 +94,7 @@ SIGNATURES = {
     "xdfm_ffm_close": [_P],
     "xdfm_build_row_ptr": [_P, _I64, _I64, _P, _P, _P, _P],
     "xdfm_embed_fwd": [_P, _P, _I64, _I64, _I64, _I32, _I32, _I64, _P, _P, _P, _I64, _P, _P, _P, _P, _P, _P],
-    "xdfm_embed_gather": [_P, _P, _I64, _I64, _I64, _I32, _P, _I64, _P, _P, _P, _P],
+    "xdfm_embed_gather": [_P, _P, _I64, _I64, _I64, _I32, _P, _I64, _P, _P, _I64, _P, _P],
     "xdfm_embed_plan_workspace_bytes": [_I64, _I64, _PSZ],
     "xdfm_embed_plan": [_P, _I64, _I64, _P, _P, _P, _SZ, _P],
     "xdfm_embed_bwd": [_I32, _P, _P, _P, _P, _P, _P, _I64, _I64, _P, _P, _I64, _I32, _I32, _I64, _P, _P, _P,

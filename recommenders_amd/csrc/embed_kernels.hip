@@ -696,7 +696,8 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restric
                                                           int64_t LS, int64_t N, int D,
                                                           const int64_t* __restrict__ rows,
                                                           int64_t n, float* __restrict__ out,
-                                                          float* __restrict__ lin_out, int32_t* err_flag) {
+                                                          float* __restrict__ lin_out, int64_t OS, int64_t OLS,
+                                                          int32_t* err_flag) {
   const int LPR = D / VEC;
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t r = t / LPR;
@@ -709,14 +710,14 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restric
   }
   float e[VEC];
   load_vec<VEC>(table + id * TS + c * VEC, e);
-  store_vec<VEC>(out + r * D + c * VEC, e);
-  if (lin_out && c == 0) lin_out[r] = lin_w[id * LS];
+  store_vec<VEC>(out + r * OS + c * VEC, e);
+  if (lin_out && c == 0) lin_out[r * OLS] = lin_w[id * LS];
 }
 
 extern "C" int xdfm_embed_gather(const float* table, const float* lin_w, int64_t table_stride,
                                  int64_t lin_stride, int64_t N, int32_t D,
                                  const int64_t* rows, int64_t n, float* out, float* lin_out,
-                                 int32_t* err_flag, void* stream) {
+                                 int64_t out_stride, int32_t* err_flag, void* stream) {
   XDFM_REQUIRE(table && out && err_flag, "xdfm_embed_gather: null argument");
   XDFM_REQUIRE(N > 0 && D > 0 && n >= 0, "xdfm_embed_gather: bad sizes");
   XDFM_REQUIRE(!lin_out || lin_w, "xdfm_embed_gather: lin_out needs lin_w");
@@ -724,11 +725,15 @@ extern "C" int xdfm_embed_gather(const float* table, const float* lin_w, int64_t
   XDFM_REQUIRE(rows, "xdfm_embed_gather: null rows");
   const int vec = pick_vec(D);
   XDFM_REQUIRE(strides_ok(&table_stride, &lin_stride, D, vec), "xdfm_embed_gather: bad row strides");
+  // out_stride: floats between consecutive output rows AND between consecutive lin_out entries
+  // (one buffer of [row | linear weight | pad] records goes through one all-to-all); 0 = dense
+  XDFM_REQUIRE(out_stride == 0 || (out_stride >= D && out_stride % vec == 0), "xdfm_embed_gather: bad out_stride");
+  const int64_t os = out_stride ? out_stride : D, ols = out_stride ? out_stride : 1;
   const int64_t threads = n * (D / vec);
   const unsigned blocks = (unsigned)((threads + 255) / 256);
 #define LAUNCH(V)                                                                                          \
   XDFM_LAUNCH("gather_rows_kernel<" #V ">", stream, gather_rows_kernel<V>, dim3(blocks), dim3(256), 0, table, \
-              lin_out ? lin_w : nullptr, table_stride, lin_stride, N, D, rows, n, out, lin_out, err_flag)
+              lin_out ? lin_w : nullptr, table_stride, lin_stride, N, D, rows, n, out, lin_out, os, ols, err_flag)
   if (vec == 4)
     LAUNCH(4);
   else if (vec == 2)

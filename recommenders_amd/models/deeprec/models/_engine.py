@@ -613,8 +613,8 @@ class XDeepFMEngine(object):
             lib.xdfm_embed_fwd(
                 _ptr(batch.src_table if batch.src_table is not None else self.table),
                 _ptr(batch.src_lin if batch.src_table is not None else self.lin_w) if use_lin else None,
-                0 if batch.src_table is not None else self.table_stride,
-                0 if batch.src_table is not None else self.lin_stride,
+                batch.src_table.stride(0) if batch.src_table is not None else self.table_stride,
+                (batch.src_lin.stride(0) if use_lin else 0) if batch.src_table is not None else self.lin_stride,
                 batch.src_N if batch.src_table is not None else self.N, D, F, B,
                 _ptr(batch.row_ptr), _ptr(batch.src_ids if batch.src_table is not None else batch.ids),
                 _ptr(batch.weights), batch.nnz,

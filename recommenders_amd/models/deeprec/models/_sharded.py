@@ -205,15 +205,16 @@ class ShardedXDeepFMEngine(XDeepFMEngine):
         if plan is None:
             plan = self.exchange.route(batch.ids)
         n_recv = plan.n_recv
-        rows_out = torch.empty((n_recv, D), dtype=torch.float32, device=self.device)
-        lin_out = torch.empty((n_recv,), dtype=torch.float32, device=self.device) if use_lin else None
+        # [row | linear weight | pad] records: rows and weights come back in one all-to-all
+        DP = D + 4 if use_lin else D
+        comb = torch.empty((n_recv, DP), dtype=torch.float32, device=self.device)
         if n_recv:
             ev = self._mark("owner_gather")
             _lib.check(
                 lib.xdfm_embed_gather(
                     _ptr(self.table), _ptr(self.lin_w) if use_lin else None, self.table_stride, self.lin_stride,
-                    self.N, D, _ptr(plan.recv_rows),
-                    n_recv, _ptr(rows_out), _ptr(lin_out) if use_lin else None, _ptr(self.err_flag), st,
+                    self.N, D, _ptr(plan.recv_rows), n_recv, _ptr(comb), _ptr(comb[:, D]) if use_lin else None,
+                    DP if use_lin else 0, _ptr(self.err_flag), st,
                 )
             )
             self._done(ev)
@@ -221,13 +222,12 @@ class ShardedXDeepFMEngine(XDeepFMEngine):
         # owner-side sort of the received row ids: runs beside the forward pass
         self._owner_plan_async(batch)
         if static is not None:
-            self.exchange.to_source(plan, rows_out, out=static.src_table)
-            if use_lin:
-                self.exchange.to_source(plan, lin_out, out=static.src_lin)
+            self.exchange.to_source(plan, comb, out=static.src_comb)
             static.src_ids.copy_(self._arange64(batch.nnz)[:batch.nnz] if plan.inverse is None else plan.inverse)
             return
-        batch.src_table = self.exchange.to_source(plan, rows_out)
-        batch.src_lin = self.exchange.to_source(plan, lin_out) if use_lin else None
+        src = self.exchange.to_source(plan, comb)
+        batch.src_table = src[:, :D]
+        batch.src_lin = src[:, D] if use_lin else None
         if plan.inverse is None:
             batch.src_ids = self._arange64(batch.nnz)
         else:
@@ -309,7 +309,7 @@ class ShardedXDeepFMEngine(XDeepFMEngine):
         ev = self._mark("token_grads")
         _lib.check(
             lib.xdfm_embed_bwd(
-                1, _ptr(batch.src_table), None, None, None, None, None, 0, 0, _ptr(send_g),
+                1, _ptr(batch.src_table), None, None, None, None, None, batch.src_table.stride(0), 0, _ptr(send_g),
                 _ptr(send_gl) if use_lin else None, max(nnz, 1), D, self.F, batch.B,
                 _ptr(self._arange32(nnz)), _ptr(order32), _ptr(batch.tok_row), _ptr(batch.weights), nnz,
                 _ptr(ws["d_emb"]), _ptr(ws["g_logit"]) if (use_lin or use_fm) else None,
@@ -467,8 +467,9 @@ class _LocalGraph(object):
         use_lin = bool(eng.hp.use_Linear_part)
         f32 = torch.float32
         self.eng = eng
-        self.src_table = torch.zeros((nnz, D), dtype=f32, device=dev)
-        self.src_lin = torch.zeros((nnz,), dtype=f32, device=dev) if use_lin else None
+        self.src_comb = torch.zeros((nnz, D + 4 if use_lin else D), dtype=f32, device=dev)
+        self.src_table = self.src_comb[:, :D]
+        self.src_lin = self.src_comb[:, D] if use_lin else None
         self.src_ids = torch.zeros((nnz,), dtype=torch.int64, device=dev)
         self.order32 = torch.zeros((nnz,), dtype=torch.int32, device=dev)
         self.send_g = torch.zeros((nnz, D), dtype=f32, device=dev)
