@@ -208,7 +208,11 @@ int xdfm_opt_advance(float* opt_state, float lr, float beta1, float beta2, void*
  *   cross a 64-token chunk boundary).
  *   d_emb[B,F,D]; d_emb2: NULL, or a second [B,F,D] array added to d_emb as it is read (two
  *   producers, e.g. the CIN and the DNN tower, then need no common accumulator);
- *   g_logit[B] and fm_sum[B,D] only when the FM / linear parts are on. */
+ *   g_logit[B] and fm_sum[B,D] only when the FM / linear parts are on.
+ *   grad_stride (0 = dense): floats between consecutive gradient records.  Mode 1 then writes
+ *   row i at grad_table + i*grad_stride and its linear gradient at grad_lin + i*grad_stride;
+ *   mode 0 reads d_emb / d_emb2 rows and g_logit entries at that stride (the owner side of the
+ *   row-sharded table gets [gradient row | linear gradient | pad] records from one all-to-all). */
 int xdfm_embed_bwd(int32_t mode, float* table, float* slot_m, float* slot_v, float* lin_w,
                    float* lin_m, float* lin_v, int64_t table_stride, int64_t lin_stride,
                    float* grad_table, float* grad_lin, int64_t N,
@@ -216,7 +220,7 @@ int xdfm_embed_bwd(int32_t mode, float* table, float* slot_m, float* slot_v, flo
                    const int32_t* sorted_tok, const int32_t* tok_row, const float* weights,
                    int64_t nnz, const float* d_emb, const float* g_logit, const float* fm_sum,
                    int32_t use_fm, const xdfm_opt_args* opt, float* pieces, const float* d_emb2,
-                   void* stream);
+                   int64_t grad_stride, void* stream);
 /* zero the rows of grad_table / grad_lin named by sorted_ids (restores the all-zero invariant) */
 int xdfm_embed_clear_rows(float* grad_table, float* grad_lin, int32_t D,
                           const int32_t* sorted_ids, int64_t nnz, void* stream);

@@ -349,6 +349,7 @@ struct BwdArgs {
   float *table, *slot_m, *slot_v, *lin_w, *lin_m, *lin_v, *grad_table, *grad_lin;
   int64_t N, B, nnz;
   int64_t TS, LS;  // row strides (floats) of table / slots and of lin_w / its slots
+  int64_t GS, GLS;  // strides of the gradient rows / scalars this call reads (mode 0) or writes (mode 1)
   int D, F;
   const int32_t *sorted_ids, *sorted_tok, *tok_row;
   const float *weights, *d_emb, *d_emb2, *g_logit, *fm_sum;
@@ -369,9 +370,9 @@ __device__ __forceinline__ void finish_row(const BwdArgs& a, int id, int c, cons
       apply_row<1>(a.opt, a.lin_w + lo, a.lin_m + lo, a.lin_v + lo, g1);
     }
   } else {
-    const int64_t off = (int64_t)id * a.D + c * VEC;  // the gradient image is always [N][D]
+    const int64_t off = (int64_t)id * a.GS + c * VEC;
     store_vec<VEC>(a.grad_table + off, acc);
-    if (a.grad_lin && c == 0) a.grad_lin[id] = lacc;
+    if (a.grad_lin && c == 0) a.grad_lin[(int64_t)id * a.GLS] = lacc;
   }
 }
 
@@ -415,7 +416,7 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(BwdArgs a) {
   const int row = a.tok_row[tok];
   const float w = pv ? a.weights[tok] : 0.f;
   float gw = 0.f;
-  if (need_g) gw = pv ? a.g_logit[row / a.F] * w : 0.f;
+  if (need_g) gw = pv ? a.g_logit[(int64_t)(row / a.F) * (MODE == 0 ? a.GLS : 1)] * w : 0.f;
   const int prev_key = (p0 > 0) ? a.sorted_ids[p0 - 1] : -1;
   const int next_key = (p0 + kChunk < a.nnz) ? a.sorted_ids[p0 + kChunk] : -2;
   const int first_key = __shfl(key, 0);
@@ -477,10 +478,11 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(BwdArgs a) {
     for (int k = 0; k < VEC; ++k) v[k] = 0.f;
     if (on) {
       float de[VEC];
-      load_vec<VEC>(a.d_emb + (int64_t)row_q * a.D + c * VEC, de);
+      const int64_t ds = MODE == 0 ? a.GS : (int64_t)a.D;  // mode 1 writes records, it reads dense rows
+      load_vec<VEC>(a.d_emb + (int64_t)row_q * ds + c * VEC, de);
       if (a.d_emb2) {  // a second producer's gradient (the DNN tower's), summed on the fly
         float de2[VEC];
-        load_vec<VEC>(a.d_emb2 + (int64_t)row_q * a.D + c * VEC, de2);
+        load_vec<VEC>(a.d_emb2 + (int64_t)row_q * ds + c * VEC, de2);
 #pragma unroll
         for (int k = 0; k < VEC; ++k) de[k] += de2[k];
       }
@@ -794,7 +796,7 @@ extern "C" int xdfm_embed_bwd(int32_t mode, float* table, float* slot_m, float* 
                               const int32_t* tok_row, const float* weights, int64_t nnz,
                               const float* d_emb, const float* g_logit, const float* fm_sum,
                               int32_t use_fm, const xdfm_opt_args* opt, float* pieces,
-                              const float* d_emb2, void* stream) {
+                              const float* d_emb2, int64_t grad_stride, void* stream) {
   XDFM_REQUIRE(mode == 0 || mode == 1, "xdfm_embed_bwd: mode must be 0 or 1");
   XDFM_REQUIRE(N > 0 && D > 0 && F > 0 && B >= 0 && nnz >= 0, "xdfm_embed_bwd: bad sizes");
   if (nnz == 0) return XDFM_OK;
@@ -853,6 +855,9 @@ extern "C" int xdfm_embed_bwd(int32_t mode, float* table, float* slot_m, float* 
   XDFM_REQUIRE(strides_ok(&table_stride, &lin_stride, D, vec), "xdfm_embed_bwd: bad row strides");
   a.TS = table_stride;
   a.LS = lin_stride;
+  XDFM_REQUIRE(grad_stride == 0 || (grad_stride >= D && grad_stride % vec == 0), "xdfm_embed_bwd: bad grad_stride");
+  a.GS = grad_stride ? grad_stride : D;
+  a.GLS = grad_stride ? grad_stride : 1;
   hipStream_t st = (hipStream_t)stream;
   const int64_t nchunks = (nnz + kChunk - 1) / kChunk;
   const unsigned blocks = (unsigned)((nchunks + 3) / 4);

@@ -1060,7 +1060,7 @@ class XDeepFMEngine(object):
                 _ptr(batch.weights), batch.nnz, _ptr(ws["d_emb"]),
                 _ptr(ws["g_logit"]) if (use_lin or use_fm) else None,
                 _ptr(ws["fm_sum"]) if use_fm else None, 1 if use_fm else 0,
-                ctypes.byref(opt_sparse), _ptr(ws["pieces"]), _ptr(self.d_emb2()), st,
+                ctypes.byref(opt_sparse), _ptr(ws["pieces"]), _ptr(self.d_emb2()), 0, st,
             )
         )
         self._done(ev)

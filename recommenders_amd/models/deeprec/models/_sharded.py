@@ -297,9 +297,14 @@ class ShardedXDeepFMEngine(XDeepFMEngine):
             batch.owner_event = torch.cuda.Event()
             batch.owner_event.record(self._side_stream)
 
-    def _token_grads(self, batch, order32, send_g, send_gl):
-        """Per-token gradient rows in partition order (segment i = token order[i]) into send_g /
-        send_gl; `batch` carries src_table, tok_row, weights."""
+    def _grad_records(self, nnz):
+        """[gradient row | linear gradient | pad] per token: one buffer, one all-to-all."""
+        DP = self.D + 4 if self.hp.use_Linear_part else self.D
+        return torch.empty((max(nnz, 1), DP), dtype=torch.float32, device=self.device)
+
+    def _token_grads(self, batch, order32, send_c):
+        """Per-token gradient records in partition order (segment i = token order[i]) into
+        send_c; `batch` carries src_table, tok_row, weights."""
         hp, lib, ws, st = self.hp, self.lib, self.ws, self._stream()
         D, nnz = self.D, batch.nnz
         use_lin, use_fm = bool(hp.use_Linear_part), bool(hp.use_FM_part)
@@ -309,17 +314,17 @@ class ShardedXDeepFMEngine(XDeepFMEngine):
         ev = self._mark("token_grads")
         _lib.check(
             lib.xdfm_embed_bwd(
-                1, _ptr(batch.src_table), None, None, None, None, None, batch.src_table.stride(0), 0, _ptr(send_g),
-                _ptr(send_gl) if use_lin else None, max(nnz, 1), D, self.F, batch.B,
+                1, _ptr(batch.src_table), None, None, None, None, None, batch.src_table.stride(0), 0, _ptr(send_c),
+                _ptr(send_c[:, D]) if use_lin else None, max(nnz, 1), D, self.F, batch.B,
                 _ptr(self._arange32(nnz)), _ptr(order32), _ptr(batch.tok_row), _ptr(batch.weights), nnz,
                 _ptr(ws["d_emb"]), _ptr(ws["g_logit"]) if (use_lin or use_fm) else None,
                 _ptr(ws["fm_sum"]) if use_fm else None, 1 if use_fm else 0, ctypes.byref(opt),
-                _ptr(ws["pieces"]), _ptr(self.d_emb2()), st,
+                _ptr(ws["pieces"]), _ptr(self.d_emb2()), send_c.stride(0) if use_lin else 0, st,
             )
         )
         self._done(ev)
 
-    def _owner_update(self, batch, send_g, send_gl):
+    def _owner_update(self, batch, send_c):
         """Gradient rows to their owners, then the owner's sorted-key segment sum over what
         arrived + fused sparse row optimizer."""
         hp, lib, st = self.hp, self.lib, self._stream()
@@ -327,8 +332,7 @@ class ShardedXDeepFMEngine(XDeepFMEngine):
         use_lin = bool(hp.use_Linear_part)
         plan = batch.route
         opt = self._opt_args()
-        recv_g = self.exchange.to_owner(plan, send_g[:nnz])
-        recv_gl = self.exchange.to_owner(plan, send_gl[:nnz]) if use_lin else None
+        recv_c = self.exchange.to_owner(plan, send_c[:nnz])
         n = plan.n_recv
         if n:
             if batch.owner_event is not None:
@@ -342,21 +346,19 @@ class ShardedXDeepFMEngine(XDeepFMEngine):
                     _ptr(self.lin_v) if use_lin else None, self.table_stride, self.lin_stride, None, None,
                     self.N, D, 1, n,
                     _ptr(batch.owner_sorted_ids), _ptr(batch.owner_sorted_tok), _ptr(self._arange32(n)),
-                    _ptr(self._ones(n)), n, _ptr(recv_g), _ptr(recv_gl) if use_lin else None, None, 0,
-                    ctypes.byref(opt), _ptr(pieces), None, st,
+                    _ptr(self._ones(n)), n, _ptr(recv_c), _ptr(recv_c[:, D]) if use_lin else None, None, 0,
+                    ctypes.byref(opt), _ptr(pieces), None, recv_c.stride(0) if use_lin else 0, st,
                 )
             )
             self._done(ev)
 
     def _update_embedding(self, batch):
-        nnz, D = batch.nnz, self.D
+        nnz = batch.nnz
         plan = batch.route
-        send_g = torch.empty((max(nnz, 1), D), dtype=torch.float32, device=self.device)
-        send_gl = (torch.empty((max(nnz, 1),), dtype=torch.float32, device=self.device)
-                   if self.hp.use_Linear_part else None)
+        send_c = self._grad_records(nnz)
         order32 = (self._arange32(nnz) if plan.order is None else plan.order.to(torch.int32))
-        self._token_grads(batch, order32, send_g, send_gl)
-        self._owner_update(batch, send_g, send_gl)
+        self._token_grads(batch, order32, send_c)
+        self._owner_update(batch, send_c)
         return True
 
     # ------------------------------------------------------ graph of the local part
@@ -395,7 +397,7 @@ class ShardedXDeepFMEngine(XDeepFMEngine):
                 g.graph.replay()
                 self.prefetch_route(next_ids)
                 self._advance_step()
-                self._owner_update(batch, g.send_g, g.send_gl)
+                self._owner_update(batch, g.send_c)
             else:
                 # the fetched rows already sit in g's buffers: finish this step without the graph
                 batch.src_table, batch.src_lin, batch.src_ids = g.src_table, g.src_lin, g.src_ids
@@ -472,8 +474,7 @@ class _LocalGraph(object):
         self.src_lin = self.src_comb[:, D] if use_lin else None
         self.src_ids = torch.zeros((nnz,), dtype=torch.int64, device=dev)
         self.order32 = torch.zeros((nnz,), dtype=torch.int32, device=dev)
-        self.send_g = torch.zeros((nnz, D), dtype=f32, device=dev)
-        self.send_gl = torch.zeros((nnz,), dtype=f32, device=dev) if use_lin else None
+        self.send_c = torch.zeros((nnz, D + 4 if use_lin else D), dtype=f32, device=dev)
         sb = DeviceBatch()
         sb.B, sb.nnz = B, nnz
         sb.labels = torch.zeros_like(batch.labels)
@@ -507,7 +508,7 @@ class _LocalGraph(object):
         eng = self.eng
         eng.forward(self.batch, with_loss=True, with_grad=True)
         eng.backward(self.batch)
-        eng._token_grads(self.batch, self.order32, self.send_g, self.send_gl)
+        eng._token_grads(self.batch, self.order32, self.send_c)
         eng.join_late()  # every fork is joined before a capture ends
 
     def load(self, batch):

@@ -151,7 +151,7 @@ def test_forward_and_gradients_match_oracle(name, loss):
         _ptr(db.sorted_tok), _ptr(db.tok_row), _ptr(db.weights), db.nnz, _ptr(eng.ws["d_emb"]),
         _ptr(eng.ws["g_logit"]) if (use_lin or use_fm) else None,
         _ptr(eng.ws["fm_sum"]) if use_fm else None, 1 if use_fm else 0, ctypes.byref(opt),
-        _ptr(eng.ws["pieces"]), _ptr(eng.d_emb2()), eng._stream()))
+        _ptr(eng.ws["pieces"]), _ptr(eng.d_emb2()), 0, eng._stream()))
     torch.cuda.synchronize()
     eng.check_errors()
 
