@@ -17,7 +17,6 @@
 #include <hip/hip_runtime.h>
 
 #include <cstring>
-#include <rocprim/rocprim.hpp>
 
 #include "xdfm_common.h"
 
@@ -229,25 +228,6 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(
     }
   }
 }
-
-// ---------------------------------------------------------------- plan
-__global__ void plan_keys_kernel(const int64_t* __restrict__ ids, int64_t nnz, int64_t N,
-                                 uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
-  const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= nnz) return;
-  int64_t id = ids[k];
-  id = id < 0 ? 0 : (id >= N ? N - 1 : id);  // out-of-range ids are flagged by the forward
-  keys[k] = (uint32_t)id;
-  vals[k] = (uint32_t)k;
-}
-
-inline unsigned key_bits(int64_t N) {
-  unsigned bits = 1;
-  while (bits < 32 && ((int64_t)1 << bits) < N) ++bits;
-  return bits;
-}
-
-inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 // ---------------------------------------------------------------- backward
 struct OptDev {
@@ -744,47 +724,6 @@ extern "C" int xdfm_embed_gather(const float* table, const float* lin_w, int64_t
     LAUNCH(1);
 #undef LAUNCH
   XDFM_LAUNCH_CHECK();
-  return XDFM_OK;
-}
-
-extern "C" int xdfm_embed_plan_workspace_bytes(int64_t nnz, int64_t N, size_t* bytes) {
-  XDFM_REQUIRE(bytes && nnz >= 0 && N > 0, "xdfm_embed_plan_workspace_bytes: bad argument");
-  size_t tmp = 0;
-  uint32_t* nul = nullptr;
-  hipError_t e = rocprim::radix_sort_pairs(nullptr, tmp, nul, nul, nul, nul, (size_t)nnz, 0u,
-                                           key_bits(N), (hipStream_t)0, false);
-  if (e != hipSuccess) return xdfm::fail(XDFM_E_HIP, "rocprim size query failed");
-  *bytes = 2 * align_up((size_t)nnz * sizeof(uint32_t), 256) + align_up(tmp, 256) + 256;
-  return XDFM_OK;
-}
-
-extern "C" int xdfm_embed_plan(const int64_t* ids, int64_t nnz, int64_t N, int32_t* sorted_ids,
-                               int32_t* sorted_tok, void* plan_ws, size_t plan_ws_bytes,
-                               void* stream) {
-  XDFM_REQUIRE(nnz >= 0 && N > 0 && N <= ((int64_t)1 << 31), "xdfm_embed_plan: bad sizes");
-  if (nnz == 0) return XDFM_OK;
-  XDFM_REQUIRE(ids && sorted_ids && sorted_tok && plan_ws, "xdfm_embed_plan: null argument");
-  size_t need = 0;
-  int rc = xdfm_embed_plan_workspace_bytes(nnz, N, &need);
-  if (rc) return rc;
-  if (plan_ws_bytes < need)
-    return xdfm::fail(XDFM_E_WORKSPACE, "xdfm_embed_plan: workspace %zu < %zu", plan_ws_bytes, need);
-  const size_t seg = align_up((size_t)nnz * sizeof(uint32_t), 256);
-  char* base = (char*)plan_ws;
-  uint32_t* keys = (uint32_t*)base;
-  uint32_t* vals = (uint32_t*)(base + seg);
-  void* tmp = base + 2 * seg;
-  size_t tmp_bytes = plan_ws_bytes - 2 * seg;
-  hipStream_t st = (hipStream_t)stream;
-  XDFM_LAUNCH("plan_keys_kernel", st, plan_keys_kernel, dim3((unsigned)((nnz + 255) / 256)), dim3(256), 0, ids,
-                     nnz, N, keys, vals);
-  XDFM_LAUNCH_CHECK();
-  {
-    xdfm::ProfScope prof_scope_("rocprim::radix_sort_pairs(plan)", (void*)st);
-    XDFM_HIP(rocprim::radix_sort_pairs(tmp, tmp_bytes, keys, (uint32_t*)sorted_ids, vals,
-                                       (uint32_t*)sorted_tok, (size_t)nnz, 0u, key_bits(N), st,
-                                       false));
-  }
   return XDFM_OK;
 }
 
