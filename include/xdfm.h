@@ -14,7 +14,7 @@
  *  - device pointers are plain `void*`-compatible pointers into HBM owned by the
  *    caller (PyTorch-ROCm allocations in the Python host); nothing is retained
  *    after a call returns, nothing is allocated or freed by the library on the
- *    device (the sort workspaces are sized by *_workspace_bytes and passed in).
+ *    device (workspaces are sized by *_workspace_bytes and passed in).
  *  - `stream` is a hipStream_t passed as void*; all device entry points only
  *    enqueue work on it and return without synchronising.
  *  - all floating point tensors are IEEE fp32, row-major, densely packed.
@@ -173,6 +173,14 @@ int xdfm_embed_plan_workspace_bytes(int64_t nnz, int64_t N, size_t* bytes);
  *   sorted_ids[nnz] int32, sorted_tok[nnz] int32 (token index into ids/weights) */
 int xdfm_embed_plan(const int64_t* ids, int64_t nnz, int64_t N, int32_t* sorted_ids,
                     int32_t* sorted_tok, void* plan_ws, size_t plan_ws_bytes, void* stream);
+/* xdfm_embed_plan for callers that cannot allocate or size a workspace (code under HIP graph
+ * capture, tight serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference.
+ * Same kernels, same output bit for bit; the sort's scratch is a file-scope __device__ array of
+ * 9 MiB that every GPU the library runs on holds until the process ends.  At most 524 288 tokens
+ * (XDFM_E_WORKSPACE beyond).  The first call on a device resolves the array's device address (make
+ * it outside a capture); calls that overlap on one GPU share the scratch and race. */
+int xdfm_embed_plan_static(const int64_t* ids, int64_t nnz, int64_t N, int32_t* sorted_ids,
+                           int32_t* sorted_tok, void* stream);
 
 typedef struct xdfm_opt_args {
   int32_t kind;       /* XDFM_OPT_* */

@@ -97,6 +97,7 @@ SIGNATURES = {
     "xdfm_embed_gather": [_P, _P, _I64, _I64, _I64, _I32, _P, _I64, _P, _P, _I64, _P, _P],
     "xdfm_embed_plan_workspace_bytes": [_I64, _I64, _PSZ],
     "xdfm_embed_plan": [_P, _I64, _I64, _P, _P, _P, _SZ, _P],
+    "xdfm_embed_plan_static": [_P, _I64, _I64, _P, _P, _P],
     "xdfm_embed_bwd": [_I32, _P, _P, _P, _P, _P, _P, _I64, _I64, _P, _P, _I64, _I32, _I32, _I64, _P, _P, _P,
                        _P, _I64, _P, _P, _P, _I32, ctypes.POINTER(OptArgs), _P, _P, _I64, _P],
     "xdfm_embed_clear_rows": [_P, _P, _I32, _P, _I64, _P],
