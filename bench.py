@@ -213,14 +213,21 @@ def main():
     nnz = int(resident[0][2].numel())
     uniq = float(np.mean([len(np.unique(hb["dnn_feat_values"])) for hb in host_batches]))
 
+    pending = {}
+
     def eager_step(i):
         labels, idx, ids, w = resident[i % n_batches]
-        batch = eng.make_batch(labels, idx, ids, w)  # CSR offsets built on the device
+        batch = pending.pop(i, None)
+        if batch is None:
+            batch = eng.make_batch(labels, idx, ids, w)  # CSR offsets built on the device
         if world > 1 or args.sharded:
             # N > 1: the all-to-all exchanges and the all-reduce are in the step; the routing of
             # the next batch's ids starts beside this step's compute
             return eng.train_step(batch, next_ids=resident[(i + 1) % n_batches][2])
-        return eng.train_step(batch)
+        if getattr(eng, "catchup_on", False):
+            # the following batch is announced: its id sort runs beside this step
+            pending[i + 1] = eng.make_batch(*resident[(i + 1) % n_batches])
+        return eng.train_step(batch, next_batch=pending.get(i + 1))
 
     graphed = None
     if world == 1 and not args.no_graph and not args.sharded:
@@ -232,7 +239,7 @@ def main():
 
     def step(i):
         if graphed is not None:
-            return graphed.run_packed(packed[i % n_batches])
+            return graphed.run_packed(packed[i % n_batches], packed[(i + 1) % n_batches])
         return eager_step(i)
 
     def fence():

@@ -229,6 +229,23 @@ int xdfm_embed_bwd(int32_t mode, float* table, float* slot_m, float* slot_v, flo
                    int64_t nnz, const float* d_emb, const float* g_logit, const float* fm_sum,
                    int32_t use_fm, const xdfm_opt_args* opt, float* pieces, const float* d_emb2,
                    int64_t grad_stride, void* stream);
+/* Lazy-row catch-up: makes sparse row updates (xdfm_embed_bwd mode 0) give the reference's numbers.
+ * In the reference the table's gradient is dense (the regulariser ops of base_model.py:121-149 sit on
+ * the table even at coefficient 0), so apply_gradients (base_model.py:322) moves
+ * every row every step: a row without a token in the batch still takes Adam's m <- b1 m, v <- b2 v,
+ * p <- p - lr_t m / (sqrt(v) + eps).  row_step[id] (int32, entries step_stride apart, 0 = dense)
+ * records the step a row's (p, m, v) are current for; this call brings the rows named by sorted_ids
+ * (the first position of each run of equal ids works; NULL: all N rows, n ignored) up to the step
+ * count in opt->opt_state[3] and writes that count + advance into row_step (advance = 1 before a
+ * training step whose xdfm_embed_bwd will update exactly these rows; 0 for a flush before scoring or
+ * a checkpoint).  The first 24 missed steps are applied one by one in TF's expression order, the
+ * geometric remainder in closed form (|error| < 1e-5).  RMSProp / Adadelta decay their accumulators;
+ * FTRL re-derives p = -linear / quadratic as TF's dense ApplyFtrl does every step (a row that never
+ * had a gradient becomes 0); SGD and Adagrad have no drift (a no-op apart from row_step). */
+int xdfm_embed_catchup(float* table, float* slot_m, float* slot_v, float* lin_w, float* lin_m,
+                       float* lin_v, int32_t* row_step, int64_t table_stride, int64_t lin_stride,
+                       int64_t step_stride, int64_t N, int32_t D, const int32_t* sorted_ids, int64_t n,
+                       int32_t advance, const xdfm_opt_args* opt, void* stream);
 /* zero the rows of grad_table / grad_lin named by sorted_ids (restores the all-zero invariant) */
 int xdfm_embed_clear_rows(float* grad_table, float* grad_lin, int32_t D,
                           const int32_t* sorted_ids, int64_t nnz, void* stream);

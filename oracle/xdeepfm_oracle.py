@@ -456,7 +456,7 @@ def train_step(params, st, batch, hp, mode="dense_exact", dropout_masks=None):
         st["b1p"] = np.float32(st["b1p"] * np.float32(0.9))
         st["b2p"] = np.float32(st["b2p"] * np.float32(0.999))
 
-    sparse = mode == "sparse_rows"
+    sparse = mode in ("sparse_rows", "sparse_lazy")  # one name per engine mode that skips absent rows
     leaves = {}
     moving = {}  # batch-norm moving statistics after this step
     if sparse:

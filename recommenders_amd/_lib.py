@@ -100,6 +100,8 @@ SIGNATURES = {
     "xdfm_embed_plan_static": [_P, _I64, _I64, _P, _P, _P],
     "xdfm_embed_bwd": [_I32, _P, _P, _P, _P, _P, _P, _I64, _I64, _P, _P, _I64, _I32, _I32, _I64, _P, _P, _P,
                        _P, _I64, _P, _P, _P, _I32, ctypes.POINTER(OptArgs), _P, _P, _I64, _P],
+    "xdfm_embed_catchup": [_P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _I32, _P, _I64, _I32,
+                           ctypes.POINTER(OptArgs), _P],
     "xdfm_embed_clear_rows": [_P, _P, _I32, _P, _I64, _P],
     "xdfm_opt_advance": [_P, ctypes.c_float, ctypes.c_float, ctypes.c_float, _P],
     "xdfm_dense_update": [_P, _P, _P, _P, _I32, _P, _P, _P, _P, ctypes.POINTER(OptArgs), _P, _P,

@@ -816,6 +816,130 @@ extern "C" int xdfm_embed_bwd(int32_t mode, float* table, float* slot_m, float* 
   return XDFM_OK;
 }
 
+// ---------------------------------------------------------------- lazy-row catch-up
+// The reference's table gradient is dense (base_model.py:121-149 put regulariser ops on the table even
+// at coefficient 0), so TF's Adam moves EVERY row EVERY step: a row without a token in
+// the batch still takes m <- b1 m, v <- b2 v, p <- p - lr_t m / (sqrt(v) + eps).  The sparse-row update
+// skips those steps; this kernel applies them when the row is next needed, so that sparse rows give the
+// reference's numbers.  row_step[id] = the step the row's (p, m, v) are current for.  A row G steps
+// behind takes its first kCatchExact missed steps one by one in TF's own expression order; the rest of
+// the geometric tail (its weight is b1^kCatchExact of the whole drift) through a log-linear fit of
+// lr_t / (sqrt(v b2^i) + eps) over the next steps, worst case 4e-6 absolute at lr 0.002
+// (tools/catchup_sim.py).
+// RMSProp / Adadelta only decay their accumulators (no gradient, no movement); FTRL re-derives the row
+// from its slots (TF does so every step: rows that never had a gradient become 0); SGD and Adagrad
+// have nothing to catch up with.
+constexpr int kCatchExact = 24;
+
+struct CatchArgs {
+  float *table, *slot_m, *slot_v, *lin_w, *lin_m, *lin_v;
+  int32_t* row_step;
+  int64_t TS, LS, SS, N, n;
+  int D, advance;
+  const int32_t* sorted_ids;  // null: every row 0..N-1
+  OptDev opt;
+  float b1, b2;
+};
+
+template <int VEC>
+__device__ __forceinline__ void catchup_vals(const CatchArgs& a, RowVals<VEC>& r, int last, int G) {
+  const OptDev& o = a.opt;
+  const float lb1 = log2f(a.b1), lb2 = log2f(a.b2);
+  if (o.kind == XDFM_OPT_ADAM) {
+    // while lr_t still bends (the first steps of training) more steps are taken one by one
+    const int k0 = kCatchExact + (last < 64 ? 64 - last : 0);
+    const int kx = G < k0 ? G : k0;
+    float b1j = exp2f((float)(last + 1) * lb1), b2j = exp2f((float)(last + 1) * lb2);
+    for (int k = 0; k < kx; ++k) {
+      const float alpha = o.lr * sqrtf(1.f - b2j) / (1.f - b1j);
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) {
+        r.m[i] = r.m[i] + (0.f - r.m[i]) * o.one_minus_b1;
+        r.v[i] = r.v[i] + (0.f - r.v[i]) * o.one_minus_b2;
+        r.p[i] = r.p[i] - (r.m[i] * alpha) / (sqrtf(r.v[i]) + o.eps);
+      }
+      b1j *= a.b1;
+      b2j *= a.b2;
+    }
+    const int gp = G - kx;
+    if (gp > 0) {
+      // steps j1 = last + kx + 1 ... : sum_i alpha(j1 + i - 1) m b1^i / (sqrt(v) g^i + eps), g = sqrt(b2);
+      // f(i) = alpha / (sqrt(v) g^i + eps) is fitted as f(1) rho^(i-1) through i = 1 and i = 9
+      const float a1 = o.lr * sqrtf(1.f - b2j) / (1.f - b1j);
+      const float b1j9 = b1j * exp2f(8.f * lb1), b2j9 = b2j * exp2f(8.f * lb2);
+      const float a9 = o.lr * sqrtf(1.f - b2j9) / (1.f - b1j9);
+      const float g1 = exp2f(0.5f * lb2), g9 = exp2f(4.5f * lb2);
+      const float pw1 = exp2f((float)gp * lb1), pw2 = exp2f((float)gp * lb2);
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) {
+        const float sv = sqrtf(r.v[i]);
+        const float f1 = a1 / (sv * g1 + o.eps), f9 = a9 / (sv * g9 + o.eps);
+        const float q = a.b1 * exp2f(log2f(f9 / f1) * 0.125f);
+        const float qg = exp2f((float)gp * log2f(q));
+        r.p[i] = r.p[i] - r.m[i] * f1 * a.b1 * (1.f - qg) / (1.f - q);
+        r.m[i] = r.m[i] * pw1;
+        r.v[i] = r.v[i] * pw2;
+      }
+    }
+  } else if (o.kind == XDFM_OPT_RMSPROP) {
+    const float pw = exp2f((float)G * lb2);  // ms <- ms + (0 - ms)(1 - decay), G times
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) r.m[i] = r.m[i] * pw;
+  } else if (o.kind == XDFM_OPT_ADADELTA) {
+    const float pw = exp2f((float)G * lb2);  // accum and accum_update both decay by rho per step
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      r.m[i] = r.m[i] * pw;
+      r.v[i] = r.v[i] * pw;
+    }
+  } else if (o.kind == XDFM_OPT_FTRL) {
+    // TF's dense ApplyFtrl rewrites var = -linear / quadratic every step, gradient or not: a row that
+    // never had a gradient (linear = 0) becomes 0 at the first step; an updated row is a fixed point
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) r.p[i] = -r.v[i] / (sqrtf(r.m[i]) / o.lr);
+  }
+}
+
+// One lane group (LPR = D/VEC lanes) per sorted position, groups never straddle a wave; only the
+// first position of an id's run works.
+template <int VEC>
+__global__ __launch_bounds__(256) void embed_catchup_kernel(CatchArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int LPR = a.D / VEC;
+  const int R = 64 / LPR;
+  const int g = lane / LPR;
+  const int c = lane - g * LPR;
+  const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t q = wave * R + g;
+  if (g >= R || q >= a.n) return;
+  int64_t id = q;
+  if (a.sorted_ids) {
+    id = a.sorted_ids[q];
+    if (q > 0 && a.sorted_ids[q - 1] == id) return;
+  }
+  const int done = (int)a.opt.state[3];  // optimizer steps applied so far
+  const int last = a.row_step[id * a.SS];
+  const int G = done - last;
+  // last == 0: never updated; Adam's / Adadelta's slots are still zero: no drift (RMSProp's rms starts
+  // at 1 and decays from the first step on)
+  if (G > 0 && (last > 0 || a.opt.kind == XDFM_OPT_RMSPROP || a.opt.kind == XDFM_OPT_FTRL)) {
+    const int64_t off = id * a.TS + c * VEC;
+    RowVals<VEC> rv;
+    row_load<VEC>(a.opt, a.table + off, a.slot_m + off, a.slot_v + off, rv);
+    catchup_vals<VEC>(a, rv, last, G);
+    row_store<VEC>(a.opt, a.table + off, a.slot_m + off, a.slot_v + off, rv);
+    if (a.lin_w && c == 0) {
+      const int64_t lo = id * a.LS;
+      RowVals<1> rl;
+      row_load<1>(a.opt, a.lin_w + lo, a.lin_m + lo, a.lin_v + lo, rl);
+      catchup_vals<1>(a, rl, last, G);
+      row_store<1>(a.opt, a.lin_w + lo, a.lin_m + lo, a.lin_v + lo, rl);
+    }
+  }
+  // written last, by a lane whose own read of it has been consumed above
+  if (c == 0 && (G > 0 || a.advance)) a.row_step[id * a.SS] = done + a.advance;
+}
+
 extern "C" int xdfm_embed_clear_rows(float* grad_table, float* grad_lin, int32_t D,
                                      const int32_t* sorted_ids, int64_t nnz, void* stream) {
   XDFM_REQUIRE(D > 0 && nnz >= 0, "xdfm_embed_clear_rows: bad sizes");
@@ -823,6 +947,58 @@ extern "C" int xdfm_embed_clear_rows(float* grad_table, float* grad_lin, int32_t
   XDFM_REQUIRE(sorted_ids, "xdfm_embed_clear_rows: null sorted_ids");
   const int64_t total = nnz * D;
   XDFM_LAUNCH("clear_rows_kernel", stream, clear_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, grad_table, grad_lin, D, sorted_ids, nnz);
+  XDFM_LAUNCH_CHECK();
+  return XDFM_OK;
+}
+
+extern "C" int xdfm_embed_catchup(float* table, float* slot_m, float* slot_v, float* lin_w, float* lin_m,
+                                  float* lin_v, int32_t* row_step, int64_t table_stride, int64_t lin_stride,
+                                  int64_t step_stride, int64_t N, int32_t D, const int32_t* sorted_ids,
+                                  int64_t n, int32_t advance, const xdfm_opt_args* opt, void* stream) {
+  XDFM_REQUIRE(table && row_step && opt, "xdfm_embed_catchup: null argument");
+  XDFM_REQUIRE(N > 0 && D > 0 && n >= 0 && (advance == 0 || advance == 1), "xdfm_embed_catchup: bad sizes");
+  XDFM_REQUIRE(opt->opt_state, "xdfm_embed_catchup: needs the device step count (opt_state)");
+  CatchArgs a;
+  memset(&a, 0, sizeof(a));
+  int rc = make_opt(opt, &a.opt);
+  if (rc) return rc;
+  XDFM_REQUIRE(opt->kind == XDFM_OPT_SGD || slot_m, "xdfm_embed_catchup: optimizer slot missing");
+  XDFM_REQUIRE(!xdfm::opt_needs_v(opt->kind) || slot_v, "xdfm_embed_catchup: this optimizer needs slot_v");
+  XDFM_REQUIRE(!lin_w || ((opt->kind == XDFM_OPT_SGD || lin_m) && (!xdfm::opt_needs_v(opt->kind) || lin_v)),
+               "xdfm_embed_catchup: lin slot missing");
+  if (!sorted_ids) n = N;
+  if (n == 0) return XDFM_OK;
+  const int vec = pick_vec(D);
+  XDFM_REQUIRE(D / vec <= kWave, "xdfm_embed_catchup: dim %d not supported", D);
+  XDFM_REQUIRE(strides_ok(&table_stride, &lin_stride, D, vec), "xdfm_embed_catchup: bad row strides");
+  a.table = table;
+  a.slot_m = slot_m;
+  a.slot_v = slot_v;
+  a.lin_w = lin_w;
+  a.lin_m = lin_m;
+  a.lin_v = lin_v;
+  a.row_step = row_step;
+  a.TS = table_stride;
+  a.LS = lin_stride;
+  a.SS = step_stride ? step_stride : 1;
+  a.N = N;
+  a.n = n;
+  a.D = D;
+  a.advance = advance;
+  a.sorted_ids = sorted_ids;
+  a.b1 = opt->beta1;
+  a.b2 = opt->beta2;
+  const int R = kWave / (D / vec);
+  const int64_t waves = (n + R - 1) / R;
+  const unsigned blocks = (unsigned)((waves + 3) / 4);
+#define LAUNCH(V) XDFM_LAUNCH("embed_catchup_kernel<" #V ">", stream, embed_catchup_kernel<V>, dim3(blocks), dim3(256), 0, a)
+  if (vec == 4)
+    LAUNCH(4);
+  else if (vec == 2)
+    LAUNCH(2);
+  else
+    LAUNCH(1);
+#undef LAUNCH
   XDFM_LAUNCH_CHECK();
   return XDFM_OK;
 }

@@ -158,13 +158,20 @@ class XDeepFMEngine(object):
                     raise ValueError("this activations not defined {0}".format(hp.activation[k]))
         if not (hp.use_Linear_part or hp.use_FM_part or hp.use_CIN_part or hp.use_DNN_part):
             raise ValueError("xDeepFM needs at least one of the Linear/FM/CIN/DNN parts")
-        if embedding_update not in ("dense_exact", "sparse_rows"):
-            raise ValueError("embedding_update must be dense_exact or sparse_rows")
+        if embedding_update not in ("dense_exact", "sparse_rows", "sparse_lazy"):
+            raise ValueError("embedding_update must be dense_exact, sparse_rows or sparse_lazy")
         self.embedding_update = embedding_update
+        self.sparse = embedding_update != "dense_exact"
         self.opt_kind = _OPT.get(hp.optimizer)
         if self.opt_kind is None:
             self.opt_kind = 0  # unknown names fall back to SGD (base_model.py:301-302)
-        if embedding_update == "sparse_rows":
+        # sparse_rows = the reference's numbers from row updates: TF moves every row every step (Adam's
+        # m keeps decaying into p without a gradient; RMSProp / Adadelta decay their accumulators), so
+        # the steps a row missed are applied when it is next needed (xdfm_embed_catchup) and before
+        # scoring / checkpoints.  sparse_lazy skips them (a different algorithm for absent rows).
+        self.catchup_on = embedding_update == "sparse_rows" and self.opt_kind in (1, 3, 4, 5)
+        self._rows_stale = False
+        if self.sparse:
             if hp.embed_l1 != 0.0 or hp.embed_l2 != 0.0:
                 raise ValueError("sparse_rows needs embed_l1 = embed_l2 = 0 (their gradient is dense)")
             if hp.use_Linear_part and (hp.layer_l1 != 0.0 or hp.layer_l2 != 0.0):
@@ -185,11 +192,11 @@ class XDeepFMEngine(object):
         # lines: [row | lin w, m, v | pad] [slot m | slot v | pad]; the forward gather reads the
         # first line only, the update two lines instead of six scattered ones.  The tensors
         # below are strided views into it (row strides go to the kernels).
-        self.interleaved = (embedding_update == "sparse_rows"
-                            and os.environ.get("XDFM_TABLE_RECORDS", "1") != "0")
+        self.interleaved = self.sparse and os.environ.get("XDFM_TABLE_RECORDS", "1") != "0"
+        self.row_step, self.step_stride = None, 1
         if self.interleaved:
             D = self.D
-            line0 = (D + 3 + 31) // 32 * 32
+            line0 = (D + 4 + 31) // 32 * 32
             self.table_stride = self.lin_stride = line0 + (2 * D + 31) // 32 * 32
             self._records = torch.zeros((self.N, self.table_stride), dtype=f32, device=dev)
             rec = self._records
@@ -199,6 +206,9 @@ class XDeepFMEngine(object):
             self.table_v = rec[:, line0 + D:line0 + 2 * D] if need_v else None
             self.lin_m = rec[:, D + 1] if (need_m and hp.use_Linear_part) else None
             self.lin_v = rec[:, D + 2] if (need_v and hp.use_Linear_part) else None
+            if self.catchup_on:  # the step a row's (p, m, v) are current for, in its first line
+                self.row_step = rec[:, D + 3].view(torch.int32)
+                self.step_stride = self.table_stride
             for t in (self.table_m, self.lin_m):
                 if t is not None and m0 != 0.0:
                     t.fill_(m0)
@@ -206,6 +216,8 @@ class XDeepFMEngine(object):
             self.table_stride, self.lin_stride = self.D, 1
             self.table = torch.zeros((self.N, self.D), dtype=f32, device=dev)
             self.lin_w = torch.zeros((self.N,), dtype=f32, device=dev) if hp.use_Linear_part else None
+            if self.catchup_on:
+                self.row_step = torch.zeros((self.N,), dtype=torch.int32, device=dev)
         self.dense_shapes = dense_param_shapes(hp)
         offs = [0]
         for shape in self.dense_shapes.values():
@@ -252,6 +264,7 @@ class XDeepFMEngine(object):
         self.loss_scratch = torch.zeros((1032,), dtype=f32, device=dev)  # [1024]: xdfm_head_loss's block counter
         self._cap_B = self._cap_nnz = 0
         self.ws = {}
+        self._ws_token = 0  # bumped whenever the workspace is re-allocated
         self._eval_ws = None
         # name -> [(start_event, end_event)]: filled when bench.py asks for in-situ kernel times
         self.kernel_events = None
@@ -260,7 +273,7 @@ class XDeepFMEngine(object):
         # with both towers on, the DNN tower (small, latency/HBM-bound launches) runs on a second
         # stream beside the CIN (matrix-core bound): the two share nothing but emb_out and d_emb
         # regularisation loss (a function of the parameters alone) beside the forward pass
-        self.early_reg = (self.overlap_dnn_wanted(hp) and embedding_update == "sparse_rows" and not hp.is_clip_norm
+        self.early_reg = (self.overlap_dnn_wanted(hp) and self.sparse and not hp.is_clip_norm
                           and 0 < len(self.dense_shapes) <= 32)
         self.prepack = os.environ.get("XDFM_CIN_PREPACK", "1") != "0"
         self.split_dw = os.environ.get("XDFM_SPLIT_DW", "1") != "0"
@@ -312,7 +325,8 @@ class XDeepFMEngine(object):
             t.fill_(1.0 if "_mv_" in name else 0.0)  # moving mean = 0, moving variance = 1
 
     def state_dict(self):
-        if self.opt_kind == 1:  # the device copy is authoritative (graph replays do not run Python)
+        self.flush_rows()
+        if self.opt_kind == 1 or self.catchup_on:  # the device copy is authoritative (graph replays do not run Python)
             b1p, b2p, _, t = self.opt_state.tolist()
             self.b1p, self.b2p, self.step = np.float32(b1p), np.float32(b2p), int(round(t))
         sd = {"embedding": self.table, "step": self.step, "b1p": float(self.b1p), "b2p": float(self.b2p)}
@@ -360,6 +374,9 @@ class XDeepFMEngine(object):
             self.b1p = np.float32(sd.get("b1p", 0.9 ** self.step))
             self.b2p = np.float32(sd.get("b2p", 0.999 ** self.step))
             self.opt_state.copy_(torch.tensor([float(self.b1p), float(self.b2p), 0.0, float(self.step)]))
+        if self.row_step is not None:  # a state dict holds flushed rows: all current for `step`
+            self.row_step.fill_(self.step)
+            self._rows_stale = False
 
     @staticmethod
     def overlap_dnn_wanted(hp):
@@ -510,7 +527,13 @@ class XDeepFMEngine(object):
             buf("d_emb_dnn", B, F * D)
         _lib.check(self.lib.xdfm_embed_plan_workspace_bytes(nnz, self.N, ctypes.byref(sz)))
         buf("plan_ws", sz.value, dtype=torch.uint8)
+        if self.ws:
+            # the old buffers may still be in use on the side streams, and captured graphs hold
+            # their addresses: wait for the device, and let every GraphedStep / local graph see that
+            # it is stale (they compare the token before a replay)
+            torch.cuda.synchronize(self.device)
         self.ws = ws
+        self._ws_token += 1
         self._cap_B, self._cap_nnz = B, nnz
 
     # ------------------------------------------------------------------- batch
@@ -560,8 +583,9 @@ class XDeepFMEngine(object):
         if self._side_stream is None:
             self._side_stream = torch.cuda.Stream(device=self.device)
         # allocated under the main stream, which is also where they are consumed and freed
-        batch.sorted_ids = torch.empty((max(batch.nnz, 1),), dtype=torch.int32, device=self.device)
-        batch.sorted_tok = torch.empty((max(batch.nnz, 1),), dtype=torch.int32, device=self.device)
+        if batch.sorted_ids is None:
+            batch.sorted_ids = torch.empty((max(batch.nnz, 1),), dtype=torch.int32, device=self.device)
+            batch.sorted_tok = torch.empty((max(batch.nnz, 1),), dtype=torch.int32, device=self.device)
         ready = torch.cuda.Event()
         ready.record(main)
         self._side_stream.wait_event(ready)
@@ -602,6 +626,8 @@ class XDeepFMEngine(object):
         # layer_keeps = keep_prob_train only under train() (base_model.py:377); eval / infer feed ones
         self._dropout_live = self.use_dropout and with_grad
         self._training = bool(with_grad)  # is_train_stage (base_model.py:378, :401, :415)
+        if not with_grad:
+            self.flush_rows()  # scoring reads the table as the reference's dense optimizer left it
         self._ensure_ws(batch.B, batch.nnz)
         ws = self.ws
         B, F, D = batch.B, self.F, self.D
@@ -1017,11 +1043,12 @@ class XDeepFMEngine(object):
         b1, b2, eps = _OPT_CONST[self.opt_kind]
         return _lib.OptArgs(self.opt_kind, float(hp.learning_rate), b1, b2, eps,
                             float(self.b1p), float(self.b2p), float(l2), float(l1), float(clip), 0,
-                            self.opt_state.data_ptr() if self.opt_kind == 1 else None)
+                            self.opt_state.data_ptr() if (self.opt_kind == 1 or self.catchup_on) else None)
 
     def _advance_step(self):
         self.step += 1
-        if self.opt_kind == 1 or self.use_dropout:  # the device-side step count also seeds the dropout masks
+        # the device-side step count also seeds the dropout masks and dates the rows (catch-up)
+        if self.opt_kind == 1 or self.use_dropout or self.catchup_on:
             self.b1p = np.float32(self.b1p * np.float32(0.9))  # host mirror (checkpoints)
             self.b2p = np.float32(self.b2p * np.float32(0.999))
             _lib.check(self.lib.xdfm_opt_advance(_ptr(self.opt_state), float(self.hp.learning_rate), 0.9, 0.999,
@@ -1046,7 +1073,7 @@ class XDeepFMEngine(object):
         if batch.plan_event is not None:
             torch.cuda.current_stream(self.device).wait_event(batch.plan_event)
             batch.plan_event = None
-        sparse = self.embedding_update == "sparse_rows"
+        sparse = self.sparse
         opt_sparse = self._opt_args()
         ev = self._mark("embed_bwd")
         _lib.check(
@@ -1128,13 +1155,52 @@ class XDeepFMEngine(object):
             self.reg_loss.zero_()
         self._done(ev_upd)
 
-    def train_step(self, batch):
-        """One optimisation step; returns (total_loss, data_loss) as 0-dim device tensors."""
-        self.plan_async(batch)
+    def catchup(self, sorted_ids, n, advance):
+        """xdfm_embed_catchup over the rows named by sorted_ids (None: the whole table)."""
+        use_lin = self.lin_w is not None
+        opt = self._opt_args()
+        _lib.check(
+            self.lib.xdfm_embed_catchup(
+                _ptr(self.table), _ptr(self.table_m), _ptr(self.table_v), _ptr(self.lin_w) if use_lin else None,
+                _ptr(self.lin_m) if use_lin else None, _ptr(self.lin_v) if use_lin else None, _ptr(self.row_step),
+                self.table_stride, self.lin_stride, self.step_stride, self.N, self.D, _ptr(sorted_ids), int(n),
+                int(advance), ctypes.byref(opt), self._stream(),
+            )
+        )
+
+    def flush_rows(self):
+        """Bring every row up to the current step (before scoring, checkpoints, table exports)."""
+        if self.catchup_on and self._rows_stale:
+            self.catchup(None, self.N, 0)
+            self._rows_stale = False
+
+    def train_step(self, batch, next_batch=None):
+        """One optimisation step; returns (total_loss, data_loss) as 0-dim device tensors.
+        next_batch (optional): the batch of the following step; its id sort then runs beside this
+        step's compute (with the catch-up of sparse_rows the sort is needed BEFORE the forward pass,
+        so a step whose batch was not planned ahead sorts first)."""
+        if self.catchup_on:
+            self.plan(batch)
+            if batch.plan_event is not None:
+                torch.cuda.current_stream(self.device).wait_event(batch.plan_event)
+                batch.plan_event = None
+            ev = self._mark("embed_catchup")
+            self.catchup(batch.sorted_ids, batch.nnz, 1)
+            self._done(ev)
+            self._rows_stale = True
+        else:
+            self.plan_async(batch)
+        if next_batch is not None and next_batch is not batch:
+            self.plan_async(next_batch)
         self.forward(batch, with_loss=True, with_grad=True)
         advanced = self.backward(batch, advance=True)
         self.update(batch, advanced)
         tot = torch.cumsum(self._loss2, 0)  # one launch: [data, data + reg]
+        if next_batch is not None and next_batch.plan_event is not None:
+            # join (the sort finished long ago): the sort workspace is free again, and a capture ends
+            # with every forked stream joined
+            torch.cuda.current_stream(self.device).wait_event(next_batch.plan_event)
+            next_batch.plan_event = None
         return tot[1], tot[0]
 
     def capture_step(self, labels, dnn_idx, ids, weights):
@@ -1164,7 +1230,12 @@ class XDeepFMEngine(object):
 class GraphedStep(object):
     """A captured train step.  The graph reads its batch from one flat device buffer (labels,
     indices, ids, weights at 256-byte aligned offsets), so handing it a batch is one copy:
-    run_packed(buf) for a batch already laid out by pack(), run(...) for four arrays."""
+    run_packed(buf) for a batch already laid out by pack(), run(...) for four arrays.
+
+    With the catch-up of sparse_rows the id sort is needed before the forward pass; the graph
+    therefore sorts the NEXT batch's ids beside this batch's compute (run_packed(buf, next_buf) /
+    run(..., next_ids=)): every replay still does one sort, one step ahead.  A batch that was not
+    announced that way is sorted eagerly in front of the replay."""
 
     def __init__(self, engine, labels, dnn_idx, ids, weights):
         self.engine = engine
@@ -1181,6 +1252,14 @@ class GraphedStep(object):
             dst.copy_(src)
         if engine.kernel_events is not None:
             raise RuntimeError("kernel event hooks cannot be captured")
+        self.lookahead = bool(engine.catchup_on)
+        self._planned_for = None  # data_ptr of the ids the graph's plan_next was sorted from
+        nnz = max(int(ids.numel()), 1)
+        if self.lookahead:
+            dev = engine.device
+            self.next_ids = torch.empty_like(self.inputs[2])
+            self.plan_cur = [torch.empty((nnz,), dtype=torch.int32, device=dev) for _ in range(2)]
+            self.plan_next = [torch.empty((nnz,), dtype=torch.int32, device=dev) for _ in range(2)]
         # warm up on a side stream (allocations, lazy module loads), as torch asks before a capture
         s = torch.cuda.Stream(device=engine.device)
         s.wait_stream(torch.cuda.current_stream(engine.device))
@@ -1189,10 +1268,25 @@ class GraphedStep(object):
         torch.cuda.current_stream(engine.device).wait_stream(s)
         torch.cuda.synchronize(engine.device)
         engine.check_errors()
+        self._ws_token = engine._ws_token
+        mirrors = (engine.step, engine.b1p, engine.b2p)
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.batch = engine.make_batch(*self.inputs)
-            self.loss, self.data_loss = engine.train_step(self.batch)
+            if self.lookahead:
+                for dst, src in zip(self.plan_cur, self.plan_next):
+                    dst.copy_(src)
+                self.batch.sorted_ids, self.batch.sorted_tok = self.plan_cur
+                self.batch.planned = True
+                nb = DeviceBatch()
+                nb.B, nb.nnz, nb.ids = self.batch.B, self.batch.nnz, self.next_ids
+                nb.sorted_ids, nb.sorted_tok = self.plan_next
+                nb.planned, nb.plan_event = False, None
+                self.loss, self.data_loss = engine.train_step(self.batch, next_batch=nb)
+            else:
+                self.loss, self.data_loss = engine.train_step(self.batch)
+        # the capture pass ran the host bookkeeping of a step without device work
+        engine.step, engine.b1p, engine.b2p = mirrors
 
     def pack(self, labels, dnn_idx, ids, weights):
         """The four arrays of a batch in the graph's input layout (a new device buffer)."""
@@ -1204,15 +1298,37 @@ class GraphedStep(object):
             buf[o:o + n].view(dt).view(shape).copy_(src)
         return buf
 
-    def run_packed(self, buf):
-        self.flat.copy_(buf, non_blocking=True)
+    def _ids_of(self, buf):
+        o, n, dt, shape = self._layout[2]
+        return buf[o:o + n].view(dt).view(shape)
+
+    def _replay(self, cur_ids, next_ids):
+        eng = self.engine
+        if eng._ws_token != self._ws_token:
+            raise RuntimeError("the engine's workspace was re-allocated after this step was captured "
+                               "(a larger batch went through the engine): capture it again")
+        if self.lookahead:
+            if self._planned_for != cur_ids.data_ptr():
+                # not announced by the previous replay: sort now, into the buffer the graph copies from
+                ws = eng.ws["plan_ws"]
+                _lib.check(eng.lib.xdfm_embed_plan(_ptr(self.inputs[2]), int(self.inputs[2].numel()), eng.N,
+                                                   _ptr(self.plan_next[0]), _ptr(self.plan_next[1]), _ptr(ws),
+                                                   ws.numel(), eng._stream()))
+            if next_ids is not None:
+                self.next_ids.copy_(next_ids, non_blocking=True)
+                self._planned_for = next_ids.data_ptr()
+            else:
+                self._planned_for = None  # the replay sorts whatever next_ids holds: never used
         self.graph.replay()
-        self.engine.step += 1
+        eng.step += 1
+        eng._rows_stale = eng.catchup_on
         return self.loss, self.data_loss
 
-    def run(self, labels, dnn_idx, ids, weights):
+    def run_packed(self, buf, next_buf=None):
+        self.flat.copy_(buf, non_blocking=True)
+        return self._replay(self._ids_of(buf), self._ids_of(next_buf) if next_buf is not None else None)
+
+    def run(self, labels, dnn_idx, ids, weights, next_ids=None):
         for dst, src in zip(self.inputs, (labels, dnn_idx, ids, weights)):
             dst.copy_(src, non_blocking=True)
-        self.graph.replay()
-        self.engine.step += 1
-        return self.loss, self.data_loss
+        return self._replay(ids, next_ids)

@@ -158,7 +158,7 @@ class ShardedXDeepFMEngine(XDeepFMEngine):
         self.global_rows = int(hp.FEATURE_COUNT)
         rows = local_rows(self.global_rows, self.rank, self.world)
         XDeepFMEngine.__init__(self, hp, device=device, seed=None if seed is None else seed + 7919 * self.rank,
-                               embedding_update="sparse_rows", table_rows=max(rows, 1))
+                               embedding_update="sparse_lazy", table_rows=max(rows, 1))
         if self.world > 1:
             self.exchange.broadcast(self.dense, 0)  # replicated parameters start identical
         self.dropout_seed ^= (0x632BE59BD9B4E019 * self.rank) & (2 ** 64 - 1)  # ranks draw different masks

@@ -141,10 +141,19 @@ class BaseModel:
         Returns ``[update, extra_update_ops, loss, data_loss, summary]`` like the reference
         (:379-388); the two losses are device scalars.
         """
+        return self._train(sess, feed_dict, None)
+
+    def _train(self, sess, feed_dict, next_feed_dict):
+        """train() with the following batch announced: it is uploaded now and its id sort runs
+        beside this step (the catch-up of embedding_update="sparse_rows" needs a batch's sort
+        before its forward pass)."""
         feed_dict[self.layer_keeps] = self.keep_prob_train
         feed_dict[self.is_train_stage] = True
         batch = self._batch_from_feed(feed_dict)
-        loss, data_loss = self.engine.train_step(batch)
+        nxt = None
+        if next_feed_dict is not None and getattr(self.engine, "catchup_on", False):
+            nxt = self._batch_from_feed(next_feed_dict)
+        loss, data_loss = self.engine.train_step(batch, next_batch=nxt)
         return [None, [], loss, data_loss, None]
 
     def eval(self, sess, feed_dict):
@@ -201,8 +210,12 @@ class BaseModel:
             epoch_loss = 0
             logged = []
             train_start = time.time()
-            for batch_data_input, impression, data_size in self.iterator.load_data_from_file(train_file):
-                step_result = self.train(train_sess, batch_data_input)
+            batches = self.iterator.load_data_from_file(train_file)
+            upcoming = next(batches, None)
+            while upcoming is not None:
+                batch_data_input, impression, data_size = upcoming
+                upcoming = next(batches, None)
+                step_result = self._train(train_sess, batch_data_input, upcoming[0] if upcoming is not None else None)
                 (_, _, step_loss, step_data_loss, summary) = step_result
                 epoch_loss = epoch_loss + step_loss
                 step += 1

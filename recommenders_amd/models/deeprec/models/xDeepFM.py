@@ -10,8 +10,13 @@ One additional, optional hyper-parameter is understood:
 ``embedding_update`` (str, default ``"dense_exact"``)
     ``"dense_exact"``: reference semantics -- the table's gradient is dense (regularisers,
     TF's IndexedSlices densification) and the optimizer moves every row every step.
-    ``"sparse_rows"``: only the rows present in the batch are updated (lazy Adam / Adagrad /
-    SGD fused into the sorted-key segment sum); needs ``embed_l1 = embed_l2 = 0``.
+    ``"sparse_rows"``: only the rows present in the batch are touched by a step (the optimizer
+    is fused into the sorted-key segment sum) and the result is still the reference's: the steps
+    a row missed -- TF's Adam keeps moving a row on its decaying ``m`` without a gradient -- are
+    applied when the row is next needed and before scoring / checkpoints
+    (``xdfm_embed_catchup``).  Needs ``embed_l1 = embed_l2 = 0`` (their gradient is dense).
+    ``"sparse_lazy"``: row updates without that catch-up (absent rows stand still: a different
+    algorithm under Adam / RMSProp / Adadelta; identical for SGD / Adagrad / FTRL).
 """
 
 import numpy as np

@@ -177,17 +177,19 @@ def test_forward_and_gradients_match_oracle(name, loss):
 
 @pytest.mark.parametrize("fast_d", [0, 2])
 @pytest.mark.parametrize("optimizer", ["adam", "adagrad", "sgd", "rmsprop", "adadelta", "ftrl", "padagrad", "pgd"])
-@pytest.mark.parametrize("mode", ["dense_exact", "sparse_rows"])
+@pytest.mark.parametrize("mode", ["dense_exact", "sparse_rows", "sparse_lazy"])
 def test_training_steps_match_oracle(optimizer, mode, fast_d):
+    """dense_exact and sparse_rows (row updates + catch-up of the steps a row missed) against the
+    oracle's reference semantics (every row moves every step); sparse_lazy against the oracle's
+    restatement of lazy row updates."""
     if fast_d and (optimizer != "adam"):
         pytest.skip("the fast-CIN filters go through the same update path; one optimizer is enough")
     reg = dict(embed_l2=0.01, layer_l2=0.01, cross_l2=0.01, embed_l1=0.001, layer_l1=0.001, cross_l1=0.001)
-    if mode == "sparse_rows":
+    if mode != "dense_exact":
         reg = dict(cross_l2=0.01, cross_l1=0.001)
     reg["fast_CIN_d"] = fast_d
     hp = make_hp(optimizer=optimizer, learning_rate=0.01, FEATURE_COUNT=300, **reg)
-    if mode == "sparse_rows":
-        hp = make_hp(optimizer=optimizer, learning_rate=0.01, FEATURE_COUNT=300, use_Linear_part=True, **reg)
+    oracle_mode = "sparse_lazy" if mode == "sparse_lazy" else "dense_exact"
     rng = np.random.default_rng(5)
     p32 = X.init_params(hp, seed=9)
     eng = load_engine(hp, p32, mode)
@@ -197,7 +199,7 @@ def test_training_steps_match_oracle(optimizer, mode, fast_d):
         b = random_batch(rng, hp, 64 if step != 2 else 33)
         db = upload(eng, b)
         loss, dloss = eng.train_step(db)
-        o_loss, o_dl, _, _ = X.train_step(p64, st, b, hp, mode=mode)
+        o_loss, o_dl, _, _ = X.train_step(p64, st, b, hp, mode=oracle_mode)
         close(float(dloss), o_dl, what="data loss step %d" % step)
         close(float(loss), o_loss, what="total loss step %d" % step)
     torch.cuda.synchronize()
@@ -210,6 +212,80 @@ def test_training_steps_match_oracle(optimizer, mode, fast_d):
         tol = 2e-3  # p = -linear / quadratic with `linear` a cancelling sum (g - sigma*p): fp32 vs the fp64 oracle
     for k, v in p64.items():
         close(sd[k].cpu().numpy().reshape(v.shape), v.numpy(), rtol=tol, what="param " + k)
+
+
+@pytest.mark.parametrize("optimizer", ["adam", "rmsprop", "adadelta"])
+def test_sparse_rows_with_long_gaps_equal_reference_dense_updates(optimizer):
+    """Rows that stay out of the batches for many steps (beyond the 24 missed steps the catch-up
+    applies one by one: the closed-form remainder) against the oracle's dense-exact optimizer, where
+    every row moves every step; 2e-4 per parameter.  A replayed step graph with
+    the next batch's sort running one step ahead must give the same bits as eager steps."""
+    from oracle import ffm_iterator_oracle as O
+    from tests.util import random_features
+
+    # no cross_l2 here: its gradient W/||W|| makes Adam oscillate filters around 0 with amplitude ~lr,
+    # which separates ANY fp32 run from the fp64 oracle over 130 steps (the dense path alike)
+    hp = make_hp(optimizer=optimizer, learning_rate=0.005, FEATURE_COUNT=6000, batch_size=32)
+    rng = np.random.default_rng(11)
+    p32 = X.init_params(hp, seed=4)
+    eng = load_engine(hp, p32, "sparse_rows")
+    lazy = load_engine(hp, p32, "sparse_lazy")
+    p64 = {k: v.double() for k, v in p32.items()}
+    st = X.new_opt_state(p64, hp)
+    steps = 130
+    batches = []
+    for k in range(steps):
+        labels, feats = random_features(rng, 32, hp.FIELD_COUNT, hp.FEATURE_COUNT, multi_p=0.0, missing_p=0.0)
+        # a handful of rows come back after long and short absences; 70 -> 129 is a gap of 58 steps late
+        # enough in training for the closed-form remainder to carry 34 of them
+        if k in (0, 3, 5, 30, 70, 129):
+            for f, tok in enumerate(feats[0]):
+                tok[1] = 10 + f
+        batches.append(O.convert(labels, feats, hp.FIELD_COUNT, hp.FEATURE_COUNT))
+    devb = [upload(eng, b) for b in batches]
+    for k in range(steps):
+        eng.train_step(devb[k], next_batch=devb[k + 1] if k + 1 < steps else None)
+        lazy.train_step(upload(lazy, batches[k]))
+        X.train_step(p64, st, batches[k], hp, mode="dense_exact")
+    torch.cuda.synchronize()
+    eng.check_errors()
+    sd, sd_lazy = eng.state_dict(), lazy.state_dict()
+    for k, v in p64.items():
+        got = sd[k].cpu().numpy().reshape(v.shape)
+        assert np.abs(got - v.numpy()).max() <= 2e-4, (k, np.abs(got - v.numpy()).max())
+    if optimizer == "adam":  # the lazy update is measurably a different algorithm here
+        d = np.abs(sd_lazy["embedding"].cpu().numpy() - p64["embedding"].numpy()).max()
+        assert d > 2e-3, d
+    # scoring after training reads flushed rows: predictions against the oracle's
+    pred = eng.forward(devb[-1], with_loss=False).cpu().numpy()
+    close(pred, X.predict(p64, batches[-1], hp).numpy(), rtol=2e-3, what="pred after training")
+
+
+def test_graphed_sparse_rows_step_sorts_one_batch_ahead_and_equals_eager():
+    hp = make_hp(optimizer="adam", learning_rate=0.02, FEATURE_COUNT=2000, batch_size=48)
+    rng = np.random.default_rng(12)
+    p32 = X.init_params(hp, seed=6)
+    batches = [random_batch(rng, hp, 48, multi_p=0.0, missing_p=0.0) for _ in range(9)]
+
+    def dev(b):
+        return [torch.from_numpy(np.ascontiguousarray(a)).cuda() for a in (
+            b["labels"].reshape(-1), b["dnn_feat_indices"], b["dnn_feat_values"], b["dnn_feat_weights"])]
+
+    eager, graph = load_engine(hp, p32, "sparse_rows"), load_engine(hp, p32, "sparse_rows")
+    eager.train_step(upload(eager, batches[0]))
+    gs = graph.capture_step(*dev(batches[0]))  # runs batch 0 once while warming up
+    packed = [gs.pack(*dev(b)) for b in batches]
+    for k in range(1, 9):
+        le = float(eager.train_step(upload(eager, batches[k]))[0])
+        # batches 1-4 announce their successor, 5 does not (eager sort in front of the replay), 6-8 do
+        nxt = packed[k + 1] if (k + 1 < 9 and k != 5) else None
+        lg = float(gs.run_packed(packed[k], nxt)[0])
+        assert le == lg, (k, le, lg)
+    sa, sb = eager.state_dict(), graph.state_dict()
+    assert sa["step"] == sb["step"] == 9
+    for k in sa:
+        if torch.is_tensor(sa[k]):
+            assert torch.equal(sa[k], sb[k]), k
 
 
 def test_dropout_training_matches_oracle_given_the_masks():

@@ -26,7 +26,7 @@ def test_sharded_step_equals_plain_engine_and_oracle(optimizer, virtual_world):
     hp = make_hp(optimizer=optimizer, learning_rate=0.01, FEATURE_COUNT=300, cross_l2=0.01, cross_l1=0.001)
     rng = np.random.default_rng(5)
     p32 = X.init_params(hp, seed=9)
-    plain = XDeepFMEngine(hp, embedding_update="sparse_rows")
+    plain = XDeepFMEngine(hp, embedding_update="sparse_lazy")
     shard = ShardedXDeepFMEngine(hp, virtual_world=virtual_world)
     assert shard.world == 1 and shard.N == 300
     plain.load_state({k: v.clone() for k, v in p32.items()})
@@ -37,7 +37,7 @@ def test_sharded_step_equals_plain_engine_and_oracle(optimizer, virtual_world):
         b = random_batch(rng, hp, 64 if step != 1 else 33)
         l0, d0 = plain.train_step(_upload(plain, b))
         l1, d1 = shard.train_step(_upload(shard, b))
-        o_loss, o_dl, _, _ = X.train_step(p64, st, b, hp, mode="sparse_rows")
+        o_loss, o_dl, _, _ = X.train_step(p64, st, b, hp, mode="sparse_lazy")
         assert abs(float(d1) - o_dl) <= 1e-5 * abs(o_dl)
         assert abs(float(l1) - o_loss) <= 1e-5 * abs(o_loss)
         # same arithmetic in the same order: the two engines agree to the bit on the forward
@@ -106,7 +106,7 @@ def _two_rank_worker(rank, world, port, optimizer, out):
             assert (eng._route_pre is not None) == (nxt is not None)
             tot = torch.stack([loss, dloss]).double().cpu()
             dist.all_reduce(tot)
-            o_loss, o_dl, _, _ = X.train_step(p64, st, O.convert(labels, feats, F, N), hp, mode="sparse_rows")
+            o_loss, o_dl, _, _ = X.train_step(p64, st, O.convert(labels, feats, F, N), hp, mode="sparse_lazy")
             assert abs(float(tot[1]) - o_dl) <= 2e-5 * abs(o_dl), (step, float(tot[1]), o_dl)
             assert abs(float(tot[0]) - o_loss) <= 2e-5 * abs(o_loss), (step, float(tot[0]), o_loss)
         torch.cuda.synchronize()
