@@ -220,12 +220,9 @@ def main():
         batch = pending.pop(i, None)
         if batch is None:
             batch = eng.make_batch(labels, idx, ids, w)  # CSR offsets built on the device
-        if world > 1 or args.sharded:
-            # N > 1: the all-to-all exchanges and the all-reduce are in the step; the routing of
-            # the next batch's ids starts beside this step's compute
-            return eng.train_step(batch, next_ids=resident[(i + 1) % n_batches][2])
-        if getattr(eng, "catchup_on", False):
-            # the following batch is announced: its id sort runs beside this step
+        if world > 1 or args.sharded or getattr(eng, "catchup_on", False):
+            # the following batch is announced: its id sort (one GPU) or its routing to the owners
+            # (N > 1: ids out, exchange sizes, owner-side sort) runs beside this step
             pending[i + 1] = eng.make_batch(*resident[(i + 1) % n_batches])
         return eng.train_step(batch, next_batch=pending.get(i + 1))
 

@@ -162,6 +162,25 @@ int xdfm_embed_gather(const float* table, const float* lin_w, int64_t table_stri
                       float* lin_out, int64_t out_stride, int32_t* err_flag, void* stream);
 
 /* ------------------------------------------------------------------------
+ * Routing for the row-sharded table (owner = id mod G, local row = id div G).
+ * No counterpart in the reference (one device, one table).  Index work, bit-exact.
+ *   xdfm_route_keys: keys[i] = (id mod G) * rpr + id div G, rpr = ceil(N / G) (ids clamped into
+ *     [0, N)).  A stable sort of these keys (xdfm_embed_plan with N = G * rpr) groups the tokens by
+ *     owner, orders them by row inside an owner and puts duplicates side by side.
+ *   xdfm_route_uniq: from that sort (sorted_keys, sorted_tok) the de-duplicated request:
+ *     slot_sorted[n]  slot (0 .. n_uniq-1) of every sorted position        (int32)
+ *     inverse[n]      slot of every token                                   (int64)
+ *     uniq_rows[..]   local row of every slot, grouped by owner, ascending  (int64, n_uniq used)
+ *     first_slot[G+1] first slot of every owner (-1: owner without a row), [G] = n_uniq
+ *     block_scratch   xdfm_route_scratch_ints(n) int32 of scratch
+ * ---------------------------------------------------------------------- */
+int xdfm_route_keys(const int64_t* ids, int64_t n, int64_t N, int32_t G, int64_t* keys, void* stream);
+int xdfm_route_scratch_ints(int64_t n, size_t* ints);
+int xdfm_route_uniq(const int32_t* sorted_keys, const int32_t* sorted_tok, int64_t n, int64_t N, int32_t G,
+                    int32_t* slot_sorted, int64_t* inverse, int64_t* uniq_rows, int32_t* first_slot,
+                    int32_t* block_scratch, void* stream);
+
+/* ------------------------------------------------------------------------
  * Embedding backward: deterministic sorted-key segment sum (+ row update).
  * Replaces TF's gradient of embedding_lookup_sparse / sparse_dense_matmul and
  * AdamOptimizer/AdagradOptimizer.apply_gradients on the table

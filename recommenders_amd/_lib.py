@@ -95,6 +95,9 @@ SIGNATURES = {
     "xdfm_build_row_ptr": [_P, _I64, _I64, _P, _P, _P, _P],
     "xdfm_embed_fwd": [_P, _P, _I64, _I64, _I64, _I32, _I32, _I64, _P, _P, _P, _I64, _P, _P, _P, _P, _P, _P],
     "xdfm_embed_gather": [_P, _P, _I64, _I64, _I64, _I32, _P, _I64, _P, _P, _I64, _P, _P],
+    "xdfm_route_keys": [_P, _I64, _I64, _I32, _P, _P],
+    "xdfm_route_scratch_ints": [_I64, _PSZ],
+    "xdfm_route_uniq": [_P, _P, _I64, _I64, _I32, _P, _P, _P, _P, _P, _P],
     "xdfm_embed_plan_workspace_bytes": [_I64, _I64, _PSZ],
     "xdfm_embed_plan": [_P, _I64, _I64, _P, _P, _P, _SZ, _P],
     "xdfm_embed_plan_static": [_P, _I64, _I64, _P, _P, _P],

@@ -106,8 +106,7 @@ class DeviceBatch(object):
     """One mini-batch resident in HBM (the dnn view of the iterator as CSR)."""
 
     __slots__ = ("B", "nnz", "labels", "ids", "weights", "row_ptr", "tok_row", "sorted_ids",
-                 "sorted_tok", "planned", "plan_event", "src_table", "src_lin", "src_ids", "src_N", "route", "owner_sorted_ids", "owner_sorted_tok",
-                 "owner_event")
+                 "sorted_tok", "planned", "plan_event", "ready_event", "src_table", "src_lin", "src_ids", "src_N", "route")
 
 
 class XDeepFMEngine(object):
@@ -568,6 +567,10 @@ class XDeepFMEngine(object):
         b.sorted_ids = b.sorted_tok = None
         b.planned = False
         b.plan_event = None
+        # what another stream waits for before it reads the batch's arrays (routing one step ahead)
+        b.ready_event = torch.cuda.Event()
+        b.ready_event.record(torch.cuda.current_stream(self.device))
+        b.route = None
         # the sharded engine points these at the rows it fetched from their owners
         b.src_table = b.src_lin = b.src_ids = None
         b.src_N = 0

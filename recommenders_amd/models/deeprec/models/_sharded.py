@@ -40,16 +40,43 @@ def local_rows(n_rows, rank, world):
 
 
 class RoutePlan(object):
-    """Routing state of one batch: partition order, split sizes, ids received as owner."""
+    """Routing state of one batch.  Tokens are sorted by (owner, local row), duplicates side by side;
+    every distinct row is one *slot* of the request sent to its owner.
 
-    __slots__ = ("order", "inverse", "send_counts", "recv_counts", "recv_rows", "n_send", "n_recv")
+    order[n_tok]        token index of every sorted position (stable: equal ids keep token order)
+    slot_sorted[n_tok]  slot of every sorted position (ascending)
+    inverse[n_tok]      slot of every token
+    uniq_rows[n_send]   local row (at its owner) of every slot; slots of one owner are contiguous
+    send_counts[G]      slots per owner;  recv_counts[G]: slots this rank is asked for, per source
+    recv_rows[n_recv]   local rows this rank serves as owner, grouped by source rank
+    owner_sorted_ids / owner_sorted_tok: the owner-side sort of recv_rows (engine)"""
+
+    __slots__ = ("n_tok", "order", "slot_sorted", "inverse", "uniq_rows", "send_counts", "recv_counts",
+                 "recv_rows", "n_send", "n_recv", "owner_sorted_ids", "owner_sorted_tok", "gen")
+
+
+class _Bufs(object):
+    """Grow-only named device buffers: no allocation per step once the batch shape has been seen."""
+
+    def __init__(self, device):
+        self.device = device
+        self.t = {}
+
+    def get(self, name, numel, dtype):
+        t = self.t.get(name)
+        if t is None or t.numel() < numel or t.dtype != dtype:
+            t = torch.empty((max(int(numel * 1.25), 16),), dtype=dtype, device=self.device)
+            self.t[name] = t
+        return t[:numel]
 
 
 class RowShardExchange(object):
-    def __init__(self, group=None, virtual_world=1):
+    def __init__(self, group=None, virtual_world=1, force_collectives=False):
         """virtual_world > 1 (single process only, for tests): partition the tokens as if there
         were that many owners, with every "owner" being this process.  The exchanges are then
-        identities, but the engine sees the permuted token order of a real multi-rank step."""
+        identities, but the engine sees the permuted token order of a real multi-rank step.
+        force_collectives (tests): issue every collective even at world size 1 (an exchange with
+        oneself), so that the RCCL calls of an N-GPU step run on a one-GPU box."""
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
@@ -57,6 +84,9 @@ class RowShardExchange(object):
         # rehearsal mode: the gloo backend has no all-to-all for device tensors, so several ranks
         # sharing one GPU (tests on a one-GPU box) stage their exchanges through the host
         self.host_staged = self.world > 1 and dist.get_backend(group) == "gloo"
+        self.collective = self.world > 1 or bool(force_collectives)
+        self._bufs = {}
+        self._calls = 0
 
     def _a2a(self, out, x, out_splits=None, in_splits=None):
         if self.host_staged and x.is_cuda:
@@ -82,58 +112,132 @@ class RowShardExchange(object):
         else:
             dist.broadcast(x, src=src, group=self.group)
 
-    def route(self, ids):
-        """ids: int64 [n] global feature ids of this rank's tokens.  Sends every id to its
-        owner (as a local row index) and returns the RoutePlan."""
+    def _all_gather_small(self, x):
+        """x: small int32 vector, same length on every rank -> [world, len] on the host."""
+        if not self.collective:
+            return x.cpu().reshape(1, -1)
+        if self.host_staged or not x.is_cuda:
+            h = x.cpu()
+            out = torch.empty((self.world * h.numel(),), dtype=h.dtype)
+            dist.all_gather_into_tensor(out, h, group=self.group)
+            return out.reshape(self.world, -1)
+        out = torch.empty((self.world * x.numel(),), dtype=x.dtype, device=x.device)
+        dist.all_gather_into_tensor(out, x, group=self.group)
+        return out.cpu().reshape(self.world, -1)
+
+    # ------------------------------------------------------------- partition + de-duplication
+    def _partition_host(self, ids, n_rows, G):
+        """torch restatement of xdfm_route_keys / xdfm_embed_plan / xdfm_route_uniq for CPU tensors (the
+        gloo rehearsal of the N > 1 path); on the GPU box it is checked against the kernels."""
+        rpr = (n_rows + G - 1) // G
+        idc = ids.clamp(0, n_rows - 1)
+        keys = (idc % G) * rpr + torch.div(idc, G, rounding_mode="floor")
+        order = torch.argsort(keys, stable=True)
+        sk = keys[order]
+        n = int(ids.numel())
+        head = torch.ones((n,), dtype=torch.bool, device=ids.device)
+        if n > 1:
+            head[1:] = sk[1:] != sk[:-1]
+        slot_sorted = (torch.cumsum(head.to(torch.int64), 0) - 1).to(torch.int32)
+        inverse = torch.empty((n,), dtype=torch.int64, device=ids.device)
+        inverse[order] = slot_sorted.to(torch.int64)
+        uk = sk[head]
+        first = torch.full((G + 1,), -1, dtype=torch.int32, device=ids.device)
+        if n:
+            owner = torch.div(uk, rpr, rounding_mode="floor")
+            oh = torch.ones_like(owner, dtype=torch.bool)
+            oh[1:] = owner[1:] != owner[:-1]
+            first[owner[oh]] = torch.nonzero(oh).reshape(-1).to(torch.int32)
+            first[G] = int(uk.numel())
+        return order.to(torch.int32), slot_sorted, inverse, uk % rpr, first
+
+    def _partition_device(self, ids, n_rows, G):
+        from recommenders_amd.models.deeprec.models._engine import _ptr
+
+        lib = _lib.lib
+        n = int(ids.numel())
+        dev = ids.device
+        slot = self._calls & 1  # the next batch is routed while this one's plan is still in use
+        bufs = self._bufs.setdefault((dev, slot), _Bufs(dev))
+        st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        rpr = (n_rows + G - 1) // G
+        sz = ctypes.c_size_t()
+        _lib.check(lib.xdfm_embed_plan_workspace_bytes(n, G * rpr, ctypes.byref(sz)))
+        ws = bufs.get("ws", sz.value, torch.uint8)
+        _lib.check(lib.xdfm_route_scratch_ints(n, ctypes.byref(sz)))
+        scratch = bufs.get("scratch", sz.value, torch.int32)
+        keys = bufs.get("keys", max(n, 1), torch.int64)
+        sk = bufs.get("sk", max(n, 1), torch.int32)
+        order = bufs.get("order", max(n, 1), torch.int32)
+        slot_sorted = bufs.get("slot_sorted", max(n, 1), torch.int32)
+        inverse = bufs.get("inverse", max(n, 1), torch.int64)
+        uniq_rows = bufs.get("uniq_rows", max(n, 1), torch.int64)
+        first = bufs.get("first", G + 1, torch.int32)
+        _lib.check(lib.xdfm_route_keys(_ptr(ids), n, n_rows, G, _ptr(keys), st))
+        _lib.check(lib.xdfm_embed_plan(_ptr(keys), n, G * rpr, _ptr(sk), _ptr(order), _ptr(ws), ws.numel(), st))
+        _lib.check(lib.xdfm_route_uniq(_ptr(sk), _ptr(order), n, n_rows, G, _ptr(slot_sorted), _ptr(inverse),
+                                       _ptr(uniq_rows), _ptr(first), _ptr(scratch), st))
+        return order[:n], slot_sorted[:n], inverse[:n], uniq_rows, first
+
+    def route(self, ids, n_rows):
+        """ids: int64 [n] global feature ids of this rank's tokens; n_rows: FEATURE_COUNT.  Sorts the
+        tokens by (owner, row), de-duplicates, sends every distinct row to its owner (as a local
+        row index) and returns the RoutePlan.  One collective for the split sizes (+ one host
+        synchronisation), one all-to-all for the rows."""
         G = self.world
+        V = G if G > 1 else self.virtual_world
+        self._calls += 1
         plan = RoutePlan()
         n = int(ids.numel())
-        plan.n_send = n
-        if G == 1 and self.virtual_world > 1:
-            order = torch.argsort(ids % self.virtual_world, stable=True)
-            inverse = torch.empty_like(order)
-            inverse[order] = torch.arange(n, dtype=order.dtype, device=order.device)
-            plan.order, plan.inverse = order, inverse
-            plan.send_counts = plan.recv_counts = [n]
-            plan.recv_rows = ids[order].contiguous()
-            plan.n_recv = n
+        plan.n_tok = n
+        part = self._partition_device if ids.is_cuda else self._partition_host
+        plan.order, plan.slot_sorted, plan.inverse, uniq_rows, first = part(ids, int(n_rows), V)
+        table = self._all_gather_small(first).tolist()  # the step's one host sync: exchange sizes
+
+        def counts_of(row):
+            starts = list(row) if row[V] >= 0 else [0] * (V + 1)  # [V] < 0: that rank holds no token
+            for g in range(V - 1, -1, -1):  # an owner without a row starts where the next one does
+                if starts[g] < 0:
+                    starts[g] = starts[g + 1]
+            return [starts[g + 1] - starts[g] for g in range(V)], starts
+
+        mine, starts = counts_of(table[self.rank])
+        plan.n_send = starts[V]
+        plan.uniq_rows = uniq_rows[:plan.n_send]
+        if not self.collective:
+            plan.send_counts = plan.recv_counts = [plan.n_send]
+            plan.n_recv = plan.n_send
+            if V > 1:
+                # every virtual owner is this process and the table is whole: ask for global ids
+                owner = torch.empty((plan.n_send,), dtype=torch.int64, device=ids.device)
+                for g in range(V):
+                    owner[starts[g]:starts[g + 1]] = g
+                plan.recv_rows = plan.uniq_rows * V + owner
+            else:
+                plan.recv_rows = plan.uniq_rows
             return plan
-        if G == 1:
-            plan.order = plan.inverse = None
-            plan.send_counts = plan.recv_counts = [n]
-            plan.recv_rows = ids
-            plan.n_recv = n
-            return plan
-        dest = ids % G
-        # stable partition by destination: tokens of one destination keep their token order
-        order = torch.argsort(dest, stable=True)
-        send_counts = torch.bincount(dest, minlength=G)
-        recv_counts = torch.empty_like(send_counts)
-        self._a2a(recv_counts, send_counts)
-        both = torch.stack([send_counts, recv_counts]).tolist()  # the step's one host sync: exchange sizes
-        plan.send_counts = [int(v) for v in both[0]]
-        plan.recv_counts = [int(v) for v in both[1]]
-        plan.order = order
-        inverse = torch.empty_like(order)
-        inverse[order] = torch.arange(n, dtype=order.dtype, device=order.device)
-        plan.inverse = inverse
+        plan.send_counts = mine
+        plan.recv_counts = [counts_of(table[src])[0][self.rank] for src in range(G)]
         plan.n_recv = sum(plan.recv_counts)
-        send_rows = torch.div(ids, G, rounding_mode="floor")[order].contiguous()
-        plan.recv_rows = self.to_owner(plan, send_rows)
+        plan.recv_rows = self.to_owner(plan, plan.uniq_rows)
         return plan
 
-    def to_owner(self, plan, x):
-        """x: [n_send, ...] in partition order -> [n_recv, ...] grouped by source rank."""
-        if self.world == 1:
-            return x
-        out = x.new_empty((plan.n_recv,) + tuple(x.shape[1:]))
+    def to_owner(self, plan, x, out=None):
+        """x: [n_send, ...] in slot order -> [n_recv, ...] grouped by source rank."""
+        if not self.collective:
+            if out is None:
+                return x
+            out.copy_(x)
+            return out
+        if out is None:
+            out = x.new_empty((plan.n_recv,) + tuple(x.shape[1:]))
         self._a2a(out, x.contiguous(), plan.recv_counts, plan.send_counts)
         return out
 
     def to_source(self, plan, y, out=None):
-        """y: [n_recv, ...] in the order of plan.recv_rows -> [n_send, ...] in partition order
+        """y: [n_recv, ...] in the order of plan.recv_rows -> [n_send, ...] in slot order
         (into `out` when given)."""
-        if self.world == 1:
+        if not self.collective:
             if out is None:
                 return y
             out.copy_(y)
@@ -148,25 +252,29 @@ class ShardedXDeepFMEngine(XDeepFMEngine):
     """XDeepFMEngine whose table shard is 1/world of the rows.  `train_step(batch)` takes this
     rank's part of the global batch; all ranks must call it with equally sized batches."""
 
-    def __init__(self, hp, device=None, seed=None, group=None, virtual_world=1):
-        self.exchange = RowShardExchange(group, virtual_world=virtual_world)
+    def __init__(self, hp, device=None, seed=None, group=None, virtual_world=1, embedding_update="sparse_rows",
+                 force_collectives=False):
+        self.exchange = RowShardExchange(group, virtual_world=virtual_world, force_collectives=force_collectives)
         self.world, self.rank = self.exchange.world, self.exchange.rank
         if hp.loss == "square_loss":
             raise ValueError("square_loss (a root of a mean) cannot be split over ranks")
         if hp.enable_BN is True:
             raise NotImplementedError("batch statistics over a batch split between ranks are not built")
+        if embedding_update == "dense_exact":
+            raise ValueError("the row-sharded engine updates rows at their owners: sparse_rows or sparse_lazy")
         self.global_rows = int(hp.FEATURE_COUNT)
         rows = local_rows(self.global_rows, self.rank, self.world)
         XDeepFMEngine.__init__(self, hp, device=device, seed=None if seed is None else seed + 7919 * self.rank,
-                               embedding_update="sparse_lazy", table_rows=max(rows, 1))
+                               embedding_update=embedding_update, table_rows=max(rows, 1))
         if self.world > 1:
             self.exchange.broadcast(self.dense, 0)  # replicated parameters start identical
         self.dropout_seed ^= (0x632BE59BD9B4E019 * self.rank) & (2 ** 64 - 1)  # ranks draw different masks
         self._consts = {}
-        self._owner_ws = {}
+        self._owner_ws = _Bufs(self.device)
         self._route_stream = None
         self._route_pre = None
-        # forward + backward + per-token gradients have fixed shapes once the rows are fetched:
+        self._gen_free = {}  # routing-buffer generation -> event after the last step that read it
+        # forward + backward + per-slot gradients have fixed shapes once the rows are fetched:
         # they replay as one HIP graph between the (variable-size) exchanges
         self.graph_local = True
         self._local_graphs = {}
@@ -187,27 +295,50 @@ class ShardedXDeepFMEngine(XDeepFMEngine):
         return t
 
     def _owner_buf(self, name, numel, dtype=torch.float32):
-        t = self._owner_ws.get(name)
-        if t is None or t.numel() < numel or t.dtype != dtype:
-            t = torch.empty((max(int(numel * 1.25), 1),), dtype=dtype, device=self.device)
-            self._owner_ws[name] = t
-        return t
+        return self._owner_ws.get(name, max(int(numel), 1), dtype)
 
     # -------------------------------------------------------------------- step
-    def fetch_rows(self, batch, static=None):
-        """Route the batch's ids, gather at the owners, bring the rows back.  Afterwards the
-        batch reads its embeddings from the fetched rows (token j -> fetched row inverse[j]).
-        static: a _LocalGraph whose buffers receive the rows instead of fresh tensors."""
+    def _prepare(self, batch):
+        """Route the batch's ids and sort, at this owner, the rows it is asked for (current stream)."""
+        plan = self.exchange.route(batch.ids, self.global_rows)
+        n = plan.n_recv
+        # two generations alive at a time: this step's and the prefetched next one's
+        gen = plan.gen = self.exchange._calls & 1
+        plan.owner_sorted_ids = self._owner_buf("osid%d" % gen, n, torch.int32)
+        plan.owner_sorted_tok = self._owner_buf("ostk%d" % gen, n, torch.int32)
+        if n:
+            sz = ctypes.c_size_t()
+            _lib.check(self.lib.xdfm_embed_plan_workspace_bytes(n, self.N, ctypes.byref(sz)))
+            ws = self._owner_buf("plan_ws%d" % gen, sz.value, torch.uint8)
+            ev = self._mark("owner_plan")
+            _lib.check(
+                self.lib.xdfm_embed_plan(_ptr(plan.recv_rows), n, self.N, _ptr(plan.owner_sorted_ids),
+                                         _ptr(plan.owner_sorted_tok), _ptr(ws), ws.numel(), self._stream())
+            )
+            self._done(ev)
+        return plan
+
+    def fetch_rows(self, batch, static=None, train=True):
+        """Route the batch's ids (unless that was prefetched), catch the requested rows up, gather them at
+        the owners, bring them back.  Afterwards the batch reads its embeddings from the fetched rows
+        (token j -> fetched row inverse[j]).  static: a _LocalGraph whose buffers receive the rows."""
         hp, lib, st = self.hp, self.lib, self._stream()
         D = self.D
         use_lin = bool(hp.use_Linear_part)
-        plan = self._take_prefetched_route(batch.ids)
+        plan = self._take_prefetched_route(batch)
         if plan is None:
-            plan = self.exchange.route(batch.ids)
+            plan = self._prepare(batch)
         n_recv = plan.n_recv
+        if train and self.catchup_on and n_recv:
+            # the rows about to be read take the steps they missed; their update follows in this step
+            ev = self._mark("embed_catchup")
+            self.catchup(plan.owner_sorted_ids, n_recv, 1)
+            self._done(ev)
+            self._rows_stale = True
         # [row | linear weight | pad] records: rows and weights come back in one all-to-all
         DP = D + 4 if use_lin else D
-        comb = torch.empty((n_recv, DP), dtype=torch.float32, device=self.device)
+        comb = self._owner_buf("comb", n_recv * DP).view(n_recv, DP) if n_recv else torch.empty(
+            (0, DP), dtype=torch.float32, device=self.device)
         if n_recv:
             ev = self._mark("owner_gather")
             _lib.check(
@@ -219,91 +350,56 @@ class ShardedXDeepFMEngine(XDeepFMEngine):
             )
             self._done(ev)
         batch.route = plan
-        # owner-side sort of the received row ids: runs beside the forward pass
-        self._owner_plan_async(batch)
         if static is not None:
-            self.exchange.to_source(plan, comb, out=static.src_comb)
-            static.src_ids.copy_(self._arange64(batch.nnz)[:batch.nnz] if plan.inverse is None else plan.inverse)
+            self.exchange.to_source(plan, comb, out=static.src_comb[:plan.n_send])
             return
-        src = self.exchange.to_source(plan, comb)
+        src = self.exchange.to_source(plan, comb, out=self._owner_buf("src", plan.n_send * DP).view(plan.n_send, DP)
+                                      if plan.n_send else None)
         batch.src_table = src[:, :D]
         batch.src_lin = src[:, D] if use_lin else None
-        if plan.inverse is None:
-            batch.src_ids = self._arange64(batch.nnz)
-        else:
-            batch.src_ids = plan.inverse
-        batch.src_N = max(batch.nnz, 1)
+        batch.src_ids = plan.inverse
+        batch.src_N = max(plan.n_send, 1)
 
-    def prefetch_route(self, ids):
-        """Route the ids of the NEXT batch (ids to their owners, exchange sizes to the host) on a
+    def prefetch_route(self, next_batch):
+        """Route the NEXT batch (ids to their owners, exchange sizes to the host, owner-side sort) on a
         stream of its own while this step computes: the one host synchronisation of a step then
         waits for a few small kernels instead of for everything enqueued before it, and the host
         can enqueue the next step while the GPU still works on this one.  Every rank must call
-        it at the same point of its step (it issues collectives)."""
-        if ids is None or (self.world == 1 and self.exchange.virtual_world == 1):
+        it at the same point of its step (it issues collectives) and must hand exactly that batch
+        to its next train_step."""
+        if next_batch is None:
             return
         if self._route_stream is None:
             self._route_stream = torch.cuda.Stream(device=self.device)
         rs = self._route_stream
-        with torch.cuda.stream(rs):  # the ids of a later batch do not depend on this step
-            plan = self.exchange.route(ids)
+        ready = getattr(next_batch, "ready_event", None)
+        if ready is not None:
+            rs.wait_event(ready)  # the copy / kernels that produced the batch's arrays
+        else:
+            rs.wait_stream(torch.cuda.current_stream(self.device))
+        free = self._gen_free.get((self.exchange._calls + 1) & 1)
+        if free is not None:
+            rs.wait_event(free)  # the step before this one still read that generation's buffers
+        with torch.cuda.stream(rs):
+            plan = self._prepare(next_batch)
             done = torch.cuda.Event()
             done.record(rs)
-        self._route_pre = (ids, plan, done)
+        self._route_pre = (next_batch, plan, done)
 
-    def _take_prefetched_route(self, ids):
+    def _take_prefetched_route(self, batch):
         pre, self._route_pre = self._route_pre, None
-        if pre is None or pre[0] is not ids:
+        if pre is None:
             return None
+        if pre[0] is not batch:
+            # routing issues collectives: a rank that silently routed again would fall out of step
+            # with its peers
+            raise RuntimeError("train_step got a different batch than the one announced as next_batch")
         _, plan, done = pre
-        main = torch.cuda.current_stream(self.device)
-        main.wait_event(done)
-        for t in (plan.order, plan.inverse, plan.recv_rows):
-            if torch.is_tensor(t) and t.is_cuda:
-                t.record_stream(main)  # allocated on the route stream, read on this one
+        torch.cuda.current_stream(self.device).wait_event(done)
         return plan
 
-    def _arange64(self, n):
-        t = self._consts.get("arange64")
-        if t is None or t.numel() < n:
-            t = torch.arange(max(n, 1024), dtype=torch.int64, device=self.device)
-            self._consts["arange64"] = t
-        return t
-
-    def _owner_plan_async(self, batch):
-        plan = batch.route
-        n = plan.n_recv
-        batch.owner_sorted_ids = torch.empty((max(n, 1),), dtype=torch.int32, device=self.device)
-        batch.owner_sorted_tok = torch.empty((max(n, 1),), dtype=torch.int32, device=self.device)
-        batch.owner_event = None
-        if n == 0:
-            return
-        sz = ctypes.c_size_t()
-        _lib.check(self.lib.xdfm_embed_plan_workspace_bytes(n, self.N, ctypes.byref(sz)))
-        ws = self._owner_buf("plan_ws", sz.value, torch.uint8)
-        main = torch.cuda.current_stream(self.device)
-        if self._side_stream is None:
-            self._side_stream = torch.cuda.Stream(device=self.device)
-        ready = torch.cuda.Event()
-        ready.record(main)
-        self._side_stream.wait_event(ready)
-        with torch.cuda.stream(self._side_stream):
-            ev = self._mark("owner_plan")
-            _lib.check(
-                self.lib.xdfm_embed_plan(_ptr(plan.recv_rows), n, self.N, _ptr(batch.owner_sorted_ids),
-                                         _ptr(batch.owner_sorted_tok), _ptr(ws), ws.numel(), self._stream())
-            )
-            self._done(ev)
-            batch.owner_event = torch.cuda.Event()
-            batch.owner_event.record(self._side_stream)
-
-    def _grad_records(self, nnz):
-        """[gradient row | linear gradient | pad] per token: one buffer, one all-to-all."""
-        DP = self.D + 4 if self.hp.use_Linear_part else self.D
-        return torch.empty((max(nnz, 1), DP), dtype=torch.float32, device=self.device)
-
-    def _token_grads(self, batch, order32, send_c):
-        """Per-token gradient records in partition order (segment i = token order[i]) into
+    def _token_grads(self, batch, seg_ids, order32, send_c):
+        """Per-slot gradient records (the tokens of one distinct row pre-reduced in token order) into
         send_c; `batch` carries src_table, tok_row, weights."""
         hp, lib, ws, st = self.hp, self.lib, self.ws, self._stream()
         D, nnz = self.D, batch.nnz
@@ -316,7 +412,7 @@ class ShardedXDeepFMEngine(XDeepFMEngine):
             lib.xdfm_embed_bwd(
                 1, _ptr(batch.src_table), None, None, None, None, None, batch.src_table.stride(0), 0, _ptr(send_c),
                 _ptr(send_c[:, D]) if use_lin else None, max(nnz, 1), D, self.F, batch.B,
-                _ptr(self._arange32(nnz)), _ptr(order32), _ptr(batch.tok_row), _ptr(batch.weights), nnz,
+                _ptr(seg_ids), _ptr(order32), _ptr(batch.tok_row), _ptr(batch.weights), nnz,
                 _ptr(ws["d_emb"]), _ptr(ws["g_logit"]) if (use_lin or use_fm) else None,
                 _ptr(ws["fm_sum"]) if use_fm else None, 1 if use_fm else 0, ctypes.byref(opt),
                 _ptr(ws["pieces"]), _ptr(self.d_emb2()), send_c.stride(0) if use_lin else 0, st,
@@ -325,18 +421,18 @@ class ShardedXDeepFMEngine(XDeepFMEngine):
         self._done(ev)
 
     def _owner_update(self, batch, send_c):
-        """Gradient rows to their owners, then the owner's sorted-key segment sum over what
-        arrived + fused sparse row optimizer."""
+        """Gradient records to their owners, then the owner's sorted-key segment sum over what
+        arrived (source-rank order: reproducible) + fused sparse row optimizer."""
         hp, lib, st = self.hp, self.lib, self._stream()
-        D, nnz = self.D, batch.nnz
+        D = self.D
         use_lin = bool(hp.use_Linear_part)
         plan = batch.route
         opt = self._opt_args()
-        recv_c = self.exchange.to_owner(plan, send_c[:nnz])
         n = plan.n_recv
+        DP = send_c.shape[1]
+        recv_c = self.exchange.to_owner(plan, send_c[:plan.n_send],
+                                        out=self._owner_buf("recv_c", n * DP).view(n, DP) if n else None)
         if n:
-            if batch.owner_event is not None:
-                torch.cuda.current_stream(self.device).wait_event(batch.owner_event)
             pieces = self._owner_buf("pieces", 2 * (n // 64 + 1) * (D + 1))
             ev = self._mark("owner_update")
             _lib.check(
@@ -345,7 +441,7 @@ class ShardedXDeepFMEngine(XDeepFMEngine):
                     _ptr(self.lin_w) if use_lin else None, _ptr(self.lin_m) if use_lin else None,
                     _ptr(self.lin_v) if use_lin else None, self.table_stride, self.lin_stride, None, None,
                     self.N, D, 1, n,
-                    _ptr(batch.owner_sorted_ids), _ptr(batch.owner_sorted_tok), _ptr(self._arange32(n)),
+                    _ptr(plan.owner_sorted_ids), _ptr(plan.owner_sorted_tok), _ptr(self._arange32(n)),
                     _ptr(self._ones(n)), n, _ptr(recv_c), _ptr(recv_c[:, D]) if use_lin else None, None, 0,
                     ctypes.byref(opt), _ptr(pieces), None, recv_c.stride(0) if use_lin else 0, st,
                 )
@@ -355,9 +451,9 @@ class ShardedXDeepFMEngine(XDeepFMEngine):
     def _update_embedding(self, batch):
         nnz = batch.nnz
         plan = batch.route
-        send_c = self._grad_records(nnz)
-        order32 = (self._arange32(nnz) if plan.order is None else plan.order.to(torch.int32))
-        self._token_grads(batch, order32, send_c)
+        DP = self.D + 4 if self.hp.use_Linear_part else self.D
+        send_c = self._owner_buf("send_c", max(nnz, 1) * DP).view(max(nnz, 1), DP)
+        self._token_grads(batch, plan.slot_sorted, plan.order, send_c)
         self._owner_update(batch, send_c)
         return True
 
@@ -365,18 +461,23 @@ class ShardedXDeepFMEngine(XDeepFMEngine):
     def _local_graph(self, batch):
         key = (batch.B, batch.nnz)
         g = self._local_graphs.get(key)
+        if g is not None and g.ws_token != self._ws_token:
+            # the workspace was re-allocated (a larger batch came through): its addresses are stale
+            self._local_graphs.clear()
+            g = None
         if g is None and len(self._local_graphs) < 4:
             g = _LocalGraph(self, batch)
             self._local_graphs[key] = g
         return g
 
-    def train_step(self, batch, next_ids=None):
+    def train_step(self, batch, next_batch=None):
         """One optimisation step on this rank's share of the global batch.  Returns this
         rank's (total_loss share, data_loss share) as device scalars: their sum over the ranks
         is the global mean loss (regularisation counted once, on rank 0's share).
-        next_ids: the ids tensor of the batch the next call will get (the same object as its
-        batch.ids): its routing is started beside this step's compute (prefetch_route)."""
+        next_batch: the batch the next call will get: its routing is started beside this step's
+        compute (prefetch_route)."""
         self.mean_count = batch.B * self.world
+        self._ensure_ws(batch.B, batch.nnz)
         g = None
         if self.graph_local and self.kernel_events is None and batch.nnz > 0:
             g = self._local_graph(batch)  # None: too many shapes seen, stay eager
@@ -395,7 +496,7 @@ class ShardedXDeepFMEngine(XDeepFMEngine):
                     g.graph = None
             if g.graph is not None:
                 g.graph.replay()
-                self.prefetch_route(next_ids)
+                self.prefetch_route(next_batch)
                 self._advance_step()
                 self._owner_update(batch, g.send_c)
             else:
@@ -404,27 +505,31 @@ class ShardedXDeepFMEngine(XDeepFMEngine):
                 batch.src_N = max(batch.nnz, 1)
                 self.forward(batch, with_loss=True, with_grad=True)
                 self.backward(batch)
-                self.prefetch_route(next_ids)
+                self.prefetch_route(next_batch)
                 self._advance_step()
                 self._update_embedding(batch)
         else:
             self.fetch_rows(batch)
             self.forward(batch, with_loss=True, with_grad=True)
             self.backward(batch)
-            self.prefetch_route(next_ids)
+            self.prefetch_route(next_batch)
             self._advance_step()
             self._update_embedding(batch)
         self.join_late()
-        if self.world > 1:
+        if self.exchange.collective:
             ev = self._mark("dense_allreduce")
             self.exchange.all_reduce(self.dense_grad)
             self._done(ev)
         self._update_dense(True)
+        done = torch.cuda.Event()
+        done.record(torch.cuda.current_stream(self.device))
+        self._gen_free[batch.route.gen] = done
         reg = self.reg_loss if self.rank == 0 else torch.zeros_like(self.reg_loss)
         return (self.data_loss + reg)[0], self.data_loss[0].clone()
 
     def predict_batch(self, batch):
-        self.fetch_rows(batch)
+        self.flush_rows()
+        self.fetch_rows(batch, train=False)
         return self.forward(batch, with_loss=False)
 
     # ------------------------------------------------------- table import / export
@@ -440,6 +545,7 @@ class ShardedXDeepFMEngine(XDeepFMEngine):
 
     def gather_global_table(self):
         """Full [FEATURE_COUNT, D] table and lin_w on every rank (tests / export)."""
+        self.flush_rows()
         G = self.world
         n = self.global_rows
         full = torch.zeros((n, self.D), dtype=torch.float32, device=self.device)
@@ -474,6 +580,10 @@ class _LocalGraph(object):
         self.src_lin = self.src_comb[:, D] if use_lin else None
         self.src_ids = torch.zeros((nnz,), dtype=torch.int64, device=dev)
         self.order32 = torch.zeros((nnz,), dtype=torch.int32, device=dev)
+        # the segment keys of the per-slot pre-reduction: a buffer of this graph's own (a captured
+        # launch keeps the address it was recorded with)
+        self.seg_ids = torch.zeros((nnz,), dtype=torch.int32, device=dev)
+        self.ws_token = eng._ws_token
         self.send_c = torch.zeros((nnz, D + 4 if use_lin else D), dtype=f32, device=dev)
         sb = DeviceBatch()
         sb.B, sb.nnz = B, nnz
@@ -508,7 +618,7 @@ class _LocalGraph(object):
         eng = self.eng
         eng.forward(self.batch, with_loss=True, with_grad=True)
         eng.backward(self.batch)
-        eng._token_grads(self.batch, self.order32, self.send_c)
+        eng._token_grads(self.batch, self.seg_ids, self.order32, self.send_c)
         eng.join_late()  # every fork is joined before a capture ends
 
     def load(self, batch):
@@ -518,7 +628,6 @@ class _LocalGraph(object):
         sb.weights.copy_(batch.weights)
         sb.row_ptr.copy_(batch.row_ptr)
         sb.tok_row.copy_(batch.tok_row)
-        if plan.order is None:
-            self.order32.copy_(self.eng._arange32(batch.nnz)[:batch.nnz])
-        else:
-            self.order32.copy_(plan.order)
+        self.order32.copy_(plan.order)
+        self.seg_ids.copy_(plan.slot_sorted)
+        self.src_ids.copy_(plan.inverse)

@@ -26,21 +26,25 @@ def test_sharded_step_equals_plain_engine_and_oracle(optimizer, virtual_world):
     hp = make_hp(optimizer=optimizer, learning_rate=0.01, FEATURE_COUNT=300, cross_l2=0.01, cross_l1=0.001)
     rng = np.random.default_rng(5)
     p32 = X.init_params(hp, seed=9)
-    plain = XDeepFMEngine(hp, embedding_update="sparse_lazy")
+    plain = XDeepFMEngine(hp, embedding_update="sparse_rows")
     shard = ShardedXDeepFMEngine(hp, virtual_world=virtual_world)
     assert shard.world == 1 and shard.N == 300
     plain.load_state({k: v.clone() for k, v in p32.items()})
     shard.load_global_state({k: v.clone() for k, v in p32.items()})
     p64 = {k: v.double() for k, v in p32.items()}
     st = X.new_opt_state(p64, hp)
-    for step in range(3):
-        b = random_batch(rng, hp, 64 if step != 1 else 33)
+    batches = [random_batch(rng, hp, 64 if step not in (1, 4) else 33) for step in range(6)]
+    dev = [_upload(shard, b) for b in batches]
+    for step, b in enumerate(batches):
         l0, d0 = plain.train_step(_upload(plain, b))
-        l1, d1 = shard.train_step(_upload(shard, b))
-        o_loss, o_dl, _, _ = X.train_step(p64, st, b, hp, mode="sparse_lazy")
+        # steps 0-2 announce their successor (routing one step ahead), 3 does not, 4 does
+        nxt = dev[step + 1] if (step + 1 < len(dev) and step != 3) else None
+        l1, d1 = shard.train_step(dev[step], next_batch=nxt)
+        # the reference's semantics: every row moves every step (rows are caught up at their owner)
+        o_loss, o_dl, _, _ = X.train_step(p64, st, b, hp, mode="dense_exact")
         assert abs(float(d1) - o_dl) <= 1e-5 * abs(o_dl)
         assert abs(float(l1) - o_loss) <= 1e-5 * abs(o_loss)
-        # same arithmetic in the same order: the two engines agree to the bit on the forward
+        # same rows read, same forward arithmetic: the two engines agree to the bit on the data loss
         assert float(d0) == float(d1)
     torch.cuda.synchronize()
     shard.check_errors()
@@ -55,7 +59,32 @@ def test_sharded_step_equals_plain_engine_and_oracle(optimizer, virtual_world):
         err = np.abs(shard.views[k].cpu().numpy() - exp).max()
         assert err <= tol * max(np.abs(exp).max(), 1e-30), (k, err)
     # plain engine took the same steps
-    assert np.abs(plain.table.cpu().numpy() - table.cpu().numpy()).max() <= 1e-6
+    assert np.abs(plain.state_dict()["embedding"].cpu().numpy() - table.cpu().numpy()).max() <= 1e-6
+
+
+def test_device_partition_equals_its_torch_restatement():
+    """xdfm_route_keys + the radix sort + xdfm_route_uniq against RowShardExchange._partition_host (the
+    torch form the gloo rehearsal on CPU tensors runs): bit-exact, incl. hot ids, an owner without
+    a row and ragged sizes around the kernels' 1024-position tiles."""
+    from recommenders_amd.models.deeprec.models._sharded import RowShardExchange
+
+    ex = RowShardExchange()
+    rng = np.random.default_rng(3)
+    for n, n_rows, G in ((1, 10, 1), (1023, 50, 3), (1024, 1000, 8), (1025, 7, 8), (50000, 1 << 20, 8),
+                         (319488, 1 << 25, 8), (4000, 1000, 4)):
+        ids = rng.integers(0, n_rows, n)
+        ids[rng.random(n) < 0.3] = ids[0]
+        if G == 4:
+            ids = ids[ids % 4 != 2]  # owner 2 gets nothing
+        ids = torch.from_numpy(ids)
+        host = ex._partition_host(ids, n_rows, G)
+        devp = ex._partition_device(ids.cuda(), n_rows, G)
+        torch.cuda.synchronize()
+        n_uniq = int(host[4][G])
+        assert torch.equal(host[4], devp[4].cpu()), (n, n_rows, G)
+        for h, d, name in zip(host[:3], devp[:3], ("order", "slot_sorted", "inverse")):
+            assert torch.equal(h, d.cpu()), (name, n, n_rows, G)
+        assert torch.equal(host[3], devp[3][:n_uniq].cpu())
 
 
 def _free_port():
@@ -86,14 +115,14 @@ def _two_rank_worker(rank, world, port, optimizer, out):
         F, N = hp.FIELD_COUNT, hp.FEATURE_COUNT
         p32 = X.init_params(hp, seed=9)
         eng = ShardedXDeepFMEngine(hp, seed=7)
-        assert eng.world == world and eng.exchange.host_staged
+        assert eng.world == world and eng.exchange.host_staged and eng.catchup_on == (optimizer == "adam")
         eng.load_global_state({k: v.clone() for k, v in p32.items()})
         p64 = {k: v.double() for k, v in p32.items()}
         st = X.new_opt_state(p64, hp)
         rng = np.random.default_rng(21)  # every rank draws the same global batches
         per = 48
         steps = []
-        for step in range(3):
+        for step in range(5):
             labels, feats = random_features(rng, per * world, F, N)
             for toks in feats[:8]:
                 toks.append([0, 5, 1.0])  # a row that several ranks touch in one step
@@ -101,12 +130,12 @@ def _two_rank_worker(rank, world, port, optimizer, out):
             steps.append((labels, feats, _upload(eng, mine)))
         for step, (labels, feats, dev_batch) in enumerate(steps):
             # the next batch's ids are routed beside this step (prefetch_route), except the last one's
-            nxt = steps[step + 1][2].ids if step + 1 < len(steps) else None
-            loss, dloss = eng.train_step(dev_batch, next_ids=nxt)
+            nxt = steps[step + 1][2] if step + 1 < len(steps) else None
+            loss, dloss = eng.train_step(dev_batch, next_batch=nxt)
             assert (eng._route_pre is not None) == (nxt is not None)
             tot = torch.stack([loss, dloss]).double().cpu()
             dist.all_reduce(tot)
-            o_loss, o_dl, _, _ = X.train_step(p64, st, O.convert(labels, feats, F, N), hp, mode="sparse_lazy")
+            o_loss, o_dl, _, _ = X.train_step(p64, st, O.convert(labels, feats, F, N), hp, mode="dense_exact")
             assert abs(float(tot[1]) - o_dl) <= 2e-5 * abs(o_dl), (step, float(tot[1]), o_dl)
             assert abs(float(tot[0]) - o_loss) <= 2e-5 * abs(o_loss), (step, float(tot[0]), o_loss)
         torch.cuda.synchronize()
@@ -148,3 +177,55 @@ def test_two_ranks_sharing_the_gpu_match_the_oracle_on_the_global_batch(optimize
     for p in procs:
         p.join(timeout=30)
     assert sorted(res) == [(r, "ok") for r in range(world)], res
+
+
+def _rccl_worker(port, out):
+    """One rank over the nccl (= RCCL) backend with every collective of the N-GPU step issued for
+    real (an exchange with oneself): the calls, dtypes and split lists of the multi-GPU path."""
+    import os
+
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        hp = make_hp(optimizer="adam", learning_rate=0.01, FEATURE_COUNT=300)
+        p32 = X.init_params(hp, seed=9)
+        eng = ShardedXDeepFMEngine(hp, seed=7, force_collectives=True)
+        assert eng.exchange.collective and not eng.exchange.host_staged
+        eng.load_global_state({k: v.clone() for k, v in p32.items()})
+        p64 = {k: v.double() for k, v in p32.items()}
+        st = X.new_opt_state(p64, hp)
+        rng = np.random.default_rng(31)
+        batches = [random_batch(rng, hp, 64) for _ in range(4)]
+        dev = [_upload(eng, b) for b in batches]
+        for k, b in enumerate(batches):
+            loss, dloss = eng.train_step(dev[k], next_batch=dev[k + 1] if k + 1 < len(dev) else None)
+            o_loss, o_dl, _, _ = X.train_step(p64, st, b, hp, mode="dense_exact")
+            assert abs(float(dloss) - o_dl) <= 1e-5 * abs(o_dl), (k, float(dloss), o_dl)
+        torch.cuda.synchronize()
+        eng.check_errors()
+        table, _ = eng.gather_global_table()
+        err = np.abs(table.cpu().numpy() - p64["embedding"].numpy()).max()
+        assert err <= 2e-4 * np.abs(p64["embedding"].numpy()).max(), err
+        out.put("ok")
+    except Exception:  # noqa: BLE001
+        import traceback
+
+        out.put(traceback.format_exc())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_collectives_of_the_sharded_step_run_over_rccl():
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    p = ctx.Process(target=_rccl_worker, args=(_free_port(), out))
+    p.start()
+    res = out.get(timeout=110)
+    p.join(timeout=30)
+    assert res == "ok", res

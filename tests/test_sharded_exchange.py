@@ -36,22 +36,30 @@ def _worker(rank, world, port, n_rows, dim, out):
         n = 500 + 37 * rank                           # ragged: ranks hold different token counts
         ids = torch.from_numpy(rng.integers(0, n_rows, n))
         ids[:50] = 3                                  # a hot id
+        if rank == world - 1:
+            ids = ids[ids % world != 0]               # this rank asks owner 0 for nothing
+            n = int(ids.numel())
         ex = RowShardExchange()
-        plan = ex.route(ids)
-        # owner side: local row -> row, in the order the ids arrived
+        plan = ex.route(ids, n_rows)
+        # every distinct id is asked for once: one slot per distinct row, grouped by owner
+        assert plan.n_send == len(torch.unique(ids)) and sum(plan.send_counts) == plan.n_send
+        # owner side: local row -> row, in the order the requests arrived
         assert int(plan.recv_rows.max()) < shard.shape[0]
         rows_back = ex.to_source(plan, shard[plan.recv_rows])
         got = rows_back[plan.inverse]                 # token order
         assert torch.equal(got, table[ids])
-        # partition order really is a stable partition by owner
-        dest = (ids % world)[plan.order]
+        # the sorted order is by (owner, row), equal ids in token order (stable)
+        order = plan.order.long()
+        dest = (ids % world)[order]
         assert torch.equal(dest, torch.sort(dest).values)
-        for d in range(world):
-            sel = plan.order[dest == d]
-            assert torch.equal(sel, torch.sort(sel).values)
-        # gradients out: one row per token, summed at the owner in arrival order
+        key = (ids % world) * ((n_rows + world - 1) // world) + ids // world
+        assert torch.equal(order, torch.argsort(key, stable=True))
+        assert torch.equal(plan.inverse[order], plan.slot_sorted.long())
+        # gradients out: the tokens of one row pre-reduced at the source, one record per slot, summed at
+        # the owner in arrival order
         grads = torch.randn(n, dim, dtype=torch.float64)
-        recv_g = ex.to_owner(plan, grads[plan.order])
+        pre = torch.zeros(plan.n_send, dim, dtype=torch.float64).index_add_(0, plan.inverse, grads)
+        recv_g = ex.to_owner(plan, pre)
         acc = torch.zeros(shard.shape[0], dim, dtype=torch.float64)
         acc.index_add_(0, plan.recv_rows, recv_g)
         # reference: every rank's contributions gathered the slow way
@@ -90,8 +98,10 @@ def test_row_shard_exchange_gloo(world):
 def test_single_rank_exchange_is_identity():
     ex = RowShardExchange()
     ids = torch.tensor([5, 1, 5, 9])
-    plan = ex.route(ids)
-    assert plan.n_recv == 4 and plan.inverse is None
-    x = torch.arange(8.0).reshape(4, 2)
+    plan = ex.route(ids, 10)
+    # one rank: nothing travels, but duplicates still collapse to one slot per distinct row
+    assert plan.n_send == plan.n_recv == 3 and plan.recv_rows.tolist() == [1, 5, 9]
+    assert plan.inverse.tolist() == [1, 0, 1, 2] and plan.order.tolist() == [1, 0, 2, 3]
+    x = torch.arange(6.0).reshape(3, 2)
     assert ex.to_owner(plan, x) is x and ex.to_source(plan, x) is x
     assert [local_rows(10, r, 4) for r in range(4)] == [3, 3, 2, 2]
