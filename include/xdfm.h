@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define XDFM_ABI_VERSION 1
+#define XDFM_ABI_VERSION 2
 
 #define XDFM_OK 0
 #define XDFM_E_INVALID (-1)   /* bad argument (null pointer, size, enum) */
@@ -201,6 +201,13 @@ int xdfm_embed_plan(const int64_t* ids, int64_t nnz, int64_t N, int32_t* sorted_
 int xdfm_embed_plan_static(const int64_t* ids, int64_t nnz, int64_t N, int32_t* sorted_ids,
                            int32_t* sorted_tok, void* stream);
 
+/* tok_row and weights in sorted order (row_sorted[p] = tok_row[sorted_tok[p]], w_sorted[p] =
+ * weights[sorted_tok[p]]): xdfm_embed_bwd called with sorted_tok = NULL reads them in place of its
+ * two dependent 4-byte gathers per token.  Depends on the batch only: a step runs it beside its
+ * forward pass. */
+int xdfm_embed_plan_gather(const int32_t* sorted_tok, const int32_t* tok_row, const float* weights,
+                           int64_t nnz, int32_t* row_sorted, float* w_sorted, void* stream);
+
 typedef struct xdfm_opt_args {
   int32_t kind;       /* XDFM_OPT_* */
   float lr;           /* learning_rate */
@@ -233,6 +240,7 @@ int xdfm_opt_advance(float* opt_state, float lr, float beta1, float beta2, void*
  *                         ids are left as they are: the caller keeps them zero).
  *   pieces: float scratch of 2*(nnz/64 + 1)*(D + 1) elements (partial sums of the segments that
  *   cross a 64-token chunk boundary).
+ *   sorted_tok = NULL: tok_row and weights are already in sorted order (xdfm_embed_plan_gather).
  *   d_emb[B,F,D]; d_emb2: NULL, or a second [B,F,D] array added to d_emb as it is read (two
  *   producers, e.g. the CIN and the DNN tower, then need no common accumulator);
  *   g_logit[B] and fm_sum[B,D] only when the FM / linear parts are on.
@@ -257,7 +265,8 @@ int xdfm_embed_bwd(int32_t mode, float* table, float* slot_m, float* slot_v, flo
  * (the first position of each run of equal ids works; NULL: all N rows, n ignored) up to the step
  * count in opt->opt_state[3] and writes that count + advance into row_step (advance = 1 before a
  * training step whose xdfm_embed_bwd will update exactly these rows; 0 for a flush before scoring or
- * a checkpoint).  The first 24 missed steps are applied one by one in TF's expression order, the
+ * a checkpoint; -1 takes a mark back: rows dated later than the step count -- prepared for a step that
+ * then went to another batch -- are re-dated to it, nothing else changes).  The first 24 missed steps are applied one by one in TF's expression order, the
  * geometric remainder in closed form (|error| < 1e-5).  RMSProp / Adadelta decay their accumulators;
  * FTRL re-derives p = -linear / quadratic as TF's dense ApplyFtrl does every step (a row that never
  * had a gradient becomes 0); SGD and Adagrad have no drift (a no-op apart from row_step). */
@@ -343,7 +352,11 @@ int xdfm_cin_bwd(const float* x0, const float* xk, const float* w, int64_t B, in
  *     XDFM_CIN_BWD_DW = XDFM_CIN_BWD_DW_PARTIAL (per-split partial sums into dw_part) followed by
  *     XDFM_CIN_BWD_DW_REDUCE (dw_part -> d_w); the reduction is a short kernel that nothing but
  *     the optimizer waits for, so a caller may give it to another stream as well (dw_part must
- *     stay untouched in between). */
+ *     stay untouched in between).
+ *     d_x0 = this layer's contribution + d_x0_in + d_x0_in2 (each [B,F,D] or NULL; d_x0_in = d_x0 is
+ *     xdfm_cin_bwd's "accumulated into").  The layer that runs first can write instead of adding to
+ *     a cleared array, the one that runs last can fold a second producer's gradient (the DNN
+ *     tower's) in: the table gradient then reads one array per token. */
 #define XDFM_CIN_BWD_DX 1
 #define XDFM_CIN_BWD_DW 2
 #define XDFM_CIN_BWD_DW_PARTIAL 4
@@ -364,7 +377,7 @@ int xdfm_cin_bwd_packed(const float* x0, const float* xk, const float* bwd_image
                         int32_t H, int32_t D, int32_t L, int32_t n_hidden, int32_t masked,
                         const float* d_xnext, const float* d_pooled, int32_t pool_stride,
                         int32_t pool_off, float* d_xk, float* d_x0, float* d_w, float* dw_part,
-                        int32_t phases, void* stream);
+                        int32_t phases, const float* d_x0_in, const float* d_x0_in2, void* stream);
 
 /* cross_activation (xDeepFM.py:242, :402): the activation between a CIN layer's product and its
  * split.  With a non-identity activation run the layer with n_hidden = L (raw curr[B,L,D] into a

@@ -101,6 +101,7 @@ SIGNATURES = {
     "xdfm_embed_plan_workspace_bytes": [_I64, _I64, _PSZ],
     "xdfm_embed_plan": [_P, _I64, _I64, _P, _P, _P, _SZ, _P],
     "xdfm_embed_plan_static": [_P, _I64, _I64, _P, _P, _P],
+    "xdfm_embed_plan_gather": [_P, _P, _P, _I64, _P, _P, _P],
     "xdfm_embed_bwd": [_I32, _P, _P, _P, _P, _P, _P, _I64, _I64, _P, _P, _I64, _I32, _I32, _I64, _P, _P, _P,
                        _P, _I64, _P, _P, _P, _I32, ctypes.POINTER(OptArgs), _P, _P, _I64, _P],
     "xdfm_embed_catchup": [_P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _I32, _P, _I64, _I32,
@@ -119,7 +120,7 @@ SIGNATURES = {
     "xdfm_cin_pack": [_P, _I32, _I64, _I32, _P],
     "xdfm_cin_fwd_packed": [_P, _P, _P, _I64, _I32, _I32, _I32, _I32, _I32, _I32, _P, _P, _I32, _I32, _P],
     "xdfm_cin_bwd_packed": [_P, _P, _P, _I64, _I32, _I32, _I32, _I32, _I32, _I32, _P, _P, _I32, _I32, _P,
-                            _P, _P, _P, _I32, _P],
+                            _P, _P, _P, _I32, _P, _P, _P],
     "xdfm_bn_fwd": [_P, _I64, _I32, _I32, _P, _P, _P, _P, ctypes.c_float, ctypes.c_float, _I32, _I32, _P, _P, _P],
     "xdfm_softmax_fwd": [_P, _I64, _I32, _I32, _P, _P],
     "xdfm_softmax_bwd": [_P, _P, _I64, _I32, _I32, _P, _P],

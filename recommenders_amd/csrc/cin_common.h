@@ -22,7 +22,7 @@ int fwd_mfma(const CinDims& c, const float* x0, const float* xk, const float* w,
 size_t bwd_mfma_workspace_floats(int64_t B, int F, int H, int D, int L, int masked);
 int bwd_mfma(const CinDims& c, const float* x0, const float* xk, const float* w, const float* packed_dx,
              const float* d_xnext, const float* d_pooled, int pool_stride, int pool_off, float* d_xk,
-             float* d_x0, float* d_w, float* ws, int phases, hipStream_t st);
+             float* d_x0, float* d_w, float* ws, int phases, hipStream_t st, const float* add0, const float* add1);
 
 // filter images packed ahead of the layer calls (xdfm_cin_pack*)
 void pack_floats(int64_t B, int F, int H, int D, int L, int masked, size_t* fwd_floats, size_t* bwd_floats);

@@ -411,7 +411,7 @@ extern "C" int xdfm_cin_bwd(const float* x0, const float* xk, const float* w, in
   }
   if (xdfm_cin::mfma_supported(B, F, H, D, L))
     return xdfm_cin::bwd_mfma(c, x0, xk, w, nullptr, d_xnext, d_pooled, pool_stride, pool_off, d_xk, d_x0, d_w,
-                              dw_part, 3, st);
+                              dw_part, 3, st, d_x0, nullptr);
   float* dc_mn = dw_part;
   float* part = dw_part + (size_t)B * D * L;
   {
@@ -497,7 +497,7 @@ extern "C" int xdfm_cin_bwd_packed(const float* x0, const float* xk, const float
                                    int32_t H, int32_t D, int32_t L, int32_t n_hidden, int32_t masked,
                                    const float* d_xnext, const float* d_pooled, int32_t pool_stride,
                                    int32_t pool_off, float* d_xk, float* d_x0, float* d_w, float* dw_part,
-                                   int32_t phases, void* stream) {
+                                   int32_t phases, const float* d_x0_in, const float* d_x0_in2, void* stream) {
   int rc = check_dims("xdfm_cin_bwd_packed", B, F, H, D, L, n_hidden, masked);
   if (rc) return rc;
   XDFM_REQUIRE(phases >= 1 && phases <= 15, "xdfm_cin_bwd_packed: phases is a mask of XDFM_CIN_BWD_*");
@@ -515,7 +515,7 @@ extern "C" int xdfm_cin_bwd_packed(const float* x0, const float* xk, const float
   }
   CinDims c{B, F, H, D, L, n_hidden, masked};
   return xdfm_cin::bwd_mfma(c, x0, xk, nullptr, bwd_image, d_xnext, d_pooled, pool_stride, pool_off, d_xk, d_x0,
-                            d_w, dw_part, phases, st);
+                            d_w, dw_part, phases, st, d_x0_in, d_x0_in2);
 }
 
 // ------------------------------------------------------------------ cross_activation

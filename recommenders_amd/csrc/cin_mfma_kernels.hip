@@ -572,6 +572,11 @@ struct Dx2Args {
   float* d_xk;
   float* d_x0;
   int SPB, ntiles;
+  // d_x0 = this layer's contribution + add0 + add1 (either may be null; add0 == d_x0 is the plain
+  // "accumulate into").  The first layer to run writes, the last one can fold another producer's
+  // gradient (the DNN tower's) in, so the table gradient reads ONE array per token.
+  const float* add0;
+  const float* add1;
 };
 struct BwdIn {  // what both backward kernels read
   CinDims c;
@@ -715,8 +720,9 @@ __device__ __forceinline__ void dx2_body(const BwdIn& in, const Dx2Args& ax, int
   const float scale = c.masked ? 2.f : 1.f;
   // results go out along d: [sample][feature][d] <- LDS [feature][row]; 16 bytes per lane when
   // 4 | D (the index arithmetic uses fdiv: this loop is a fifth of the kernel's VALU work otherwise)
-  auto flush = [&](float* dst, const float* img, int R, bool accumulate) {
-    if ((c.D & 3) == 0 && (reinterpret_cast<uintptr_t>(dst) & 15) == 0) {
+  auto flush = [&](float* dst, const float* img, int R, const float* add0, const float* add1) {
+    if ((c.D & 3) == 0 && ((reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(add0) |
+                            reinterpret_cast<uintptr_t>(add1)) & 15) == 0) {
       const int D4 = c.D >> 2, RD4 = R * D4;
       const float invRD4 = 1.0f / (float)RD4, invD4 = 1.0f / (float)D4;
       f32x4* base4 = reinterpret_cast<f32x4*>(dst + b0 * R * c.D);
@@ -725,8 +731,10 @@ __device__ __forceinline__ void dx2_body(const BwdIn& in, const Dx2Args& ax, int
         const int rem = idx - bl * RD4;
         const int f = fdiv(rem, invD4);
         const int d4 = rem - f * D4;
-        const f32x4 v = *reinterpret_cast<const f32x4*>(img + f * Tp + bl * c.D + 4 * d4) * scale;
-        base4[idx] = accumulate ? base4[idx] + v : v;
+        f32x4 v = *reinterpret_cast<const f32x4*>(img + f * Tp + bl * c.D + 4 * d4) * scale;
+        if (add0) v = reinterpret_cast<const f32x4*>(add0 + b0 * R * c.D)[idx] + v;
+        if (add1) v = v + reinterpret_cast<const f32x4*>(add1 + b0 * R * c.D)[idx];
+        base4[idx] = v;
       }
     } else {
       const int RD = R * c.D;
@@ -737,13 +745,15 @@ __device__ __forceinline__ void dx2_body(const BwdIn& in, const Dx2Args& ax, int
         const int rem = idx - bl * RD;
         const int f = fdiv(rem, invD);
         const int d = rem - f * c.D;
-        const float v = img[f * Tp + bl * c.D + d] * scale;
-        base[idx] = accumulate ? base[idx] + v : v;
+        float v = img[f * Tp + bl * c.D + d] * scale;
+        if (add0) v = add0[b0 * R * c.D + idx] + v;
+        if (add1) v = v + add1[b0 * R * c.D + idx];
+        base[idx] = v;
       }
     }
   };
-  flush(d_x0, as, c.F, true);
-  if (!shared_x) flush(d_xk, xs, c.H, false);
+  flush(d_x0, as, c.F, ax.add0, ax.add1);
+  if (!shared_x) flush(d_xk, xs, c.H, nullptr, nullptr);
 }
 
 // ----------------------------------------------------------------- filter gradient
@@ -1165,7 +1175,7 @@ static bool dx2_applies(int F, int H, int L, bool shared_x) {
 // w == nullptr: `packed_dx` holds the input-gradient image (xdfm_cin_pack)
 int bwd_mfma(const CinDims& c, const float* x0, const float* xk, const float* w, const float* packed_dx,
              const float* d_xnext, const float* d_pooled, int pool_stride, int pool_off, float* d_xk,
-             float* d_x0, float* d_w, float* ws, int phases, hipStream_t st) {
+             float* d_x0, float* d_w, float* ws, int phases, hipStream_t st, const float* add0, const float* add1) {
   float* dc_mn = ws;
   float* wpk = ws + (((size_t)c.B * c.D * c.L + 3) & ~(size_t)3);  // 16-byte aligned: staged as float4
   const size_t wpk_floats = (size_t)((c.F + 3) / 4) * 4 * ((c.H + 3) & ~3) * (4 * smax_for((c.L + 3) / 4) + 1);
@@ -1205,7 +1215,7 @@ int bwd_mfma(const CinDims& c, const float* x0, const float* xk, const float* w,
     const int SPB = 256 / c.D;
     const int ntiles = n_tiles(nft, nht, c.masked);
     const int n_dx = (int)((c.B + SPB - 1) / SPB);
-    const Dx2Args ax{w ? wpk : packed_dx, d_xk, d_x0, SPB, ntiles};
+    const Dx2Args ax{w ? wpk : packed_dx, d_xk, d_x0, SPB, ntiles, add0, add1};
     const int SS = S <= 3 ? 3 : 5;
     if (w) {
       const int64_t total = (int64_t)ntiles * 64 * ((SS + 3) & ~3);
@@ -1238,6 +1248,7 @@ int bwd_mfma(const CinDims& c, const float* x0, const float* xk, const float* w,
 #undef CALL2
     }
   } else {
+    XDFM_REQUIRE(add0 == d_x0 && !add1, "xdfm_cin_bwd: this shape only accumulates into d_x0");
     {
       const int64_t total = c.B * c.D * c.L;
       XDFM_LAUNCH("cin_dcurr_kernel", st, cin_dcurr_kernel, dim3((unsigned)((total + 255) / 256)),

@@ -392,7 +392,7 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(BwdArgs a) {
   const bool pv = lane < nvalid;
   const int64_t p = p0 + (pv ? lane : 0);
   const int key = pv ? a.sorted_ids[p] : -1;
-  const int tok = a.sorted_tok[p];
+  const int tok = a.sorted_tok ? a.sorted_tok[p] : (int)p;  // null: tok_row / weights come sorted
   const int row = a.tok_row[tok];
   const float w = pv ? a.weights[tok] : 0.f;
   float gw = 0.f;
@@ -586,6 +586,16 @@ __global__ __launch_bounds__(256) void embed_bwd_long_kernel(BwdArgs a) {
   if (g == 0) finish_row<VEC, MODE>(a, key, c, v, lsum);
 }
 
+__global__ void plan_gather_kernel(const int32_t* __restrict__ sorted_tok, const int32_t* __restrict__ tok_row,
+                                   const float* __restrict__ weights, int64_t nnz,
+                                   int32_t* __restrict__ row_sorted, float* __restrict__ w_sorted) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= nnz) return;
+  const int tok = sorted_tok[p];
+  row_sorted[p] = tok_row[tok];
+  w_sorted[p] = weights[tok];
+}
+
 __global__ void clear_rows_kernel(float* __restrict__ grad_table, float* __restrict__ grad_lin,
                                   int D, const int32_t* __restrict__ sorted_ids, int64_t nnz) {
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -739,7 +749,7 @@ extern "C" int xdfm_embed_bwd(int32_t mode, float* table, float* slot_m, float* 
   XDFM_REQUIRE(mode == 0 || mode == 1, "xdfm_embed_bwd: mode must be 0 or 1");
   XDFM_REQUIRE(N > 0 && D > 0 && F > 0 && B >= 0 && nnz >= 0, "xdfm_embed_bwd: bad sizes");
   if (nnz == 0) return XDFM_OK;
-  XDFM_REQUIRE(sorted_ids && sorted_tok && tok_row && weights && d_emb && pieces,
+  XDFM_REQUIRE(sorted_ids && tok_row && weights && d_emb && pieces,
                "xdfm_embed_bwd: null argument");
   XDFM_REQUIRE(!use_fm || (g_logit && fm_sum && table), "xdfm_embed_bwd: FM needs g_logit, fm_sum, table");
   BwdArgs a;
@@ -919,6 +929,12 @@ __global__ __launch_bounds__(256) void embed_catchup_kernel(CatchArgs a) {
   }
   const int done = (int)a.opt.state[3];  // optimizer steps applied so far
   const int last = a.row_step[id * a.SS];
+  if (a.advance < 0) {
+    // un-mark: rows that were prepared for a step that did not come (a batch announced as the next
+    // one and then not trained) are current for the steps applied so far, nothing more
+    if (c == 0 && last > done) a.row_step[id * a.SS] = done;
+    return;
+  }
   const int G = done - last;
   // last == 0: never updated; Adam's / Adadelta's slots are still zero: no drift (RMSProp's rms starts
   // at 1 and decays from the first step on)
@@ -956,7 +972,7 @@ extern "C" int xdfm_embed_catchup(float* table, float* slot_m, float* slot_v, fl
                                   int64_t step_stride, int64_t N, int32_t D, const int32_t* sorted_ids,
                                   int64_t n, int32_t advance, const xdfm_opt_args* opt, void* stream) {
   XDFM_REQUIRE(table && row_step && opt, "xdfm_embed_catchup: null argument");
-  XDFM_REQUIRE(N > 0 && D > 0 && n >= 0 && (advance == 0 || advance == 1), "xdfm_embed_catchup: bad sizes");
+  XDFM_REQUIRE(N > 0 && D > 0 && n >= 0 && advance >= -1 && advance <= 1, "xdfm_embed_catchup: bad sizes");
   XDFM_REQUIRE(opt->opt_state, "xdfm_embed_catchup: needs the device step count (opt_state)");
   CatchArgs a;
   memset(&a, 0, sizeof(a));
@@ -999,6 +1015,17 @@ extern "C" int xdfm_embed_catchup(float* table, float* slot_m, float* slot_v, fl
   else
     LAUNCH(1);
 #undef LAUNCH
+  XDFM_LAUNCH_CHECK();
+  return XDFM_OK;
+}
+
+extern "C" int xdfm_embed_plan_gather(const int32_t* sorted_tok, const int32_t* tok_row, const float* weights,
+                                      int64_t nnz, int32_t* row_sorted, float* w_sorted, void* stream) {
+  XDFM_REQUIRE(nnz >= 0, "xdfm_embed_plan_gather: bad size");
+  if (nnz == 0) return XDFM_OK;
+  XDFM_REQUIRE(sorted_tok && tok_row && weights && row_sorted && w_sorted, "xdfm_embed_plan_gather: null argument");
+  XDFM_LAUNCH("plan_gather_kernel", stream, plan_gather_kernel, dim3((unsigned)((nnz + 255) / 256)), dim3(256), 0,
+              sorted_tok, tok_row, weights, nnz, row_sorted, w_sorted);
   XDFM_LAUNCH_CHECK();
   return XDFM_OK;
 }

@@ -106,7 +106,7 @@ class DeviceBatch(object):
     """One mini-batch resident in HBM (the dnn view of the iterator as CSR)."""
 
     __slots__ = ("B", "nnz", "labels", "ids", "weights", "row_ptr", "tok_row", "sorted_ids",
-                 "sorted_tok", "planned", "plan_event", "ready_event", "src_table", "src_lin", "src_ids", "src_N", "route")
+                 "sorted_tok", "sorted_row", "sorted_w", "planned", "planned_gather", "plan_event", "ready_event", "src_table", "src_lin", "src_ids", "src_N", "route")
 
 
 class XDeepFMEngine(object):
@@ -277,6 +277,7 @@ class XDeepFMEngine(object):
         self.prepack = os.environ.get("XDFM_CIN_PREPACK", "1") != "0"
         self.split_dw = os.environ.get("XDFM_SPLIT_DW", "1") != "0"
         self._late_event = None
+        self._fold_dx = False
         self.overlap_dnn = self.overlap_dnn_wanted(hp)
         self.mean_count = 0  # set by the sharded engine: global batch size of the step
         self.init_parameters(seed)
@@ -564,8 +565,8 @@ class XDeepFMEngine(object):
             self.lib.xdfm_build_row_ptr(_ptr(dnn_idx), b.nnz, b.B * self.F, _ptr(b.row_ptr),
                                         _ptr(b.tok_row), _ptr(self.err_flag), self._stream())
         )
-        b.sorted_ids = b.sorted_tok = None
-        b.planned = False
+        b.sorted_ids = b.sorted_tok = b.sorted_row = b.sorted_w = None
+        b.planned = b.planned_gather = False
         b.plan_event = None
         # what another stream waits for before it reads the batch's arrays (routing one step ahead)
         b.ready_event = torch.cuda.Event()
@@ -576,19 +577,25 @@ class XDeepFMEngine(object):
         b.src_N = 0
         return b
 
+    def _plan_complete(self, batch):
+        if not batch.planned:
+            return False
+        if batch.tok_row is None or batch.nnz == 0:
+            return True  # nothing to bring into sorted order (a batch known by its ids only)
+        return batch.sorted_row is not None and batch.planned_gather
+
     def plan_async(self, batch):
-        """Start the id sort of `batch` on a side stream so that it runs beside the forward
-        pass (it depends on the ids only); update() waits for it."""
-        if batch.planned:
+        """Start the id sort of `batch` (and the gather of its rows / weights into sorted order) on a
+        side stream so that it runs beside the forward pass (it depends on the batch only);
+        update() waits for it."""
+        if self._plan_complete(batch):
             return
         self._ensure_ws(batch.B, batch.nnz)
         main = torch.cuda.current_stream(self.device)
         if self._side_stream is None:
             self._side_stream = torch.cuda.Stream(device=self.device)
         # allocated under the main stream, which is also where they are consumed and freed
-        if batch.sorted_ids is None:
-            batch.sorted_ids = torch.empty((max(batch.nnz, 1),), dtype=torch.int32, device=self.device)
-            batch.sorted_tok = torch.empty((max(batch.nnz, 1),), dtype=torch.int32, device=self.device)
+        self._plan_buffers(batch)
         ready = torch.cuda.Event()
         ready.record(main)
         self._side_stream.wait_event(ready)
@@ -597,22 +604,39 @@ class XDeepFMEngine(object):
             batch.plan_event = torch.cuda.Event()
             batch.plan_event.record(self._side_stream)
 
-    def plan(self, batch):
-        """Sort the batch's tokens by feature id (needed by the backward only)."""
-        if batch.planned:
+    def _plan_buffers(self, batch):
+        n = max(batch.nnz, 1)
+        if batch.sorted_ids is None:
+            batch.sorted_ids = torch.empty((n,), dtype=torch.int32, device=self.device)
+            batch.sorted_tok = torch.empty((n,), dtype=torch.int32, device=self.device)
+        if batch.sorted_row is None and batch.tok_row is not None and batch.nnz:
+            batch.sorted_row = torch.empty((n,), dtype=torch.int32, device=self.device)
+            batch.sorted_w = torch.empty((n,), dtype=torch.float32, device=self.device)
+            batch.planned_gather = False
+
+    def plan(self, batch, sort_only=False):
+        """Sort the batch's tokens by feature id, then bring tok_row / weights into that order (what
+        the table gradient reads per token); both on the current stream."""
+        if self._plan_complete(batch):
             return
         self._ensure_ws(batch.B, batch.nnz)
-        if batch.sorted_ids is None:
-            batch.sorted_ids = torch.empty((max(batch.nnz, 1),), dtype=torch.int32, device=self.device)
-            batch.sorted_tok = torch.empty((max(batch.nnz, 1),), dtype=torch.int32, device=self.device)
-        ws = self.ws["plan_ws"]
-        ev = self._mark("embed_plan")
-        _lib.check(
-            self.lib.xdfm_embed_plan(_ptr(batch.ids), batch.nnz, self.N, _ptr(batch.sorted_ids),
-                                     _ptr(batch.sorted_tok), _ptr(ws), ws.numel(), self._stream())
-        )
-        self._done(ev)
-        batch.planned = True
+        self._plan_buffers(batch)
+        if not batch.planned:
+            ws = self.ws["plan_ws"]
+            ev = self._mark("embed_plan")
+            _lib.check(
+                self.lib.xdfm_embed_plan(_ptr(batch.ids), batch.nnz, self.N, _ptr(batch.sorted_ids),
+                                         _ptr(batch.sorted_tok), _ptr(ws), ws.numel(), self._stream())
+            )
+            self._done(ev)
+            batch.planned = True
+        if not sort_only and batch.sorted_row is not None and not batch.planned_gather:
+            _lib.check(
+                self.lib.xdfm_embed_plan_gather(_ptr(batch.sorted_tok), _ptr(batch.tok_row), _ptr(batch.weights),
+                                                batch.nnz, _ptr(batch.sorted_row), _ptr(batch.sorted_w),
+                                                self._stream())
+            )
+            batch.planned_gather = True
 
     def check_errors(self):
         """Read the device error flag (synchronises) and raise like the reference's
@@ -657,10 +681,16 @@ class XDeepFMEngine(object):
         if self.overlap_dnn:
             # fork: the DNN tower starts on its stream as soon as emb_out is there
             side = self._branch_stream()
+            # d_emb without a clear and without a second array: the CIN layer whose backward runs
+            # first writes it, the one that runs last folds the DNN tower's gradient in
+            self._fold_dx = bool(with_grad and hp.use_CIN_part and not self.fast_d and not self.cross_path
+                                 and all(("img_b_%d" % k) in ws for k in range(len(hp.cross_layer_sizes)))
+                                 and self._dnn_plain() and os.environ.get("XDFM_FOLD_DX", "1") != "0")
             with torch.cuda.stream(side):
                 self._dnn_forward(B)
                 if with_grad:
-                    ws["d_emb"][:B].zero_()  # the CIN backward accumulates into it
+                    if not self._fold_dx:
+                        ws["d_emb"][:B].zero_()  # the CIN backward accumulates into it
                     if self.early_reg:
                         self._reg_loss_early()
                 dnn_done = torch.cuda.Event()
@@ -840,9 +870,18 @@ class XDeepFMEngine(object):
         )
         self._done(ev)
 
-    def _dnn_backward(self, B, first_layer_dx):
+    def _dnn_plain(self):
+        """No dropout, batch norm or softmax in the tower: its backward splits into an input-gradient
+        chain and the weight gradients."""
+        hp = self.hp
+        return not (self._dropout_live or self.use_bn or any(_ACT[hp.activation[k]] == _SOFTMAX
+                                                              for k in range(len(hp.layer_sizes))))
+
+    def _dnn_backward(self, B, first_layer_dx, phase="all"):
         """Backward of the DNN tower on the current stream.  first_layer_dx: (buffer, accumulate)
-        for the gradient w.r.t. emb_out, None to skip it."""
+        for the gradient w.r.t. emb_out, None to skip it.  phase (plain towers only): "dx" = the
+        chain of input gradients down to emb_out alone, "dw" = the weight / bias gradients alone
+        (after "dx": they read the d_h the chain left)."""
         hp, lib, ws, st = self.hp, self.lib, self.ws, self._stream()
         g, gv = ws["g_logit"], self.grad_views
         ev = self._mark("dnn_bwd")
@@ -850,6 +889,25 @@ class XDeepFMEngine(object):
         sizes = [self.F * self.D] + [int(s) for s in hp.layer_sizes]
         acts = [ws["emb_out"]] + [ws["h_%d" % k] for k in range(n_layers)]
         d_acts = [None] + [ws["d_h_%d" % k] for k in range(n_layers)]
+        want_dx, want_dw = phase != "dw", phase != "dx"
+        if phase != "all":
+            x_in, K_in = acts[-1], sizes[-1]
+            layers = [(x_in, self.views["dnn_w_out"], ws["dnn_out"], g, K_in, 1, 0, d_acts[-1], 0,
+                       gv["dnn_w_out"], gv["dnn_b_out"])]
+            for k in range(n_layers - 1, -1, -1):
+                dx, acc = (first_layer_dx if first_layer_dx is not None else (None, 0)) if k == 0 else (d_acts[k], 0)
+                layers.append((acts[k], self.views["dnn_w_%d" % k], acts[k + 1], d_acts[k + 1], sizes[k], sizes[k + 1],
+                               _ACT[hp.activation[k]], dx, acc, gv["dnn_w_%d" % k], gv["dnn_b_%d" % k]))
+            for (x, w, y, dy, K, Nout, act, dx, acc, dw, db) in layers:
+                if want_dx and dx is None:
+                    continue
+                _lib.check(
+                    lib.xdfm_dense_bwd(_ptr(x), _ptr(w), _ptr(y), _ptr(dy), B, K, Nout, act,
+                                       _ptr(dx) if want_dx else None, acc, _ptr(dw) if want_dw else None,
+                                       _ptr(db) if want_dw else None, _ptr(ws["part_dnn"]) if want_dw else None, st)
+                )
+            self._done(ev)
+            return
         _lib.check(
             lib.xdfm_dense_bwd(_ptr(acts[-1]), _ptr(self.views["dnn_w_out"]), _ptr(ws["dnn_out"]),
                                _ptr(g), B, sizes[-1], 1, 0, _ptr(d_acts[-1]), 0, _ptr(gv["dnn_w_out"]),
@@ -925,7 +983,14 @@ class XDeepFMEngine(object):
                     self._loss_deferred = False
                 if fused_head:
                     small_grads(ws["part_dnn"])
-                self._dnn_backward(B, (ws["d_emb_dnn"], 0))
+                dnn_dx_done = None
+                if self._fold_dx:
+                    self._dnn_backward(B, (ws["d_emb_dnn"], 0), phase="dx")
+                    dnn_dx_done = torch.cuda.Event()
+                    dnn_dx_done.record(side)
+                    self._dnn_backward(B, None, phase="dw")
+                else:
+                    self._dnn_backward(B, (ws["d_emb_dnn"], 0))
                 if advance:
                     self._advance_step()  # nothing reads the scalars before the join
                 dnn_done = torch.cuda.Event()
@@ -933,8 +998,9 @@ class XDeepFMEngine(object):
             st = self._stream()
             if not fused_head:
                 small_grads(ws["part"])
-                d_emb[:B].zero_()
-            wrote_d_emb = True  # zeroed beside the forward pass (or just above)
+                if not self._fold_dx:
+                    d_emb[:B].zero_()
+            wrote_d_emb = True  # zeroed beside the forward pass (or just above), or written by the CIN
         else:
             small_grads(ws["part"])
             if hp.use_DNN_part:
@@ -984,12 +1050,19 @@ class XDeepFMEngine(object):
                     )
                     continue
                 if ("img_b_%d" % k) in ws:
+                    fold = self.overlap_dnn and self._fold_dx
+                    add0 = None if (fold and k == len(shapes) - 1) else d_emb
+                    add1 = ws["d_emb_dnn"] if (fold and k == 0) else None
+                    if add1 is not None:
+                        torch.cuda.current_stream(self.device).wait_event(dnn_dx_done)
+
                     def layer_bwd(phases, stream):
                         _lib.check(
                             lib.xdfm_cin_bwd_packed(_ptr(x0), _ptr(xk), _ptr(ws["img_b_%d" % k]), B, F, H, D, L,
                                                     up_nh, 1 if k == 0 else 0, _ptr(d_xnext), _ptr(d_pool),
                                                     final_len, offs[k], _ptr(d_xk), _ptr(d_emb),
-                                                    _ptr(gv["cin_f_%d" % k]), _ptr(ws["part"]), phases, stream)
+                                                    _ptr(gv["cin_f_%d" % k]), _ptr(ws["part"]), phases,
+                                                    _ptr(add0), _ptr(add1), stream)
                         )
 
                     side_dw = dnn_done is not None and self.split_dw
@@ -1039,7 +1112,7 @@ class XDeepFMEngine(object):
 
     def d_emb2(self):
         """Second summand of the gradient w.r.t. emb_out (None when d_emb holds all of it)."""
-        return self.ws["d_emb_dnn"] if self.overlap_dnn else None
+        return self.ws["d_emb_dnn"] if (self.overlap_dnn and not self._fold_dx) else None
 
     def _opt_args(self, l2=0.0, l1=0.0, clip=0.0):
         hp = self.hp
@@ -1078,6 +1151,7 @@ class XDeepFMEngine(object):
             batch.plan_event = None
         sparse = self.sparse
         opt_sparse = self._opt_args()
+        pre = batch.sorted_row is not None and batch.planned_gather  # tok_row / weights in sorted order
         ev = self._mark("embed_bwd")
         _lib.check(
             lib.xdfm_embed_bwd(
@@ -1086,8 +1160,9 @@ class XDeepFMEngine(object):
                 _ptr(self.lin_v) if use_lin else None, self.table_stride, self.lin_stride,
                 _ptr(self.grad_table),
                 _ptr(self.grad_lin) if use_lin else None, self.N, self.D, self.F, batch.B,
-                _ptr(batch.sorted_ids), _ptr(batch.sorted_tok), _ptr(batch.tok_row),
-                _ptr(batch.weights), batch.nnz, _ptr(ws["d_emb"]),
+                _ptr(batch.sorted_ids), None if pre else _ptr(batch.sorted_tok),
+                _ptr(batch.sorted_row if pre else batch.tok_row),
+                _ptr(batch.sorted_w if pre else batch.weights), batch.nnz, _ptr(ws["d_emb"]),
                 _ptr(ws["g_logit"]) if (use_lin or use_fm) else None,
                 _ptr(ws["fm_sum"]) if use_fm else None, 1 if use_fm else 0,
                 ctypes.byref(opt_sparse), _ptr(ws["pieces"]), _ptr(self.d_emb2()), 0, st,
@@ -1183,7 +1258,7 @@ class XDeepFMEngine(object):
         step's compute (with the catch-up of sparse_rows the sort is needed BEFORE the forward pass,
         so a step whose batch was not planned ahead sorts first)."""
         if self.catchup_on:
-            self.plan(batch)
+            self.plan(batch, sort_only=True)  # a batch that was not announced sorts here
             if batch.plan_event is not None:
                 torch.cuda.current_stream(self.device).wait_event(batch.plan_event)
                 batch.plan_event = None
@@ -1191,8 +1266,7 @@ class XDeepFMEngine(object):
             self.catchup(batch.sorted_ids, batch.nnz, 1)
             self._done(ev)
             self._rows_stale = True
-        else:
-            self.plan_async(batch)
+        self.plan_async(batch)  # whatever of the plan is still missing runs beside the forward pass
         if next_batch is not None and next_batch is not batch:
             self.plan_async(next_batch)
         self.forward(batch, with_loss=True, with_grad=True)
@@ -1284,7 +1358,8 @@ class GraphedStep(object):
                 nb = DeviceBatch()
                 nb.B, nb.nnz, nb.ids = self.batch.B, self.batch.nnz, self.next_ids
                 nb.sorted_ids, nb.sorted_tok = self.plan_next
-                nb.planned, nb.plan_event = False, None
+                nb.sorted_row = nb.sorted_w = nb.tok_row = nb.weights = None  # known by its ids only
+                nb.planned, nb.planned_gather, nb.plan_event = False, False, None
                 self.loss, self.data_loss = engine.train_step(self.batch, next_batch=nb)
             else:
                 self.loss, self.data_loss = engine.train_step(self.batch)
