@@ -170,6 +170,8 @@ class XDeepFMEngine(object):
         # scoring / checkpoints.  sparse_lazy skips them (a different algorithm for absent rows).
         self.catchup_on = embedding_update == "sparse_rows" and self.opt_kind in (1, 3, 4, 5)
         self._rows_stale = False
+        self._announced = None  # the batch whose rows have been caught up for the step to come
+        self._adv_event = None
         if self.sparse:
             if hp.embed_l1 != 0.0 or hp.embed_l2 != 0.0:
                 raise ValueError("sparse_rows needs embed_l1 = embed_l2 = 0 (their gradient is dense)")
@@ -1254,31 +1256,70 @@ class XDeepFMEngine(object):
 
     def train_step(self, batch, next_batch=None):
         """One optimisation step; returns (total_loss, data_loss) as 0-dim device tensors.
-        next_batch (optional): the batch of the following step; its id sort then runs beside this
-        step's compute (with the catch-up of sparse_rows the sort is needed BEFORE the forward pass,
-        so a step whose batch was not planned ahead sorts first)."""
+        next_batch (optional): the batch of the following step.  Its id sort runs beside this step's
+        compute, and with embedding_update="sparse_rows" so does the catch-up of its rows (they are
+        rows this step does not update, or rows it marks as current): the following step then starts
+        with its forward pass.  A step whose batch was not announced sorts and catches up first."""
         if self.catchup_on:
-            self.plan(batch, sort_only=True)  # a batch that was not announced sorts here
-            if batch.plan_event is not None:
+            if self._announced is not batch:
+                if self._announced is not None:
+                    # rows dated for a step that went to another batch: take the mark back
+                    self.catchup(self._announced.sorted_ids, self._announced.nnz, -1)
+                self.plan(batch, sort_only=True)
+                if batch.plan_event is not None:
+                    torch.cuda.current_stream(self.device).wait_event(batch.plan_event)
+                    batch.plan_event = None
+                ev = self._mark("embed_catchup")
+                self.catchup(batch.sorted_ids, batch.nnz, 1)
+                self._done(ev)
+            elif batch.plan_event is not None:
                 torch.cuda.current_stream(self.device).wait_event(batch.plan_event)
                 batch.plan_event = None
-            ev = self._mark("embed_catchup")
-            self.catchup(batch.sorted_ids, batch.nnz, 1)
-            self._done(ev)
+            self._announced = None
             self._rows_stale = True
         self.plan_async(batch)  # whatever of the plan is still missing runs beside the forward pass
-        if next_batch is not None and next_batch is not batch:
+        if next_batch is batch:
+            next_batch = None
+        if next_batch is not None:
             self.plan_async(next_batch)
         self.forward(batch, with_loss=True, with_grad=True)
         advanced = self.backward(batch, advance=True)
-        self.update(batch, advanced)
+        if not advanced:
+            self._advance_step()
+        ahead = None
+        if next_batch is not None and self.catchup_on:
+            ahead = self._catchup_ahead(next_batch)
+        self.update(batch, True)
         tot = torch.cumsum(self._loss2, 0)  # one launch: [data, data + reg]
-        if next_batch is not None and next_batch.plan_event is not None:
+        if ahead is not None:
+            # joined at the end of the step: the next step's forward pass reads caught-up rows
+            torch.cuda.current_stream(self.device).wait_event(ahead)
+        if next_batch is not None and next_batch.plan_event is not None and not self.catchup_on:
             # join (the sort finished long ago): the sort workspace is free again, and a capture ends
             # with every forked stream joined
             torch.cuda.current_stream(self.device).wait_event(next_batch.plan_event)
             next_batch.plan_event = None
         return tot[1], tot[0]
+
+    def _catchup_ahead(self, nxt):
+        """The catch-up of the announced batch's rows on the sort stream, behind its sort and behind
+        this step's opt_advance: rows this step updates are already dated for it (untouched here, only
+        re-dated), every other row takes its missed steps INCLUDING this one -- which this step's
+        row update does not touch.  The table gradient of this step may run at the same time: the
+        two write disjoint rows."""
+        side = self._side_stream
+        # behind everything this step has enqueued so far (its opt_advance included: backward() has
+        # joined the stream that ran it)
+        ready = torch.cuda.Event()
+        ready.record(torch.cuda.current_stream(self.device))
+        side.wait_event(ready)
+        with torch.cuda.stream(side):
+            self.catchup(nxt.sorted_ids, nxt.nnz, 1)
+            done = torch.cuda.Event()
+            done.record(side)
+        nxt.plan_event = None
+        self._announced = nxt
+        return done
 
     def capture_step(self, labels, dnn_idx, ids, weights):
         """Capture CSR build + train_step for batches of exactly this shape into a HIP graph
@@ -1355,7 +1396,8 @@ class GraphedStep(object):
                     dst.copy_(src)
                 self.batch.sorted_ids, self.batch.sorted_tok = self.plan_cur
                 self.batch.planned = True
-                nb = DeviceBatch()
+                engine._announced = self.batch  # its rows were caught up by the replay before (or eagerly)
+                nb = self._nb = DeviceBatch()
                 nb.B, nb.nnz, nb.ids = self.batch.B, self.batch.nnz, self.next_ids
                 nb.sorted_ids, nb.sorted_tok = self.plan_next
                 nb.sorted_row = nb.sorted_w = nb.tok_row = nb.weights = None  # known by its ids only
@@ -1365,6 +1407,7 @@ class GraphedStep(object):
                 self.loss, self.data_loss = engine.train_step(self.batch)
         # the capture pass ran the host bookkeeping of a step without device work
         engine.step, engine.b1p, engine.b2p = mirrors
+        engine._announced = None
 
     def pack(self, labels, dnn_idx, ids, weights):
         """The four arrays of a batch in the graph's input layout (a new device buffer)."""
@@ -1386,17 +1429,22 @@ class GraphedStep(object):
             raise RuntimeError("the engine's workspace was re-allocated after this step was captured "
                                "(a larger batch went through the engine): capture it again")
         if self.lookahead:
-            if self._planned_for != cur_ids.data_ptr():
-                # not announced by the previous replay: sort now, into the buffer the graph copies from
+            if eng._announced is not self._nb or self._planned_for != cur_ids.data_ptr():
+                # not announced by the replay before: take back whatever was, then sort and catch up now,
+                # into the buffer the graph copies from
+                if eng._announced is not None:
+                    eng.catchup(eng._announced.sorted_ids, eng._announced.nnz, -1)
                 ws = eng.ws["plan_ws"]
-                _lib.check(eng.lib.xdfm_embed_plan(_ptr(self.inputs[2]), int(self.inputs[2].numel()), eng.N,
-                                                   _ptr(self.plan_next[0]), _ptr(self.plan_next[1]), _ptr(ws),
-                                                   ws.numel(), eng._stream()))
+                n = int(self.inputs[2].numel())
+                _lib.check(eng.lib.xdfm_embed_plan(_ptr(self.inputs[2]), n, eng.N, _ptr(self.plan_next[0]),
+                                                   _ptr(self.plan_next[1]), _ptr(ws), ws.numel(), eng._stream()))
+                eng.catchup(self.plan_next[0], n, 1)
             if next_ids is not None:
                 self.next_ids.copy_(next_ids, non_blocking=True)
                 self._planned_for = next_ids.data_ptr()
             else:
-                self._planned_for = None  # the replay sorts whatever next_ids holds: never used
+                self._planned_for = None  # the replay prepares whatever next_ids holds: taken back later
+            eng._announced = self._nb
         self.graph.replay()
         eng.step += 1
         eng._rows_stale = eng.catchup_on

@@ -116,6 +116,10 @@ def test_full_size_step_is_deterministic_and_graph_equals_eager(setup):
     for eng in engines:
         eng.check_errors()
     assert losses[:2] == losses[2:] and l1 == losses[1]
-    assert torch.equal(a._records, b._records) and torch.equal(a._records, c._records)
+    # rows are compared as the reference's dense optimizer would have left them (state_dict flushes the
+    # steps rows still owe; the graph engine has caught some up ahead of time, row dates differ)
+    sa, sb, sc = a.state_dict(), b.state_dict(), c.state_dict()
+    for key in ("embedding", "lin_w", "slot/table_m", "slot/table_v", "slot/lin_m", "slot/lin_v"):
+        assert torch.equal(sa[key], sb[key]) and torch.equal(sa[key], sc[key]), key
     assert torch.equal(a.dense, b.dense) and torch.equal(a.dense, c.dense)
     assert np.isfinite(losses).all()
