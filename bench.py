@@ -37,17 +37,30 @@ from recommenders_amd import _lib  # noqa: E402
 from recommenders_amd.models.deeprec.deeprec_utils import prepare_hparams  # noqa: E402
 from recommenders_amd.synth import criteo_shape_ids  # noqa: E402
 
-# HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE doubled as MI355X_MICROARCH.md
-# prescribes for gfx950, + WRITE_SIZE), measured on this workload: profiles/r01_f_pmc_traffic.txt
-TRAFFIC = {
-    "cin_fwd2_mfma_kernel": 26.90e6,  # mean of the two layers' launches
-    "cin_bwd_dw_mfma_kernel<7, 2>": 44.66e6,
-    "cin_bwd_dw_mfma_kernel<8, 1>": 31.53e6,
-    "cin_bwd_dx2_mfma_kernel<10, 5>": 68.42e6,
-    "cin_bwd_dx2_mfma_kernel<10, 3>": 73.05e6,
-    "embed_fwd_kernel<4>": 44.76e6,
-    "embed_bwd_kernel<4, 0>": 144.26e6,  # two gradient sources (d_emb, d_emb2); rows as 2-line records
-}
+# HBM bytes per launch of each kernel from rocprofv3 PMC passes over this workload (FETCH_SIZE doubled
+# as MI355X_MICROARCH.md prescribes for gfx950, + WRITE_SIZE): written by
+# `tools/gpu_pmc.sh <tag>` + `tools/pmc_summary.py ... --json profiles/traffic.json`
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "traffic.json")
+
+
+def load_traffic():
+    try:
+        with open(TRAFFIC_FILE) as f:
+            return json.load(f).get("kernels", {})
+    except (OSError, ValueError):
+        return {}
+
+
+def traffic_of(name):
+    """HBM bytes per launch of a kernel, by the name the library gives it (rocprofv3 prints every
+    template argument, the library's label may leave trailing ones out)."""
+    table = load_traffic()
+    if name in table:
+        return table[name]
+    stem = name[:-1] if name.endswith(">") else name
+    hits = [v for k, v in table.items() if k.startswith(stem + ",") or k.startswith(stem + "<")]
+    return hits[0] if len(hits) == 1 else None
+
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 F32_MATRIX_PEAK_TFLOPS = 157.3  # same guide: fp32 MFMA / vector peak
@@ -122,8 +135,10 @@ def kernel_models(hp, nnz, uniq):
     return m
 
 
-def run_cpu_baseline(hp, batches, budget_s=15.0):
-    """The oracle's train_step (torch CPU fp32, sparse_rows) on the first batch(es)."""
+def run_cpu_baseline(hp, batches, budget_s=20.0):
+    """The oracle's train_step (torch CPU fp32) on the first batches, in the reference's semantics
+    (dense-exact Adam: every one of the 2^25 rows moves every step) and, for scale,
+    with lazy row updates (the cheapest thing a CPU could do)."""
     from oracle import xdeepfm_oracle as X
 
     cores = min(16, os.cpu_count() or 1)
@@ -139,17 +154,25 @@ def run_cpu_baseline(hp, batches, budget_s=15.0):
             t.uniform_(-0.1, 0.1, generator=gen)
         params[name] = t
     st = X.new_opt_state(params, hp)
-    X.train_step(params, st, batches[0], hp, mode="sparse_rows")  # warm-up (allocator, threads)
-    done, t0 = 0, time.perf_counter()
-    while True:
-        X.train_step(params, st, batches[(done + 1) % len(batches)], hp, mode="sparse_rows")
-        done += 1
-        el = time.perf_counter() - t0
-        if el > budget_s or done >= 32:
-            break
-    return {"value": done * hp.batch_size / el, "unit": "samples/s", "cores": cores, "kind": "port",
-            "sample": "%d training steps of the same batch-%d workload (oracle/xdeepfm_oracle.py, "
-                      "torch CPU fp32, sparse_rows) after 1 warm-up step" % (done, hp.batch_size)}
+
+    def timed(mode, budget, max_steps):
+        X.train_step(params, st, batches[0], hp, mode=mode)  # warm-up (allocator, threads)
+        done, t0 = 0, time.perf_counter()
+        while True:
+            X.train_step(params, st, batches[(done + 1) % len(batches)], hp, mode=mode)
+            done += 1
+            el = time.perf_counter() - t0
+            if el > budget or done >= max_steps:
+                return done, el
+
+    lazy_n, lazy_t = timed("sparse_lazy", 0.3 * budget_s, 16)
+    dense_n, dense_t = timed("dense_exact", 0.7 * budget_s, 8)
+    return {"value": dense_n * hp.batch_size / dense_t, "unit": "samples/s", "cores": cores, "kind": "port",
+            "sample": "%d training steps of the same batch-%d workload (oracle/xdeepfm_oracle.py, torch CPU fp32, "
+                      "dense-exact Adam = the reference's semantics) after 1 warm-up step" % (dense_n, hp.batch_size),
+            "lazy_rows_value": lazy_n * hp.batch_size / lazy_t,
+            "lazy_rows_sample": "%d steps with lazy row updates (a different algorithm for absent rows; the "
+                                "cheapest CPU form)" % lazy_n}
 
 
 def main():
@@ -163,6 +186,7 @@ def main():
     ap.add_argument("--workload", choices=["criteo", "wide"], default="criteo",
                     help="criteo = BASELINE configs[2] (the bench line); wide = configs[4]'s layer sizes "
                          "(dim 64, CIN [256,256,256], DNN [1024,512]) at --batch per GPU, a side measurement")
+    ap.add_argument("--batches", type=int, default=64, help="distinct synthetic batches cycled through")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly in the timed region")
     ap.add_argument("--sharded", action="store_true",
@@ -194,7 +218,9 @@ def main():
             dist.init_process_group(backend)
 
     hp = workload_hparams(args)
-    n_batches = 8
+    # distinct batches cycled: their touched rows (~98 k x 256 B each) must exceed the 256 MB Infinity
+    # Cache, or the "HBM" rates are last-level-cache rates
+    n_batches = args.batches
     host_batches = synth_batches(hp, n_batches, seed=1234 + rank)
 
     if world == 1 and not args.sharded:
@@ -315,7 +341,7 @@ def main():
                 continue
             bound, ach, peak, unit, avg_s = r
             roofline = {"kernel": name, "bound": bound, "achieved": round(ach, 3), "peak": peak, "unit": unit,
-                        "frac": round(ach / peak, 4), "traffic": TRAFFIC.get(name), "avg_us": round(avg_s * 1e6, 2),
+                        "frac": round(ach / peak, 4), "traffic": traffic_of(name), "avg_us": round(avg_s * 1e6, 2),
                         "share_of_kernel_time": round(v["ms"] / total_ms, 3)}
             break
         kernels = {}

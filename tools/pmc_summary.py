@@ -1,7 +1,10 @@
 #!/usr/bin/env python
 """Per-kernel averages of rocprofv3 --pmc passes (counter_collection.csv files).
 
-    python tools/pmc_summary.py <dir with */*/*_counter_collection.csv> [substring filter]
+    python tools/pmc_summary.py <dir with */*/*_counter_collection.csv> [substring filter] [--json out.json]
+
+--json writes {kernel name: HBM bytes per launch} (read + write, corrected as below) for the kernels
+that have both a FETCH_SIZE and a WRITE_SIZE pass: bench.py loads profiles/traffic.json from it.
 
 FETCH_SIZE / WRITE_SIZE are reported in bytes per launch with the corrections of
 /opt/skills/guides/MI355X_MICROARCH.md (TCC counters count 32 B... see HBM section):
@@ -24,8 +27,15 @@ def short(name):
 
 
 def main():
-    root = sys.argv[1]
-    filt = sys.argv[2] if len(sys.argv) > 2 else ""
+    args = list(sys.argv[1:])
+    json_out = None
+    if "--json" in args:
+        i = args.index("--json")
+        json_out = args[i + 1]
+        del args[i:i + 2]
+    root = args[0]
+    filt = args[1] if len(args) > 1 else ""
+    traffic = {}
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
     dur = collections.defaultdict(list)
     for path in glob.glob(root + "/**/*_counter_collection.csv", recursive=True):
@@ -39,6 +49,8 @@ def main():
         c = {n: sum(v) / len(v) for n, v in acc[k].items()}
         n = max(len(v) for v in acc[k].values())
         out = ["%-60s n=%d" % (k, n)]
+        if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+            traffic[k.split(" lds=")[0]] = round(c["FETCH_SIZE"] * 1024 * 2 + c["WRITE_SIZE"] * 1024)
         if "FETCH_SIZE" in c:
             out.append("hbm_read_MB=%.2f" % (c["FETCH_SIZE"] * 1024 * 2 / 1e6))
         if "WRITE_SIZE" in c:
@@ -47,6 +59,12 @@ def main():
             if n_ not in ("FETCH_SIZE", "WRITE_SIZE"):
                 out.append("%s=%.4g" % (n_, v))
         print("  ".join(out))
+    if json_out:
+        import json
+
+        with open(json_out, "w") as f:
+            json.dump({"unit": "HBM bytes per launch (2 x FETCH_SIZE + WRITE_SIZE, kB units -> bytes)",
+                       "source": root, "kernels": traffic}, f, indent=1, sort_keys=True)
 
 
 if __name__ == "__main__":
