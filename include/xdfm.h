@@ -356,7 +356,8 @@ int xdfm_cin_bwd(const float* x0, const float* xk, const float* w, int64_t B, in
  *     d_x0 = this layer's contribution + d_x0_in + d_x0_in2 (each [B,F,D] or NULL; d_x0_in = d_x0 is
  *     xdfm_cin_bwd's "accumulated into").  The layer that runs first can write instead of adding to
  *     a cleared array, the one that runs last can fold a second producer's gradient (the DNN
- *     tower's) in: the table gradient then reads one array per token. */
+ *     tower's) in: the table gradient then reads one array per token.
+ *     ldw: floats between consecutive rows of d_w (0 = L), as in xdfm_cin_pack_job. */
 #define XDFM_CIN_BWD_DX 1
 #define XDFM_CIN_BWD_DW 2
 #define XDFM_CIN_BWD_DW_PARTIAL 4
@@ -366,6 +367,9 @@ typedef struct xdfm_cin_pack_job {
   int32_t F, H, L, masked;
   float* fwd_image;  /* xdfm_cin_pack_floats fwd_floats elements, or NULL */
   float* bwd_image;  /* bwd_floats elements, or NULL */
+  int32_t ldw;       /* floats between consecutive filter rows (0 = L): L may be a leading column
+                      * range of a wider filter (a layer's hidden channels, see xdfm_cin_pair_sum) */
+  int32_t reserved;  /* set to 0 */
 } xdfm_cin_pack_job;
 int xdfm_cin_pack_floats(int64_t B, int32_t F, int32_t H, int32_t D, int32_t L, int32_t masked,
                          size_t* fwd_floats, size_t* bwd_floats);
@@ -377,7 +381,31 @@ int xdfm_cin_bwd_packed(const float* x0, const float* xk, const float* bwd_image
                         int32_t H, int32_t D, int32_t L, int32_t n_hidden, int32_t masked,
                         const float* d_xnext, const float* d_pooled, int32_t pool_stride,
                         int32_t pool_off, float* d_xk, float* d_x0, float* d_w, float* dw_part,
-                        int32_t phases, const float* d_x0_in, const float* d_x0_in2, void* stream);
+                        int32_t phases, const float* d_x0_in, const float* d_x0_in2, int32_t ldw, void* stream);
+
+/* The pooled ("direct") channels of a layer (xDeepFM.py:253-270: channels n >= n_hidden are summed
+ * over the embedding dimension) without the factor D of work: the sum over d is taken first,
+ *     S[b,p] = sum_d x0[b,f,d] xk[b,h,d]          p = f*H + h, or the index of (f,h) in the row-major
+ *                                                  strict upper triangle on the masked layer
+ *     pooled[b,j] = sum_p S[b,p] wp[p,j]           wp = the filter's columns n_hidden.. in pair order,
+ *                                                  the masked layer's factor 2 folded in
+ * -- the same sums in another association, 1/D of the multiply-adds.  A layer then runs its hidden
+ * channels alone through xdfm_cin_fwd_packed / xdfm_cin_bwd_packed (L = n_hidden, ldw = the filter's
+ * width) and its pooled channels as
+ *   forward : xdfm_cin_pool_pack, xdfm_cin_pair_sum, xdfm_dense_fwd(S, wp) -> pooled columns
+ *   backward: xdfm_dense_bwd(S, wp, d_pooled columns) -> dS, dwp; xdfm_cin_pool_unpack(dwp) -> d_w
+ *             columns; xdfm_cin_pair_bwd(dS) -> d_x0 (+ d_xk), written or added to.
+ * xdfm_cin_pair_count: number of pairs P. */
+int xdfm_cin_pair_count(int32_t F, int32_t H, int32_t masked, int64_t* pairs);
+int xdfm_cin_pair_sum(const float* x0, const float* xk, int64_t B, int32_t F, int32_t H, int32_t D,
+                      int32_t masked, float* S, void* stream);
+int xdfm_cin_pair_bwd(const float* x0, const float* xk, const float* dS, int64_t B, int32_t F, int32_t H,
+                      int32_t D, int32_t masked, float* d_x0, int32_t accumulate_x0, float* d_xk,
+                      int32_t accumulate_xk, void* stream);
+int xdfm_cin_pool_pack(const float* w, int32_t F, int32_t H, int32_t L, int32_t n_hidden, int32_t masked,
+                       float* wp, void* stream);
+int xdfm_cin_pool_unpack(const float* dwp, int32_t F, int32_t H, int32_t L, int32_t n_hidden,
+                         int32_t masked, float* d_w, void* stream);
 
 /* cross_activation (xDeepFM.py:242, :402): the activation between a CIN layer's product and its
  * split.  With a non-identity activation run the layer with n_hidden = L (raw curr[B,L,D] into a

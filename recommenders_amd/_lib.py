@@ -61,6 +61,8 @@ class CinPackJob(ctypes.Structure):
         ("masked", ctypes.c_int32),
         ("fwd_image", ctypes.c_void_p),
         ("bwd_image", ctypes.c_void_p),
+        ("ldw", ctypes.c_int32),
+        ("reserved", ctypes.c_int32),
     ]
 
 
@@ -120,7 +122,12 @@ SIGNATURES = {
     "xdfm_cin_pack": [_P, _I32, _I64, _I32, _P],
     "xdfm_cin_fwd_packed": [_P, _P, _P, _I64, _I32, _I32, _I32, _I32, _I32, _I32, _P, _P, _I32, _I32, _P],
     "xdfm_cin_bwd_packed": [_P, _P, _P, _I64, _I32, _I32, _I32, _I32, _I32, _I32, _P, _P, _I32, _I32, _P,
-                            _P, _P, _P, _I32, _P, _P, _P],
+                            _P, _P, _P, _I32, _P, _P, _I32, _P],
+    "xdfm_cin_pair_count": [_I32, _I32, _I32, ctypes.POINTER(ctypes.c_int64)],
+    "xdfm_cin_pair_sum": [_P, _P, _I64, _I32, _I32, _I32, _I32, _P, _P],
+    "xdfm_cin_pair_bwd": [_P, _P, _P, _I64, _I32, _I32, _I32, _I32, _P, _I32, _P, _I32, _P],
+    "xdfm_cin_pool_pack": [_P, _I32, _I32, _I32, _I32, _I32, _P, _P],
+    "xdfm_cin_pool_unpack": [_P, _I32, _I32, _I32, _I32, _I32, _P, _P],
     "xdfm_bn_fwd": [_P, _I64, _I32, _I32, _P, _P, _P, _P, ctypes.c_float, ctypes.c_float, _I32, _I32, _P, _P, _P],
     "xdfm_softmax_fwd": [_P, _I64, _I32, _I32, _P, _P],
     "xdfm_softmax_bwd": [_P, _P, _I64, _I32, _I32, _P, _P],

@@ -12,7 +12,10 @@ namespace xdfm_cin {
 struct CinDims {
   int64_t B;
   int F, H, D, L, n_hidden, masked;
+  int ldw;  // floats between consecutive rows of the filter / its gradient (0 = L): a layer may run on
+            // a leading column range of a wider filter (its hidden channels)
 };
+__host__ __device__ inline int cin_ldw(const CinDims& c) { return c.ldw ? c.ldw : c.L; }
 
 // shapes the MFMA path handles (else the generic VALU kernels run)
 bool mfma_supported(int64_t B, int F, int H, int D, int L);

@@ -52,7 +52,7 @@ __device__ __forceinline__ void fwd_accumulate(const CinDims& c, const float* __
     const float af = as[f * Tp + tid];
     for (int h = c.masked ? f + 1 : 0; h < c.H; ++h) {
       const float t = af * xs[h * Tp + tid];
-      const float* __restrict__ wrow = w + (int64_t)(f * c.H + h) * c.L + c0;
+      const float* __restrict__ wrow = w + (int64_t)(f * c.H + h) * cin_ldw(c) + c0;
 #pragma unroll
       for (int n = 0; n < NCH; ++n)
         if (FULL || c0 + n < c.L) out[n] = fmaf(t, wrow[n], out[n]);
@@ -145,7 +145,7 @@ __device__ __forceinline__ void dx_accumulate(const CinDims& c, const float* __r
     const float af = as[f * Tp + tid];
     float accf = 0.f;
     for (int h = c.masked ? f + 1 : 0; h < c.H; ++h) {
-      const float* __restrict__ wrow = w + (int64_t)(f * c.H + h) * c.L + c0;
+      const float* __restrict__ wrow = w + (int64_t)(f * c.H + h) * cin_ldw(c) + c0;
       float g = 0.f;
 #pragma unroll
       for (int n = 0; n < NCH; ++n)
@@ -291,7 +291,7 @@ __global__ void cin_dw_reduce_kernel(CinDims c, const float* __restrict__ part, 
   float s = 0.f;
   if (!(c.masked && h <= f))
     for (int k = 0; k < n_splits; ++k) s += part[(int64_t)k * total + idx];
-  d_w[idx] = s;
+  d_w[(int64_t)p * cin_ldw(c) + (idx - (int64_t)p * c.L)] = s;
 }
 
 int pick_nch(int L) {
@@ -497,7 +497,8 @@ extern "C" int xdfm_cin_bwd_packed(const float* x0, const float* xk, const float
                                    int32_t H, int32_t D, int32_t L, int32_t n_hidden, int32_t masked,
                                    const float* d_xnext, const float* d_pooled, int32_t pool_stride,
                                    int32_t pool_off, float* d_xk, float* d_x0, float* d_w, float* dw_part,
-                                   int32_t phases, const float* d_x0_in, const float* d_x0_in2, void* stream) {
+                                   int32_t phases, const float* d_x0_in, const float* d_x0_in2, int32_t ldw,
+                                   void* stream) {
   int rc = check_dims("xdfm_cin_bwd_packed", B, F, H, D, L, n_hidden, masked);
   if (rc) return rc;
   XDFM_REQUIRE(phases >= 1 && phases <= 15, "xdfm_cin_bwd_packed: phases is a mask of XDFM_CIN_BWD_*");
@@ -513,7 +514,8 @@ extern "C" int xdfm_cin_bwd_packed(const float* x0, const float* xk, const float
       XDFM_HIP(hipMemsetAsync(d_w, 0, (size_t)F * H * L * sizeof(float), st));
     return XDFM_OK;
   }
-  CinDims c{B, F, H, D, L, n_hidden, masked};
+  XDFM_REQUIRE(ldw == 0 || ldw >= L, "xdfm_cin_bwd_packed: ldw must be 0 or >= L");
+  CinDims c{B, F, H, D, L, n_hidden, masked, ldw};
   return xdfm_cin::bwd_mfma(c, x0, xk, nullptr, bwd_image, d_xnext, d_pooled, pool_stride, pool_off, d_xk, d_x0,
                             d_w, dw_part, phases, st, d_x0_in, d_x0_in2);
 }

@@ -92,7 +92,7 @@ __device__ __forceinline__ void pack_fwd_body(const CinDims& c, const float* __r
   const int o = 4 * oq + (i >> 2), n = 4 * nq + (i & 3), in = 4 * ks + k;
   const int f = swap ? in : o, h = swap ? o : in;
   const bool ok = (desc & kFwdValid) && f < c.F && h < c.H && n < c.L && (!c.masked || h > f);
-  const float v = ok ? w[(int64_t)(f * c.H + h) * c.L + n] : 0.f;
+  const float v = ok ? w[(int64_t)(f * c.H + h) * cin_ldw(c) + n] : 0.f;
   wq[(((int64_t)nq * (nsteps_img >> 2) + (s >> 2)) * 64 + lane) * 4 + (s & 3)] = v;
 }
 
@@ -282,7 +282,7 @@ __global__ void cin_pack_w_kernel(CinDims c, const float* __restrict__ w, int Hp
   const int h = (int)(t % Hp);
   const int f = (int)(t / Hp);  // = 4*ft + fi
   const bool ok = f < c.F && h < c.H && n < c.L && (!c.masked || h > f);
-  wpk[idx] = ok ? w[(int64_t)(f * c.H + h) * c.L + n] : 0.f;
+  wpk[idx] = ok ? w[(int64_t)(f * c.H + h) * cin_ldw(c) + n] : 0.f;
 }
 
 // Block = 4 waves x 16 rows.  Pair tile = 4 f x 4 h (lane&15 = fi*4 + hi).
@@ -524,7 +524,7 @@ __device__ __forceinline__ void pack_dx_body(const CinDims& c, const float* __re
   const int i = lane & 15, k = lane >> 4;
   const int f = 4 * ft + (i >> 2), h = 4 * ht + (i & 3), n = 4 * s + k;
   const bool ok = f < c.F && h < c.H && n < c.L && (!c.masked || h > f);
-  wdx[idx] = ok ? w[(int64_t)(f * c.H + h) * c.L + n] : 0.f;
+  wdx[idx] = ok ? w[(int64_t)(f * c.H + h) * cin_ldw(c) + n] : 0.f;
 }
 
 template <int S>
@@ -1050,7 +1050,8 @@ __global__ __launch_bounds__(256) void cin_dw_unpack_kernel(CinDims c, const flo
 #pragma unroll
       for (int q = 0; q < 8; ++q) t += red[q][e];
     }
-    d_w[idx] = t * (c.masked ? 2.f : 1.f);
+    const int64_t pr = idx / c.L;
+    d_w[pr * cin_ldw(c) + (idx - pr * c.L)] = t * (c.masked ? 2.f : 1.f);
   }
 }
 
@@ -1357,7 +1358,7 @@ int pack_all(const xdfm_cin_pack_job* jobs, int n_jobs, int64_t B, int D, hipStr
     XDFM_REQUIRE(!in.fwd_image || ff, "xdfm_cin_pack: job %d has no packed forward path", k);
     XDFM_REQUIRE(!in.bwd_image || bf, "xdfm_cin_pack: job %d has no packed backward path", k);
     PackJob& J = pj.j[pj.n];
-    J.c = CinDims{B, in.F, in.H, D, in.L, 0, in.masked ? 1 : 0};
+    J.c = CinDims{B, in.F, in.H, D, in.L, 0, in.masked ? 1 : 0, in.ldw};
     J.w = in.w;
     J.fwd = in.fwd_image;
     J.dx = in.bwd_image;

@@ -277,6 +277,11 @@ class XDeepFMEngine(object):
         self.early_reg = (self.overlap_dnn_wanted(hp) and self.sparse and not hp.is_clip_norm
                           and 0 < len(self.dense_shapes) <= 32)
         self.prepack = os.environ.get("XDFM_CIN_PREPACK", "1") != "0"
+        # pooled channels summed over d first (S = sum_d x0*xk, pooled = S Wp): 1/D of their MACs, but
+        # measured slower on configs[2] (0.629 against 0.572 ms/step: the layer kernels do not shrink
+        # with the channel count and the pair kernels sit at 24/38 us) -- opt-in until they do
+        self.pool_split = os.environ.get("XDFM_POOL_SPLIT", "0") != "0"
+        self._split = {}
         self.split_dw = os.environ.get("XDFM_SPLIT_DW", "1") != "0"
         self._late_event = None
         self._fold_dx = False
@@ -456,6 +461,8 @@ class XDeepFMEngine(object):
         sz = ctypes.c_size_t()
         _lib.check(self.lib.xdfm_dense_bwd_workspace_floats(B, 1, 1, ctypes.byref(sz)))
         part_floats = sz.value
+        pool_part_floats = 1
+        self._split = {}
         if hp.use_CIN_part:
             shapes = cin_shapes(hp)
             final_len = sum(L - nh for (_, L, nh) in shapes)
@@ -475,25 +482,57 @@ class XDeepFMEngine(object):
                         buf("bn_stats_cin_%d" % k, 2 * L)
             if self.cross_path:
                 buf("d_cur", B, max(L for (_, L, _) in shapes) * D)
+            self._split = {}
+            max_pairs = 0
             for k, (H, L, nh) in enumerate(shapes):
                 if self.fast_d:
                     _lib.check(self.lib.xdfm_fast_cin_bwd_workspace_floats(B, F, H, D, L, self.fast_d,
                                                                            ctypes.byref(sz)))
                     part_floats = max(part_floats, sz.value)
                     continue
-                _lib.check(self.lib.xdfm_cin_bwd_workspace_floats(B, F, H, D, L, ctypes.byref(sz)))
+                # The pooled channels (n >= nh) take their sum over the embedding dimension first
+                # (xdfm_cin_pair_sum + a plain product: 1/D of the multiply-adds); the layer kernels
+                # then carry the nh hidden channels only.  Needs the packed path for that narrower
+                # layer (or no hidden channel at all: the last layer).
+                Lk = L
+                if self.pool_split and self.prepack and not self.cross_path and L - nh > 0:
+                    fsz, bsz = ctypes.c_size_t(), ctypes.c_size_t()
+                    if nh > 0:
+                        _lib.check(self.lib.xdfm_cin_pack_floats(B, F, H, D, nh, 1 if k == 0 else 0,
+                                                                 ctypes.byref(fsz), ctypes.byref(bsz)))
+                    if nh == 0 or (fsz.value and bsz.value):
+                        npair = ctypes.c_int64()
+                        _lib.check(self.lib.xdfm_cin_pair_count(F, H, 1 if k == 0 else 0, ctypes.byref(npair)))
+                        P, Lp = int(npair.value), L - nh
+                        self._split[k] = (P, Lp)
+                        max_pairs = max(max_pairs, P)
+                        buf("S_%d" % k, B, P)
+                        buf("wp_%d" % k, P, Lp)
+                        buf("dwp_%d" % k, P, Lp)
+                        buf("pool_%d" % k, B, Lp)
+                        _lib.check(self.lib.xdfm_dense_bwd_workspace_floats(B, P, Lp, ctypes.byref(sz)))
+                        pool_part_floats = max(pool_part_floats, sz.value)
+                        Lk = nh
+                if Lk == 0:
+                    continue
+                _lib.check(self.lib.xdfm_cin_bwd_workspace_floats(B, F, H, D, Lk, ctypes.byref(sz)))
                 part_floats = max(part_floats, sz.value)
-                _lib.check(self.lib.xdfm_cin_fwd_workspace_floats(B, F, H, D, L, ctypes.byref(sz)))
+                _lib.check(self.lib.xdfm_cin_fwd_workspace_floats(B, F, H, D, Lk, ctypes.byref(sz)))
                 part_floats = max(part_floats, sz.value)
                 # filter images packed once per step, ahead of the layer calls (where the shape
                 # has a packed path)
                 fsz, bsz = ctypes.c_size_t(), ctypes.c_size_t()
-                _lib.check(self.lib.xdfm_cin_pack_floats(B, F, H, D, L, 1 if k == 0 else 0, ctypes.byref(fsz),
+                _lib.check(self.lib.xdfm_cin_pack_floats(B, F, H, D, Lk, 1 if k == 0 else 0, ctypes.byref(fsz),
                                                          ctypes.byref(bsz)))
                 if self.prepack and fsz.value:
                     buf("img_f_%d" % k, fsz.value)
                 if self.prepack and bsz.value:
                     buf("img_b_%d" % k, bsz.value)
+            if self._split:
+                buf("dS", B, max_pairs)
+                buf("part_pool", pool_part_floats)
+                buf("zeros", max(Lp for (_, Lp) in self._split.values()))  # the bias of the plain product
+                buf("db_pool", max(Lp for (_, Lp) in self._split.values()))  # its (unused) bias gradient
             _lib.check(self.lib.xdfm_dense_bwd_workspace_floats(B, final_len, 1, ctypes.byref(sz)))
             part_floats = max(part_floats, sz.value)
         dnn_part_floats = 1
@@ -686,7 +725,9 @@ class XDeepFMEngine(object):
             # d_emb without a clear and without a second array: the CIN layer whose backward runs
             # first writes it, the one that runs last folds the DNN tower's gradient in
             self._fold_dx = bool(with_grad and hp.use_CIN_part and not self.fast_d and not self.cross_path
-                                 and all(("img_b_%d" % k) in ws for k in range(len(hp.cross_layer_sizes)))
+                                 and "img_b_0" in ws
+                                 and all(("img_b_%d" % k) in ws or (k in self._split and nh == 0)
+                                         for k, (_, _, nh) in enumerate(cin_shapes(hp)))
                                  and self._dnn_plain() and os.environ.get("XDFM_FOLD_DX", "1") != "0")
             with torch.cuda.stream(side):
                 self._dnn_forward(B)
@@ -712,6 +753,22 @@ class XDeepFMEngine(object):
                 # with a cross_activation the layer writes raw curr for all L channels; the
                 # activation kernel then produces the hidden / pooled split
                 out_h, out_nh = (ws["cur_%d" % k], L) if self.cross_path else (xnext, nh)
+                if k in self._split:
+                    P, Lp = self._split[k]
+                    if nh > 0:
+                        _lib.check(
+                            lib.xdfm_cin_fwd_packed(_ptr(x0), _ptr(xk), _ptr(ws["img_f_%d" % k]), B, F, H, D,
+                                                    nh, nh, 1 if k == 0 else 0, _ptr(xnext), _ptr(ws["pooled"]),
+                                                    final_len, off, st)
+                        )
+                    _lib.check(lib.xdfm_cin_pair_sum(_ptr(x0), _ptr(xk), B, F, H, D, 1 if k == 0 else 0,
+                                                     _ptr(ws["S_%d" % k]), st))
+                    _lib.check(lib.xdfm_dense_fwd(_ptr(ws["S_%d" % k]), _ptr(ws["wp_%d" % k]), _ptr(ws["zeros"]), B, P,
+                                                  Lp, 0, _ptr(ws["pool_%d" % k]), st))
+                    ws["pooled"][:B, off:off + Lp].copy_(ws["pool_%d" % k][:B])
+                    off += L - nh
+                    xk = xnext
+                    continue
                 if self.fast_d:
                     _lib.check(
                         lib.xdfm_fast_cin_fwd(_ptr(x0), _ptr(xk), _ptr(self.views["fcin_w_%d" % k]),
@@ -816,13 +873,17 @@ class XDeepFMEngine(object):
         jobs = (_lib.CinPackJob * len(shapes))()
         n = 0
         for k, (H, L, nh) in enumerate(shapes):
+            if k in self._split:  # the pooled channels' filter slice in pair order
+                _lib.check(self.lib.xdfm_cin_pool_pack(_ptr(self.views["cin_f_%d" % k]), self.F, H, L, nh,
+                                                       1 if k == 0 else 0, _ptr(ws["wp_%d" % k]), self._stream()))
             f_img = ws.get("img_f_%d" % k)
             b_img = ws.get("img_b_%d" % k) if with_grad else None
             if f_img is None and b_img is None:
                 continue
-            jobs[n] = _lib.CinPackJob(self.views["cin_f_%d" % k].data_ptr(), self.F, H, L, 1 if k == 0 else 0,
+            Lk = nh if k in self._split else L  # a split layer's kernels carry its hidden channels only
+            jobs[n] = _lib.CinPackJob(self.views["cin_f_%d" % k].data_ptr(), self.F, H, Lk, 1 if k == 0 else 0,
                                       f_img.data_ptr() if f_img is not None else None,
-                                      b_img.data_ptr() if b_img is not None else None)
+                                      b_img.data_ptr() if b_img is not None else None, L, 0)
             n += 1
         for s0 in range(0, n, 8):
             chunk = ctypes.cast(ctypes.byref(jobs, s0 * ctypes.sizeof(_lib.CinPackJob)), ctypes.c_void_p)
@@ -1051,21 +1112,46 @@ class XDeepFMEngine(object):
                                               _ptr(ws["part"]), st)
                     )
                     continue
+                fold = self.overlap_dnn and self._fold_dx
+                first_writer = fold and k == len(shapes) - 1  # nothing has been put into d_emb yet
+                Lk, pair_after = L, False
+                if k in self._split:
+                    # pooled channels: dS = d_pooled Wp^T and dWp = S^T d_pooled as one dense-layer
+                    # backward, then the per-sample products with dS
+                    P, Lp = self._split[k]
+                    ws["pool_%d" % k][:B].copy_(ws["d_pooled"][:B, offs[k]:offs[k] + Lp])
+                    _lib.check(
+                        lib.xdfm_dense_bwd(_ptr(ws["S_%d" % k]), _ptr(ws["wp_%d" % k]), _ptr(ws["pool_%d" % k]),
+                                           _ptr(ws["pool_%d" % k]), B, P, Lp, 0, _ptr(ws["dS"]), 0,
+                                           _ptr(ws["dwp_%d" % k]), _ptr(ws["db_pool"]), _ptr(ws["part_pool"]), st)
+                    )
+                    _lib.check(lib.xdfm_cin_pool_unpack(_ptr(ws["dwp_%d" % k]), F, H, L, nh, 1 if k == 0 else 0,
+                                                        _ptr(gv["cin_f_%d" % k]), st))
+                    if nh == 0:  # no hidden channel: the layer is done with the pair products
+                        _lib.check(lib.xdfm_cin_pair_bwd(_ptr(x0), _ptr(xk), _ptr(ws["dS"]), B, F, H, D,
+                                                         1 if k == 0 else 0, _ptr(d_emb), 0 if first_writer else 1,
+                                                         _ptr(d_xk), 0, st))
+                        continue
+                    Lk, up_nh, d_pool, pair_after = nh, nh, None, True
                 if ("img_b_%d" % k) in ws:
-                    fold = self.overlap_dnn and self._fold_dx
-                    add0 = None if (fold and k == len(shapes) - 1) else d_emb
+                    add0 = None if first_writer else d_emb
                     add1 = ws["d_emb_dnn"] if (fold and k == 0) else None
                     if add1 is not None:
                         torch.cuda.current_stream(self.device).wait_event(dnn_dx_done)
 
                     def layer_bwd(phases, stream):
                         _lib.check(
-                            lib.xdfm_cin_bwd_packed(_ptr(x0), _ptr(xk), _ptr(ws["img_b_%d" % k]), B, F, H, D, L,
+                            lib.xdfm_cin_bwd_packed(_ptr(x0), _ptr(xk), _ptr(ws["img_b_%d" % k]), B, F, H, D, Lk,
                                                     up_nh, 1 if k == 0 else 0, _ptr(d_xnext), _ptr(d_pool),
                                                     final_len, offs[k], _ptr(d_xk), _ptr(d_emb),
                                                     _ptr(gv["cin_f_%d" % k]), _ptr(ws["part"]), phases,
-                                                    _ptr(add0), _ptr(add1), stream)
+                                                    _ptr(add0), _ptr(add1), L if Lk != L else 0, stream)
                         )
+
+                    def pair_bwd():
+                        if pair_after:  # behind the hidden channels' kernel, which wrote d_xk
+                            _lib.check(lib.xdfm_cin_pair_bwd(_ptr(x0), _ptr(xk), _ptr(ws["dS"]), B, F, H, D,
+                                                             1 if k == 0 else 0, _ptr(d_emb), 1, _ptr(d_xk), 1, st))
 
                     side_dw = dnn_done is not None and self.split_dw
                     if k == 1 and side_dw and "img_b_0" in ws:
@@ -1073,6 +1159,7 @@ class XDeepFMEngine(object):
                         # that only the optimizer waits for: the side stream runs it (and is the
                         # next writer of the partials' buffer, with the first layer's gradient)
                         layer_bwd(1 | 4, st)
+                        pair_bwd()
                         part_done = torch.cuda.Event()
                         part_done.record(torch.cuda.current_stream(self.device))
                         side.wait_event(part_done)
@@ -1083,6 +1170,7 @@ class XDeepFMEngine(object):
                         # path: it runs on the side stream beside the table gradient / update
                         # (latency bound), which only needs d_emb
                         layer_bwd(1, st)
+                        pair_bwd()
                         dx_done = torch.cuda.Event()
                         dx_done.record(torch.cuda.current_stream(self.device))
                         side.wait_event(dx_done)
@@ -1092,6 +1180,7 @@ class XDeepFMEngine(object):
                             self._late_event.record(side)
                     else:
                         layer_bwd(3, st)
+                        pair_bwd()
                     continue
                 _lib.check(
                     lib.xdfm_cin_bwd(_ptr(x0), _ptr(xk), _ptr(self.views["cin_f_%d" % k]), B, F, H, D, L,

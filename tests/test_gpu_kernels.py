@@ -288,6 +288,32 @@ def test_graphed_sparse_rows_step_sorts_one_batch_ahead_and_equals_eager():
             assert torch.equal(sa[k], sb[k]), k
 
 
+@pytest.mark.parametrize("name", ["all_parts", "criteo_shape", "wide_shape"])
+def test_pooled_channels_summed_over_d_first_equal_the_layer_kernels(name):
+    """The pooled channels of a CIN layer through xdfm_cin_pair_sum + a plain product (the sum over the
+    embedding dimension taken first) against the layer kernels carrying every channel: another
+    association of the same fp32 sums, 1e-5 apart at most."""
+    hp = make_hp(**CONFIGS[name])
+    rng = np.random.default_rng(4)
+    b = random_batch(rng, hp, 70)
+    p32 = X.init_params(hp, seed=3)
+    outs = []
+    for split in (True, False):
+        eng = load_engine(hp, p32)
+        eng.pool_split = split
+        db = upload(eng, b)
+        eng.forward(db, with_loss=True, with_grad=True)
+        eng.backward(db)
+        torch.cuda.synchronize()
+        assert bool(eng._split) == split
+        d_emb = eng.ws["d_emb"][:70].clone()
+        if eng.d_emb2() is not None:
+            d_emb = d_emb + eng.d_emb2()[:70]
+        outs.append((eng.ws["logit"][:70].clone(), eng.dense_grad.clone(), d_emb))
+    for x, y, what in zip(outs[0], outs[1], ("logit", "dense gradients", "d emb_out")):
+        close(x.cpu().numpy(), y.cpu().numpy(), rtol=2e-5, what=what)
+
+
 def test_dropout_training_matches_oracle_given_the_masks():
     """user_dropout (base_model.py:335-336, :377): the masks come from the engine's own generator
     (TF's stream is not reproducible); with the same masks the oracle must take the same steps.
@@ -336,6 +362,7 @@ def test_filters_packed_ahead_change_no_bit(name):
     for prepack in (True, False):
         eng = load_engine(hp, p32)
         eng.prepack = prepack
+        eng.pool_split = False  # (the pooled channels' own path needs the packed images: off on both sides)
         db = upload(eng, b)
         eng.forward(db, with_loss=True, with_grad=True)
         eng.backward(db)
