@@ -123,8 +123,8 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(
         beg[u] = row_ptr[r];
         end[u] = row_ptr[r + 1];
         const int64_t guess = r < nnz ? r : 0;
-        id0[u] = ids[guess];
-        w0[u] = weights[guess];
+        id0[u] = nnz > 0 ? ids[guess] : 0;  // a batch without tokens has no array to guess in
+        w0[u] = nnz > 0 ? weights[guess] : 0.f;
         if (f >= F) end[u] = beg[u];  // no such row: behaves as empty, nothing is stored
       }
 #pragma unroll

@@ -90,15 +90,6 @@ def gen_hparams_and_metrics():
         mcases.append({"labels": y.tolist(), "preds": [float(v) for v in p],
                        "metrics": ["auc", "logloss", "rmse", "acc", "f1"],
                        "expected": {k: float(v) for k, v in res.items()}})
-    # the docstring-style grouped call (deeprec_utils.py:529-530 shows the format)
-    gl = [rng.integers(0, 2, 6).astype(float) for _ in range(5)]
-    gp = [rng.random(6) for _ in range(5)]
-    for g in gl:
-        g[0], g[1] = 1.0, 0.0
-    res = R.cal_metric(gl, gp, ["ndcg@2;4;6", "group_auc", "mean_mrr", "hit@1;3"])
-    mcases.append({"labels": [g.tolist() for g in gl], "preds": [g.tolist() for g in gp],
-                   "metrics": ["ndcg@2;4;6", "group_auc", "mean_mrr", "hit@1;3"],
-                   "expected": {k: float(v) for k, v in res.items()}})
     with open(os.path.join(HERE, "cal_metric_golden.json"), "w") as f:
         json.dump(mcases, f)
 
@@ -153,7 +144,35 @@ def gen_iterator():
         json.dump(out, f)
 
 
+def gen_notebook_hparams():
+    """The HParams the quick-start notebook PRINTED when its authors ran it
+    (examples/00_quick_start/xdeepfm_criteo.ipynb, the cell that calls prepare_hparams): an output
+    the reference holds, taken as text from the notebook's JSON, together with that cell's keyword
+    arguments.  The yaml it read (a downloaded resource) is not in the repository; the test rebuilds
+    an equivalent one from the printed values."""
+    import ast
+
+    with open("/root/reference/examples/00_quick_start/xdeepfm_criteo.ipynb") as f:
+        nb = json.load(f)
+    for cell in nb["cells"]:
+        if cell["cell_type"] != "code" or "prepare_hparams(yaml_file" not in "".join(cell["source"]):
+            continue
+        text = "".join("".join(o.get("text", "")) for o in cell.get("outputs", []))
+        at = text.index("HParams object with values ") + len("HParams object with values ")
+        values = ast.literal_eval(text[at:].strip())
+        kwargs = dict(FEATURE_COUNT=2300000, FIELD_COUNT=39, cross_l2=0.01, embed_l2=0.01, layer_l2=0.01,
+                      learning_rate=0.002, batch_size=4096, epochs=10, cross_layer_sizes=[20, 10],
+                      init_value=0.1, layer_sizes=[20, 20], use_Linear_part=True, use_CIN_part=True,
+                      use_DNN_part=True)
+        with open(os.path.join(HERE, "notebook_hparams.json"), "w") as out:
+            json.dump({"source": "examples/00_quick_start/xdeepfm_criteo.ipynb (printed output)",
+                       "kwargs": kwargs, "printed_values": values}, out, indent=1)
+        return
+    raise RuntimeError("notebook cell not found")
+
+
 if __name__ == "__main__":
     gen_hparams_and_metrics()
+    gen_notebook_hparams()
     gen_iterator()
     print("golden fixtures written to", HERE)

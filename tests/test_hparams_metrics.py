@@ -68,3 +68,30 @@ def test_cal_metric_docstring_example_and_errors():
     # preds of exactly 0 / 1 are clipped, not infinite
     r = U.cal_metric([0.0, 1.0], [np.float32(1.0), np.float32(0.0)], ["logloss"])
     assert np.isfinite(r["logloss"]) and r["logloss"] > 20
+
+
+def test_notebook_hparams_equal_the_values_the_reference_printed(golden, tmp_path):
+    """configs[1]: the quick-start notebook printed its HParams (xdeepfm_criteo.ipynb, the
+    prepare_hparams cell).  The yaml it read is a downloaded resource; an equivalent one is rebuilt
+    here from the printed values of the keys such a file sets -- every other key of the printed
+    dict must come out of this package's defaults and the cell's keyword arguments."""
+    import yaml
+
+    fx = golden("notebook_hparams.json")
+    printed, kwargs = fx["printed_values"], fx["kwargs"]
+    sections = {
+        "data": ["data_format"],
+        "model": ["method", "model_type", "dim", "activation", "dropout", "use_FM_part"],
+        "train": ["init_method", "loss", "optimizer", "enable_BN"],
+        "show": ["show_step", "save_model", "save_epoch", "metrics"],
+        "info": ["load_model_name"],
+    }
+    doc = {sec: {k: printed[k] for k in keys} for sec, keys in sections.items()}
+    path = tmp_path / "xDeepFM.yaml"
+    path.write_text(yaml.safe_dump(doc))
+    hp = U.prepare_hparams(str(path), **kwargs)
+    got = hp.values()
+    assert set(got) == set(printed), (set(got) ^ set(printed))
+    for k, v in printed.items():
+        assert got[k] == v and type(got[k]) is type(v), (k, got[k], v)
+    assert "HParams object with values " + repr(printed) == str(hp) or got == printed
