@@ -15,9 +15,14 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <condition_variable>
+#include <functional>
+#include <memory>
+#include <mutex>
 #include <cerrno>
 #include <cmath>
 #include <cstdlib>
+#include <cstring>
 #include <limits>
 #include <numeric>
 #include <cstdarg>
@@ -201,6 +206,9 @@ struct Staging {
   std::vector<uint8_t> imp_present;
   std::string imp_chars;
   int64_t dnn_width = 0;
+  bool in_order = true;   // tokens already in (row, col) order (the dnn view needs no sort)
+  bool in_range = true;   // every field inside [0, F)
+  int64_t lo = 0, hi = 0; // the samples of the batch this piece holds
   // per-sample scratch: running count per field (reference: dnn_feat_dic, :178-185)
   std::vector<int64_t> cnt, stamp;                        // fields inside [0, F)
   std::vector<std::pair<int64_t, int64_t>> field_count;   // any other field index
@@ -218,6 +226,7 @@ struct Staging {
     imp_present.clear();
     imp_chars.clear();
     dnn_width = 0;
+    in_order = in_range = true;
     err_code = 0;
     err.clear();
   }
@@ -233,6 +242,74 @@ struct Staging {
   }
 };
 
+namespace {
+
+// Threads that live as long as the reader: a batch is parsed and its arrays are filled by the same
+// few threads, so neither step pays for starting them (a batch of 8192 lines lasts about a
+// millisecond).  run(n, fn) calls fn(0..n-1), one index per thread, and returns when all are done.
+class Pool {
+ public:
+  explicit Pool(int threads) {
+    for (int t = 1; t < threads; ++t) th_.emplace_back([this, t]() { loop(t); });
+  }
+  ~Pool() {
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      stop_ = true;
+      ++gen_;
+    }
+    cv_.notify_all();
+    for (auto& t : th_) t.join();
+  }
+  int size() const { return (int)th_.size() + 1; }
+  void run(int n, const std::function<void(int)>& fn) {
+    if (n <= 1) {
+      if (n == 1) fn(0);
+      return;
+    }
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      fn_ = &fn;
+      n_ = n;
+      pending_ = n - 1;
+      ++gen_;
+    }
+    cv_.notify_all();
+    fn(0);
+    std::unique_lock<std::mutex> lk(mu_);
+    done_.wait(lk, [this]() { return pending_ == 0; });
+    fn_ = nullptr;
+  }
+
+ private:
+  void loop(int t) {
+    uint64_t seen = 0;
+    for (;;) {
+      const std::function<void(int)>* fn = nullptr;
+      {
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_.wait(lk, [&]() { return gen_ != seen; });
+        seen = gen_;
+        if (stop_) return;
+        if (t < n_) fn = fn_;
+      }
+      if (!fn) continue;
+      (*fn)(t);
+      std::lock_guard<std::mutex> lk(mu_);
+      if (--pending_ == 0) done_.notify_one();
+    }
+  }
+  std::vector<std::thread> th_;
+  std::mutex mu_;
+  std::condition_variable cv_, done_;
+  const std::function<void(int)>* fn_ = nullptr;
+  int n_ = 0, pending_ = 0;
+  uint64_t gen_ = 0;
+  bool stop_ = false;
+};
+
+}  // namespace
+
 struct xdfm_ffm_reader {
   int fd = -1;
   const char* data = nullptr;
@@ -241,13 +318,18 @@ struct xdfm_ffm_reader {
   int64_t line_no = 0;  // lines consumed so far
   int64_t F = 0, N = 0;
   char col_sep = ' ', id_sep = '%';
-  // staged batch, file order
+  // staged batch, file order: `pieces` runs of lines, one per parsing thread
   int64_t first_line = 0;
-  Staging st;                    // the batch
-  std::vector<Staging> workers;  // per-thread pieces of it
+  int64_t n_rows = 0, nnz = 0;
+  std::vector<Staging> workers;
+  int pieces = 0;
+  std::vector<int64_t> tok_base, imp_base;  // of each piece, [pieces + 1]
+  bool in_order = true, in_range = true;
+  Staging st;                   // the pieces joined: only when the dnn view has to be sorted
+  std::vector<uint32_t> order;  // dnn view permutation (stable by (row, col)) of `st`
   std::vector<xdfm::Span> lines;
-  std::vector<uint32_t> order;  // dnn view permutation (stable by (row, col))
   int threads = 1;
+  std::unique_ptr<Pool> pool;
 };
 
 extern "C" int xdfm_ffm_open(const char* path, int64_t field_count, int64_t feature_count,
@@ -287,12 +369,14 @@ extern "C" int xdfm_ffm_open(const char* path, int64_t field_count, int64_t feat
     int t = e ? atoi(e) : (int)std::thread::hardware_concurrency();
     r->threads = t < 1 ? 1 : (t > 16 ? 16 : t);
   }
+  r->pool.reset(new Pool(r->threads));
   *out = r;
   return XDFM_OK;
 }
 
 extern "C" int xdfm_ffm_close(xdfm_ffm_reader* r) {
   if (!r) return XDFM_OK;
+  r->pool.reset();
   if (r->data) munmap((void*)r->data, r->size);
   if (r->fd >= 0) close(r->fd);
   delete r;
@@ -306,13 +390,10 @@ int parse_line(const xdfm_ffm_reader* r, Staging& st, Span line, int64_t sample,
   using namespace xdfm;
   line = strip(line);
   // words = line.split(ID_spliter); impression id only when len(words) == 2
-  const char* first_sep = nullptr;
-  int seps = 0;
-  for (const char* p = line.b; p < line.e; ++p)
-    if (*p == r->id_sep) {
-      if (!first_sep) first_sep = p;
-      ++seps;
-    }
+  const char* first_sep = line.empty() ? nullptr : (const char*)memchr(line.b, r->id_sep, (size_t)(line.e - line.b));
+  int seps = first_sep ? 1 : 0;
+  if (first_sep && first_sep + 1 < line.e && memchr(first_sep + 1, r->id_sep, (size_t)(line.e - first_sep - 1)))
+    seps = 2;  // two or more: no impression id (:101-103)
   Span head = line;
   if (first_sep) head.e = first_sep;
   st.imp_off.push_back((int64_t)st.imp_chars.size());
@@ -329,8 +410,8 @@ int parse_line(const xdfm_ffm_reader* r, Staging& st, Span line, int64_t sample,
   const char* p = head.b;
   auto next_word = [&](Span* w) -> bool {
     if (p > head.e) return false;
-    const char* q = p;
-    while (q < head.e && *q != r->col_sep) ++q;
+    const char* q = (const char*)memchr(p, r->col_sep, (size_t)(head.e - p));
+    if (!q) q = head.e;
     *w = Span{p, q};
     p = q + 1;  // past the separator (or past the end -> terminates)
     return true;
@@ -349,6 +430,8 @@ int parse_line(const xdfm_ffm_reader* r, Staging& st, Span line, int64_t sample,
     st.stamp.assign((size_t)r->F, -1);
   }
   const int64_t epoch = ln;  // unique per line
+  int64_t prev_row = st.dnn_row.empty() ? -1 : st.dnn_row.back();
+  int64_t prev_col = st.dnn_col.empty() ? -1 : st.dnn_col.back();
   while (next_word(&w)) {
     if (strip(w).empty()) continue;
     // tokens = word.split(':'); tokens[0..2] used, extra ones ignored
@@ -376,6 +459,7 @@ int parse_line(const xdfm_ffm_reader* r, Staging& st, Span line, int64_t sample,
         st.cnt[(size_t)field] = 0;
       }
     } else {
+      st.in_range = false;
       bool seen = false;
       for (auto& fc : st.field_count)
         if (fc.first == field) {
@@ -385,10 +469,14 @@ int parse_line(const xdfm_ffm_reader* r, Staging& st, Span line, int64_t sample,
         }
       if (!seen) st.field_count.emplace_back(field, 0);
     }
+    const int64_t row = sample * r->F + field;
+    if (row < prev_row || (row == prev_row && col < prev_col)) st.in_order = false;
+    prev_row = row;
+    prev_col = col;
     st.tok_sample.push_back(sample);
     st.tok_feat.push_back(feat);
     st.tok_val.push_back((float)val);
-    st.dnn_row.push_back(sample * r->F + field);
+    st.dnn_row.push_back(row);
     st.dnn_col.push_back(col);
     if (col + 1 > st.dnn_width) st.dnn_width = col + 1;
   }
@@ -400,13 +488,33 @@ void append(std::vector<T>& dst, const std::vector<T>& src) {
   dst.insert(dst.end(), src.begin(), src.end());
 }
 
+// the pieces joined into r->st and the stable (row, col) order of the dnn view: only for batches
+// whose tokens do not already come in that order (fields out of order inside a line)
+void join_and_sort(xdfm_ffm_reader* r) {
+  Staging& st = r->st;
+  st.clear();
+  for (int t = 0; t < r->pieces; ++t) {
+    const Staging& w = r->workers[(size_t)t];
+    append(st.tok_sample, w.tok_sample);
+    append(st.tok_feat, w.tok_feat);
+    append(st.dnn_row, w.dnn_row);
+    append(st.dnn_col, w.dnn_col);
+    append(st.tok_val, w.tok_val);
+  }
+  const size_t nnz = st.dnn_row.size();
+  r->order.resize(nnz);
+  std::iota(r->order.begin(), r->order.end(), 0u);
+  std::stable_sort(r->order.begin(), r->order.end(), [&st](uint32_t a, uint32_t b) {
+    if (st.dnn_row[a] != st.dnn_row[b]) return st.dnn_row[a] < st.dnn_row[b];
+    return st.dnn_col[a] < st.dnn_col[b];
+  });
+}
+
 }  // namespace
 
 extern "C" int xdfm_ffm_next(xdfm_ffm_reader* r, int64_t batch_size, xdfm_ffm_batch_info* info) {
   XDFM_REQUIRE(r && info, "xdfm_ffm_next: null argument");
   XDFM_REQUIRE(batch_size > 0, "xdfm_ffm_next: batch_size must be positive");
-  Staging& st = r->st;
-  st.clear();
   r->first_line = r->line_no + 1;
 
   // 1. the next batch_size lines (universal newlines)
@@ -414,8 +522,11 @@ extern "C" int xdfm_ffm_next(xdfm_ffm_reader* r, int64_t batch_size, xdfm_ffm_ba
   const char* end = r->data + r->size;
   while ((int64_t)r->lines.size() < batch_size && r->pos < r->size) {
     const char* b = r->data + r->pos;
-    const char* e = b;
-    while (e < end && *e != '\n' && *e != '\r') ++e;
+    // the line ends at the first '\n' or '\r': two library scans instead of a byte loop (this
+    // part runs on one thread)
+    const char* e = (const char*)memchr(b, '\n', (size_t)(end - b));
+    if (!e) e = end;
+    if (const char* cr = (const char*)memchr(b, '\r', (size_t)(e - b))) e = cr;
     size_t next = (size_t)(e - r->data);
     if (e < end) next += (*e == '\r' && e + 1 < end && e[1] == '\n') ? 2 : 1;
     r->pos = next;
@@ -428,88 +539,50 @@ extern "C" int xdfm_ffm_next(xdfm_ffm_reader* r, int64_t batch_size, xdfm_ffm_ba
   int T = r->threads;
   if (T > n / 256) T = (int)(n / 256);
   if (T < 1) T = 1;
+  if ((int)r->workers.size() < T) r->workers.resize((size_t)T);
   const int64_t base_line = r->line_no;
-  if (T == 1) {
-    for (int64_t i = 0; i < n; ++i)
-      if (parse_line(r, st, r->lines[(size_t)i], i, base_line + i + 1) != XDFM_OK) break;
-  } else {
-    if ((int)r->workers.size() < T) r->workers.resize((size_t)T);
-    std::vector<std::thread> pool;
-    const int64_t per = (n + T - 1) / T;
-    for (int t = 0; t < T; ++t) {
-      pool.emplace_back([r, t, per, n, base_line]() {
-        Staging& w = r->workers[(size_t)t];
-        w.clear();
-        const int64_t lo = t * per, hi = std::min<int64_t>(n, lo + per);
-        for (int64_t i = lo; i < hi; ++i)
-          if (parse_line(r, w, r->lines[(size_t)i], i, base_line + i + 1) != XDFM_OK) break;
-      });
-    }
-    for (auto& th : pool) th.join();
-    // 3. stitch the pieces together in file order; the first failing piece decides the error
-    for (int t = 0; t < T; ++t) {
-      Staging& w = r->workers[(size_t)t];
-      const int64_t imp_base = (int64_t)st.imp_chars.size();
-      append(st.labels, w.labels);
-      append(st.tok_sample, w.tok_sample);
-      append(st.tok_feat, w.tok_feat);
-      append(st.dnn_row, w.dnn_row);
-      append(st.dnn_col, w.dnn_col);
-      append(st.tok_val, w.tok_val);
-      append(st.imp_present, w.imp_present);
-      for (int64_t o : w.imp_off) st.imp_off.push_back(o + imp_base);
-      st.imp_chars += w.imp_chars;
-      if (w.dnn_width > st.dnn_width) st.dnn_width = w.dnn_width;
-      if (w.err_code) {
-        st.err_code = w.err_code;
-        st.err = w.err;
-        break;
-      }
+  const int64_t per = (n + T - 1) / T;
+  r->pool->run(T, [r, per, n, base_line](int t) {
+    Staging& w = r->workers[(size_t)t];
+    w.clear();
+    w.lo = std::min<int64_t>(n, t * per);
+    w.hi = std::min<int64_t>(n, w.lo + per);
+    for (int64_t i = w.lo; i < w.hi; ++i)
+      if (parse_line(r, w, r->lines[(size_t)i], i, base_line + i + 1) != XDFM_OK) break;
+  });
+  r->line_no += n;
+  r->pieces = T;
+
+  // 3. the pieces stay where they are; the first failing one (file order) decides the error
+  r->tok_base.assign((size_t)T + 1, 0);
+  r->imp_base.assign((size_t)T + 1, 0);
+  r->in_order = r->in_range = true;
+  int64_t width = 0, prev_row = -1, prev_col = -1;
+  for (int t = 0; t < T; ++t) {
+    Staging& w = r->workers[(size_t)t];
+    if (w.err_code) return xdfm::fail(w.err_code, "%s", w.err.c_str());
+    r->tok_base[(size_t)t + 1] = r->tok_base[(size_t)t] + (int64_t)w.dnn_row.size();
+    r->imp_base[(size_t)t + 1] = r->imp_base[(size_t)t] + (int64_t)w.imp_chars.size();
+    width = std::max(width, w.dnn_width);
+    r->in_range = r->in_range && w.in_range;
+    r->in_order = r->in_order && w.in_order;
+    if (!w.dnn_row.empty()) {
+      if (w.dnn_row.front() < prev_row || (w.dnn_row.front() == prev_row && w.dnn_col.front() < prev_col))
+        r->in_order = false;
+      prev_row = w.dnn_row.back();
+      prev_col = w.dnn_col.back();
     }
   }
-  r->line_no += n;
-  if (st.err_code) return xdfm::fail(st.err_code, "%s", st.err.c_str());
-  st.imp_off.push_back((int64_t)st.imp_chars.size());
-
-  // dnn view order: stable by (row, col)   (iterator.py:198-201)
-  const size_t nnz = r->st.dnn_row.size();
-  r->order.resize(nnz);
-  std::iota(r->order.begin(), r->order.end(), 0u);
-  bool sorted = true;
-  for (size_t k = 1; k < nnz && sorted; ++k)
-    sorted = std::make_pair(r->st.dnn_row[k - 1], r->st.dnn_col[k - 1]) <=
-             std::make_pair(r->st.dnn_row[k], r->st.dnn_col[k]);
-  if (!sorted)
-    std::stable_sort(r->order.begin(), r->order.end(), [r](uint32_t a, uint32_t b) {
-      if (r->st.dnn_row[a] != r->st.dnn_row[b]) return r->st.dnn_row[a] < r->st.dnn_row[b];
-      return r->st.dnn_col[a] < r->st.dnn_col[b];
-    });
+  r->n_rows = n;
+  r->nnz = r->tok_base[(size_t)T];
+  if (!r->in_order) join_and_sort(r);  // dnn view order: stable by (row, col)   (iterator.py:198-201)
 
   info->n_rows = n;
-  info->nnz = (int64_t)nnz;
-  info->dnn_width = r->st.dnn_width;
-  info->imp_bytes = (int64_t)r->st.imp_chars.size();
+  info->nnz = r->nnz;
+  info->dnn_width = width;
+  info->imp_bytes = r->imp_base[(size_t)T];
   info->first_line = r->first_line;
   return XDFM_OK;
-}
-
-// fn(lo, hi) over [0, n) on up to T threads (the arrays of a batch are tens of megabytes: one
-// core's store bandwidth is what the fill is bound by)
-template <typename Fn>
-static void par_ranges(size_t n, int T, Fn fn) {
-  if (T > 8) T = 8;
-  if (T <= 1 || n < ((size_t)1 << 16)) {
-    fn((size_t)0, n);
-    return;
-  }
-  std::vector<std::thread> pool;
-  const size_t per = (n + (size_t)T - 1) / (size_t)T;
-  for (int t = 0; t < T; ++t) {
-    const size_t lo = (size_t)t * per, hi = std::min(n, lo + per);
-    if (lo >= hi) break;
-    pool.emplace_back([fn, lo, hi]() { fn(lo, hi); });
-  }
-  for (auto& th : pool) th.join();
 }
 
 extern "C" int xdfm_ffm_fill(xdfm_ffm_reader* r, float* labels, int64_t* fm_feat_indices,
@@ -518,43 +591,69 @@ extern "C" int xdfm_ffm_fill(xdfm_ffm_reader* r, float* labels, int64_t* fm_feat
                              int32_t* row_ptr, int64_t* imp_offsets, char* imp_chars,
                              uint8_t* imp_present) {
   XDFM_REQUIRE(r, "xdfm_ffm_fill: null reader");
-  const size_t n = r->st.labels.size();
-  const size_t nnz = r->st.dnn_row.size();
-  if (labels) memcpy(labels, r->st.labels.data(), n * sizeof(float));
-  par_ranges(nnz, r->threads, [=](size_t lo, size_t hi) {
-    if (fm_feat_indices)
-      for (size_t k = lo; k < hi; ++k) {
-        fm_feat_indices[2 * k] = r->st.tok_sample[k];
-        fm_feat_indices[2 * k + 1] = r->st.tok_feat[k];
-      }
-    if (fm_feat_values) memcpy(fm_feat_values + lo, r->st.tok_val.data() + lo, (hi - lo) * sizeof(float));
-    for (size_t k = lo; k < hi; ++k) {
-      const uint32_t s = r->order[k];
-      if (dnn_feat_indices) {
-        dnn_feat_indices[2 * k] = r->st.dnn_row[s];
-        dnn_feat_indices[2 * k + 1] = r->st.dnn_col[s];
-      }
-      if (dnn_feat_values) dnn_feat_values[k] = r->st.tok_feat[s];
-      if (dnn_feat_weights) dnn_feat_weights[k] = r->st.tok_val[s];
-    }
-  });
+  const int64_t n = r->n_rows, nnz = r->nnz, F = r->F;
+  const int64_t rows = n * F;
   if (row_ptr) {
-    const int64_t rows = (int64_t)n * r->F;
-    XDFM_REQUIRE(rows + 1 < (int64_t)1 << 31 && nnz < ((size_t)1 << 31),
+    XDFM_REQUIRE(rows + 1 < (int64_t)1 << 31 && nnz < ((int64_t)1 << 31),
                  "xdfm_ffm_fill: batch too large for int32 CSR offsets");
-    memset(row_ptr, 0, (size_t)(rows + 1) * sizeof(int32_t));
-    for (size_t k = 0; k < nnz; ++k) {
-      const int64_t row = r->st.dnn_row[k];
-      if (row < 0 || row >= rows)
-        return xdfm::fail(XDFM_E_INVALID,
-                          "batch starting at line %lld: field index outside [1, FIELD_COUNT=%lld]",
-                          (long long)r->first_line, (long long)r->F);
-      row_ptr[row + 1] += 1;
-    }
-    for (int64_t i = 0; i < rows; ++i) row_ptr[i + 1] += row_ptr[i];
+    if (!r->in_range)
+      return xdfm::fail(XDFM_E_INVALID, "batch starting at line %lld: field index outside [1, FIELD_COUNT=%lld]",
+                        (long long)r->first_line, (long long)F);
   }
-  if (imp_offsets) memcpy(imp_offsets, r->st.imp_off.data(), (n + 1) * sizeof(int64_t));
-  if (imp_chars && !r->st.imp_chars.empty()) memcpy(imp_chars, r->st.imp_chars.data(), r->st.imp_chars.size());
-  if (imp_present) memcpy(imp_present, r->st.imp_present.data(), n);
+  // every piece writes its own stretch of the arrays (tens of megabytes per batch: one core's
+  // store bandwidth would be the bound)
+  const bool sorted = r->in_order;
+  r->pool->run(r->pieces, [=](int t) {
+    const Staging& w = r->workers[(size_t)t];
+    const size_t base = (size_t)r->tok_base[(size_t)t], cnt = w.dnn_row.size();
+    if (labels && w.hi > w.lo) memcpy(labels + w.lo, w.labels.data(), (size_t)(w.hi - w.lo) * sizeof(float));
+    if (fm_feat_indices)
+      for (size_t k = 0; k < cnt; ++k) {
+        fm_feat_indices[2 * (base + k)] = w.tok_sample[k];
+        fm_feat_indices[2 * (base + k) + 1] = w.tok_feat[k];
+      }
+    if (fm_feat_values && cnt) memcpy(fm_feat_values + base, w.tok_val.data(), cnt * sizeof(float));
+    if (sorted) {
+      if (dnn_feat_indices)
+        for (size_t k = 0; k < cnt; ++k) {
+          dnn_feat_indices[2 * (base + k)] = w.dnn_row[k];
+          dnn_feat_indices[2 * (base + k) + 1] = w.dnn_col[k];
+        }
+      if (dnn_feat_values && cnt) memcpy(dnn_feat_values + base, w.tok_feat.data(), cnt * sizeof(int64_t));
+      if (dnn_feat_weights && cnt) memcpy(dnn_feat_weights + base, w.tok_val.data(), cnt * sizeof(float));
+    } else {
+      // positions [base, base + cnt) of the sorted view, gathered from the joined staging
+      const Staging& st = r->st;
+      for (size_t k = base; k < base + cnt; ++k) {
+        const uint32_t s = r->order[k];
+        if (dnn_feat_indices) {
+          dnn_feat_indices[2 * k] = st.dnn_row[s];
+          dnn_feat_indices[2 * k + 1] = st.dnn_col[s];
+        }
+        if (dnn_feat_values) dnn_feat_values[k] = st.tok_feat[s];
+        if (dnn_feat_weights) dnn_feat_weights[k] = st.tok_val[s];
+      }
+    }
+    if (row_ptr) {
+      // fields in range: this piece's tokens fall into rows [lo*F, hi*F) and no other piece's do,
+      // so its CSR offsets are its token base plus a running count (entries lo*F+1 .. hi*F)
+      const int64_t r0 = w.lo * F, r1 = w.hi * F;
+      if (t == 0) row_ptr[0] = 0;
+      for (int64_t i = r0 + 1; i <= r1; ++i) row_ptr[i] = 0;
+      for (size_t k = 0; k < cnt; ++k) row_ptr[w.dnn_row[k] + 1] += 1;
+      int32_t acc = (int32_t)base;
+      for (int64_t i = r0 + 1; i <= r1; ++i) {
+        acc += row_ptr[i];
+        row_ptr[i] = acc;
+      }
+    }
+    if (imp_offsets) {
+      const int64_t ib = r->imp_base[(size_t)t];
+      for (int64_t i = w.lo; i < w.hi; ++i) imp_offsets[i] = w.imp_off[(size_t)(i - w.lo)] + ib;
+      if (imp_chars && !w.imp_chars.empty()) memcpy(imp_chars + ib, w.imp_chars.data(), w.imp_chars.size());
+    }
+    if (imp_present && w.hi > w.lo) memcpy(imp_present + w.lo, w.imp_present.data(), (size_t)(w.hi - w.lo));
+  });
+  if (imp_offsets) imp_offsets[n] = r->imp_base[(size_t)r->pieces];
   return XDFM_OK;
 }

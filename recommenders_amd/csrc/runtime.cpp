@@ -3,6 +3,7 @@
 // bench.py uses for its roofline line.
 #include <hip/hip_runtime_api.h>
 
+#include <atomic>
 #include <map>
 #include <mutex>
 #include <string>
@@ -31,30 +32,40 @@ struct Record {
   hipEvent_t beg, end;
 };
 std::mutex g_mu;
-bool g_on = false;
+std::atomic<bool> g_on{false};
 std::vector<Record> g_records;
 constexpr size_t kMaxRecords = 1u << 18;
 }  // namespace
 
-ProfScope::ProfScope(const char* name, void* stream) : slot_(-1), stream_(stream) {
-  if (!g_on) return;
-  std::lock_guard<std::mutex> lk(g_mu);
-  if (!g_on || g_records.size() >= kMaxRecords) return;
-  Record r{name, nullptr, nullptr};
-  if (hipEventCreate(&r.beg) != hipSuccess) return;
-  if (hipEventCreate(&r.end) != hipSuccess) {
-    (void)hipEventDestroy(r.beg);
+ProfScope::ProfScope(const char* name, void* stream) : name_(name), stream_(stream), beg_(nullptr), end_(nullptr) {
+  if (!g_on.load(std::memory_order_relaxed)) return;
+  // an event recorded on a capturing stream would become part of the graph (or fail the capture)
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing((hipStream_t)stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) {
+    (void)hipGetLastError();
     return;
   }
-  (void)hipEventRecord(r.beg, (hipStream_t)stream);
-  slot_ = (long)g_records.size();
-  g_records.push_back(r);
+  hipEvent_t beg = nullptr, end = nullptr;
+  if (hipEventCreate(&beg) != hipSuccess) return;
+  if (hipEventCreate(&end) != hipSuccess) {
+    (void)hipEventDestroy(beg);
+    return;
+  }
+  (void)hipEventRecord(beg, (hipStream_t)stream);
+  beg_ = beg;
+  end_ = end;
 }
 
 ProfScope::~ProfScope() {
-  if (slot_ < 0) return;
+  if (!beg_) return;
+  (void)hipEventRecord((hipEvent_t)end_, (hipStream_t)stream_);
   std::lock_guard<std::mutex> lk(g_mu);
-  if ((size_t)slot_ < g_records.size()) (void)hipEventRecord(g_records[slot_].end, (hipStream_t)stream_);
+  if (g_on.load(std::memory_order_relaxed) && g_records.size() < kMaxRecords) {
+    g_records.push_back(Record{name_, (hipEvent_t)beg_, (hipEvent_t)end_});  // complete: both events recorded
+  } else {
+    (void)hipEventDestroy((hipEvent_t)beg_);
+    (void)hipEventDestroy((hipEvent_t)end_);
+  }
 }
 
 }  // namespace xdfm
@@ -64,7 +75,7 @@ extern "C" const char* xdfm_last_error(void) { return xdfm::error_buffer(); }
 
 extern "C" int xdfm_prof_enable(int32_t on) {
   std::lock_guard<std::mutex> lk(xdfm::g_mu);
-  xdfm::g_on = on != 0;
+  xdfm::g_on.store(on != 0);
   return XDFM_OK;
 }
 

@@ -15,7 +15,8 @@ int fail(int code, const char* fmt, ...);
 inline bool opt_needs_v(int kind) { return kind == 1 || kind == 4 || kind == 5; }
 
 // Times everything enqueued on `stream` during its lifetime when xdfm_prof_enable(1) is on
-// (two HIP events); otherwise a no-op.  The name is the kernel's (as rocprofv3 prints it).
+// (two HIP events, owned by the scope until both are recorded); a no-op otherwise and on a stream
+// that is being captured into a graph.  The name is the kernel's (as rocprofv3 prints it).
 class ProfScope {
  public:
   ProfScope(const char* name, void* stream);
@@ -24,8 +25,10 @@ class ProfScope {
   ProfScope& operator=(const ProfScope&) = delete;
 
  private:
-  long slot_;
+  const char* name_;
   void* stream_;
+  void* beg_;  // hipEvent_t, null when the scope is off
+  void* end_;
 };
 
 }  // namespace xdfm

@@ -132,8 +132,9 @@ class FFMTextIterator(BaseIterator):
         epoch, and parsing text is an order of magnitude slower than the training step, so the
         batches of a file that fits the budget (XDFM_FFM_CACHE_MB of host memory, default 4096,
         0 = off) are kept and yielded again while the file is unchanged (same size and mtime).
-        The feed dicts themselves are kept, so whatever the model attached to them (the batch in
-        device memory, its sort plan) is reused as well."""
+        The feed dicts themselves are kept (their arrays read-only), so whatever the model attached
+        to them (the batch in device memory, its sort plan) is reused as well; the model bounds
+        that device memory by XDFM_FFM_CACHE_DEVICE_MB (base_model._batch_from_feed)."""
         budget = int(os.environ.get("XDFM_FFM_CACHE_MB", "4096")) << 20
         if budget <= 0:
             yield from self._read_ahead(self._load_native(infile))
@@ -156,6 +157,11 @@ class FFMTextIterator(BaseIterator):
                 if held + size > budget:
                     kept = None  # too large: stream it, as the reference does
                 else:
+                    # handed out again by reference in later epochs: a caller that wrote into
+                    # them would corrupt those epochs
+                    for v in item[0].values():
+                        if isinstance(v, np.ndarray):
+                            v.setflags(write=False)
                     kept.append(item)
             yield item
         if kept is not None:
@@ -292,11 +298,14 @@ class FFMTextIterator(BaseIterator):
             # np.asarray([], dtype)[[]] in the reference has shape (0,), not (0, 2)
             fm_idx = fm_idx.reshape(0)
             dnn_idx = dnn_idx.reshape(0)
-        raw = imp_chars.tobytes()
-        impression_ids = [
-            raw[imp_off[i] : imp_off[i + 1]].decode("utf-8", "replace") if imp_present[i] else 0
-            for i in range(n)
-        ]
+        if imp_present.any():
+            raw = imp_chars.tobytes()
+            impression_ids = [
+                raw[imp_off[i] : imp_off[i + 1]].decode("utf-8", "replace") if imp_present[i] else 0
+                for i in range(n)
+            ]
+        else:
+            impression_ids = [0] * n
         res = {
             "labels": labels,
             "fm_feat_indices": fm_idx,

@@ -10,6 +10,7 @@ engine without a visible GPU raises.
 
 import ctypes
 import os
+import warnings
 
 import numpy as np
 import torch
@@ -587,12 +588,13 @@ class XDeepFMEngine(object):
         idx = np.ascontiguousarray(np.asarray(dnn_feat_indices, dtype=np.int64).reshape(-1, 2))
         if not (len(ids) == len(w) == len(idx)):
             raise ValueError("dnn_feat_indices / values / weights disagree in length")
-        return self.make_batch(
-            torch.from_numpy(labels).to(dev, non_blocking=True),
-            torch.from_numpy(idx).to(dev, non_blocking=True),
-            torch.from_numpy(ids).to(dev, non_blocking=True),
-            torch.from_numpy(w).to(dev, non_blocking=True),
-        )
+        def dev_copy(a):
+            # arrays the iterator keeps for later epochs are read-only; they are only read here
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore", UserWarning)
+                return torch.from_numpy(a).to(dev, non_blocking=True)
+
+        return self.make_batch(dev_copy(labels), dev_copy(idx), dev_copy(ids), dev_copy(w))
 
     def make_batch(self, labels, dnn_idx, ids, weights):
         """Device tensors -> DeviceBatch (builds the CSR offsets on the device)."""
@@ -1464,7 +1466,7 @@ class GraphedStep(object):
         nnz = max(int(ids.numel()), 1)
         if self.lookahead:
             dev = engine.device
-            self.next_ids = torch.empty_like(self.inputs[2])
+            self.next_ids = self.inputs[2].clone()  # always ids of a real batch: the replay sorts and reads rows by them
             self.plan_cur = [torch.empty((nnz,), dtype=torch.int32, device=dev) for _ in range(2)]
             self.plan_next = [torch.empty((nnz,), dtype=torch.int32, device=dev) for _ in range(2)]
         # warm up on a side stream (allocations, lazy module loads), as torch asks before a capture
@@ -1532,7 +1534,10 @@ class GraphedStep(object):
                 self.next_ids.copy_(next_ids, non_blocking=True)
                 self._planned_for = next_ids.data_ptr()
             else:
-                self._planned_for = None  # the replay prepares whatever next_ids holds: taken back later
+                # nothing announced: the replay's look-ahead prepares this batch's own rows again
+                # (valid ids, nothing to bring forward; the marks are taken back by the next call)
+                self.next_ids.copy_(cur_ids, non_blocking=True)
+                self._planned_for = None
             eng._announced = self._nb
         self.graph.replay()
         eng.step += 1

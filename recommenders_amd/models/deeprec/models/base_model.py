@@ -18,6 +18,7 @@ Differences that are visible on purpose:
 import abc
 import os
 import time
+import weakref
 from os.path import join
 
 import numpy as np
@@ -129,11 +130,25 @@ class BaseModel:
             feed_dict[it.dnn_feat_values],
             feed_dict[it.dnn_feat_weights],
         )
-        try:
-            feed_dict.device_batch = batch
-        except AttributeError:
-            pass  # a plain dict: nothing to cache on
+        # The iterator may keep this feed dict for later epochs (XDFM_FFM_CACHE_MB); the batch in
+        # device memory stays attached to it only inside a budget of its own, XDFM_FFM_CACHE_DEVICE_MB
+        # (default 8192, 0 = never keep device batches): beyond it the batch is uploaded again.
+        nbytes = sum(t.numel() * t.element_size() for t in
+                     (batch.labels, batch.ids, batch.weights, batch.row_ptr, batch.tok_row))
+        nbytes += 16 * batch.nnz  # the sort plan the first training step attaches
+        budget = int(os.environ.get("XDFM_FFM_CACHE_DEVICE_MB", "8192")) << 20
+        held = getattr(self, "_device_cache_bytes", 0)
+        if held + nbytes <= budget:
+            try:
+                feed_dict.device_batch = batch
+            except AttributeError:
+                return batch  # a plain dict: nothing to cache on
+            self._device_cache_bytes = held + nbytes
+            weakref.finalize(feed_dict, self._release_device_cache, nbytes)
         return batch
+
+    def _release_device_cache(self, nbytes):
+        self._device_cache_bytes = max(0, getattr(self, "_device_cache_bytes", 0) - nbytes)
 
     def train(self, sess, feed_dict):
         """One optimisation step on the batch in ``feed_dict``.

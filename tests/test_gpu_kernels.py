@@ -575,7 +575,12 @@ def test_graph_replay_equals_eager_steps(dropout):
     torch.cuda.synchronize()
     graph.check_errors()
     assert losses_g == losses_e[1:]
-    assert torch.equal(eager.table, graph.table) and torch.equal(eager.dense, graph.dense)
-    assert torch.equal(eager.table_m, graph.table_m) and torch.equal(eager.lin_w, graph.lin_w)
+    # state_dict() brings every row up to date first: a replay without an announced next batch
+    # prepares whatever its next-ids buffer holds (rows caught up a step early, taken back later),
+    # so the raw records may differ in how far single rows have been brought forward
+    se, sg = eager.state_dict(), graph.state_dict()
+    for k in ("embedding", "lin_w", "slot/table_m", "slot/table_v", "slot/lin_m"):
+        assert torch.equal(se[k], sg[k]), k
+    assert torch.equal(eager.dense, graph.dense)
     assert all(torch.equal(eager.bn_state[k], graph.bn_state[k]) for k in eager.bn_state)  # moving statistics
     assert graph.state_dict()["step"] == 3 and abs(graph.state_dict()["b1p"] - 0.9 ** 3) < 1e-6

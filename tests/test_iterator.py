@@ -104,6 +104,42 @@ def test_native_reader_vs_oracle_on_plumbing_sample(tmp_path):
         assert np.array_equal(feed.row_ptr, ptr)
 
 
+@pytest.mark.parametrize("threads", ["1", "5"])
+def test_native_reader_pieces_parsed_on_several_threads_equal_the_oracle(tmp_path, monkeypatch, threads):
+    """Batches large enough to be split between parsing threads (a piece is at least 256 lines):
+    ragged lines, fields out of order inside a line (the dnn view then needs its stable sort),
+    multi-hot fields, impression ids on some lines, a partial last batch, and a file whose last
+    batches come sorted -- each piece writes its own stretch of the arrays and of the CSR offsets."""
+    from tests.util import random_features, write_libffm
+
+    monkeypatch.setenv("XDFM_PARSE_THREADS", threads)
+    monkeypatch.setenv("XDFM_FFM_CACHE_MB", "0")
+    rng = np.random.default_rng(7)
+    F, N, B = 9, 300, 1500
+    labels, feats = random_features(rng, 3 * B + 700, F, N, multi_p=0.3, missing_p=0.2)
+    for toks in feats[2 * B:]:  # the tail of the file in field order: no sort needed there
+        toks.sort(key=lambda t: t[0])
+    path = write_libffm(str(tmp_path / "big.txt"), labels, feats, imp_every=3)
+    hp = make_hp(FEATURE_COUNT=N, FIELD_COUNT=F, batch_size=B)
+    it = FFMTextIterator(hp, None)
+    got = list(it.load_data_from_file(path))
+    exp = list(O.batches(path, B, F, N))
+    assert len(got) == len(exp) == 4
+    for (feed, imps, n), (arrays, eimps, en) in zip(got, exp):
+        assert n == en and list(imps) == eimps
+        for k in KEYS:
+            g, e = feed[getattr(it, k)], arrays[k]
+            assert g.dtype == e.dtype and g.shape == e.shape and np.array_equal(g, e), k
+        rows = arrays["dnn_feat_indices"][:, 0]
+        ptr = np.concatenate([[0], np.cumsum(np.bincount(rows, minlength=n * F))])
+        assert np.array_equal(feed.row_ptr, ptr)
+    # an error inside a later piece is reported with its line number
+    with open(path, "a") as f:
+        f.write("1 2:3:x\n")
+    with pytest.raises(ValueError, match="line %d" % (3 * B + 701)):
+        list(FFMTextIterator(hp, None).load_data_from_file(path))
+
+
 def test_parser_one_line_and_errors(tmp_path):
     hp = make_hp(FEATURE_COUNT=10, FIELD_COUNT=3, batch_size=2)
     it = FFMTextIterator(hp, None)
