@@ -407,6 +407,39 @@ int xdfm_cin_pool_pack(const float* w, int32_t F, int32_t H, int32_t L, int32_t 
 int xdfm_cin_pool_unpack(const float* dwp, int32_t F, int32_t H, int32_t L, int32_t n_hidden,
                          int32_t masked, float* d_w, void* stream);
 
+/* ------------------------------------------------------------------------
+ * The same layer on the bf16 matrix cores (v_mfma_f32_32x32x16_bf16, fp32 accumulation), for the
+ * wide shapes: embedding dim 64, up to 128 inputs per side and 128 channels per call
+ * (xDeepFM.py:191-267; BASELINE configs[4]).  Operands (x, filter, upstream gradient) are rounded
+ * to bf16, sums stay fp32: results within 2e-2 relative of the fp32 entry points.
+ * These calls run a layer's HIDDEN channels (L = their number, ldw = the filter's full width);
+ * the pooled channels go through xdfm_cin_pair_sum / xdfm_cin_pair_bwd and bf16 dense products.
+ *   xdfm_cin_bf16_image_bytes / xdfm_cin_bf16_pack: the filter in matrix-core operand order, one
+ *     image for the forward pass and one for the input gradient (256-byte aligned device buffers;
+ *     either may be NULL), valid until the filter changes.  On the masked layer the images hold
+ *     the symmetrised filter w[(min(f,h), max(f,h))] with a zero diagonal (the same sum as
+ *     "pairs f < h, times 2").
+ *   xdfm_cin_bf16_fwd:    xnext[B,L,D].
+ *   xdfm_cin_bf16_bwd_dx: d_xk[B,H,D] written (NULL on the masked layer, where both roles are x0);
+ *                         d_x0[B,F,D] written, or added to when accumulate_x0 != 0.
+ *   xdfm_cin_bf16_bwd_dw: d_w[(f,h), 0..L) written with row stride ldw (masked layer: rows f < h,
+ *                         times 2; other rows untouched); workspace of
+ *                         xdfm_cin_bf16_bwd_dw_workspace_floats elements.
+ * ---------------------------------------------------------------------- */
+int xdfm_cin_bf16_image_bytes(int32_t F, int32_t H, int32_t L, size_t* fwd_bytes, size_t* dx_bytes);
+int xdfm_cin_bf16_pack(const float* w, int32_t F, int32_t H, int32_t L, int32_t ldw, int32_t masked,
+                       void* fwd_image, void* dx_image, void* stream);
+int xdfm_cin_bf16_fwd(const float* x0, const float* xk, const void* fwd_image, int64_t B, int32_t F,
+                      int32_t H, int32_t D, int32_t L, int32_t masked, float* xnext, void* stream);
+int xdfm_cin_bf16_bwd_dx(const float* x0, const float* xk, const void* dx_image, const float* d_xnext,
+                         int64_t B, int32_t F, int32_t H, int32_t D, int32_t L, int32_t masked,
+                         float* d_xk, float* d_x0, int32_t accumulate_x0, void* stream);
+int xdfm_cin_bf16_bwd_dw_workspace_floats(int64_t B, int32_t F, int32_t H, int32_t D, int32_t L,
+                                          size_t* floats);
+int xdfm_cin_bf16_bwd_dw(const float* x0, const float* xk, const float* d_xnext, int64_t B, int32_t F,
+                         int32_t H, int32_t D, int32_t L, int32_t masked, float* d_w, int32_t ldw,
+                         float* workspace, void* stream);
+
 /* cross_activation (xDeepFM.py:242, :402): the activation between a CIN layer's product and its
  * split.  With a non-identity activation run the layer with n_hidden = L (raw curr[B,L,D] into a
  * buffer of its own, no pooled output), then

@@ -126,6 +126,12 @@ SIGNATURES = {
     "xdfm_cin_pair_count": [_I32, _I32, _I32, ctypes.POINTER(ctypes.c_int64)],
     "xdfm_cin_pair_sum": [_P, _P, _I64, _I32, _I32, _I32, _I32, _P, _P],
     "xdfm_cin_pair_bwd": [_P, _P, _P, _I64, _I32, _I32, _I32, _I32, _P, _I32, _P, _I32, _P],
+    "xdfm_cin_bf16_image_bytes": [_I32, _I32, _I32, _PSZ, _PSZ],
+    "xdfm_cin_bf16_pack": [_P, _I32, _I32, _I32, _I32, _I32, _P, _P, _P],
+    "xdfm_cin_bf16_fwd": [_P, _P, _P, _I64, _I32, _I32, _I32, _I32, _I32, _P, _P],
+    "xdfm_cin_bf16_bwd_dx": [_P, _P, _P, _P, _I64, _I32, _I32, _I32, _I32, _I32, _P, _P, _I32, _P],
+    "xdfm_cin_bf16_bwd_dw_workspace_floats": [_I64, _I32, _I32, _I32, _I32, _PSZ],
+    "xdfm_cin_bf16_bwd_dw": [_P, _P, _P, _I64, _I32, _I32, _I32, _I32, _I32, _P, _I32, _P, _P],
     "xdfm_cin_pool_pack": [_P, _I32, _I32, _I32, _I32, _I32, _P, _P],
     "xdfm_cin_pool_unpack": [_P, _I32, _I32, _I32, _I32, _I32, _P, _P],
     "xdfm_bn_fwd": [_P, _I64, _I32, _I32, _P, _P, _P, _P, ctypes.c_float, ctypes.c_float, _I32, _I32, _P, _P, _P],

@@ -1,0 +1,238 @@
+// Filter gradient of the bf16 matrix-core CIN (see cin_bf16_kernels.hip for the family).  A file of
+// its own: the kernel keeps 256 accumulator registers per lane, which this compiler only handles in
+// its default (AGPR) MFMA form, so the Makefile builds this file without -amdgpu-mfma-vgpr-form.
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "cin_bf16.h"
+#include "xdfm_common.h"
+
+using namespace xdfm_bf16;
+
+namespace {
+
+// ---------------------------------------------------------------- filter gradient
+// dW[(f,h),n] = sum_m x0[f,m] xk[h,m] dcurr[n,m]: the contraction runs over m, so here m is the K of
+// the matrix product.  A block = 4 waves = 4 consecutive f over one split of the m range; a wave
+// keeps the whole [h][n] tile of its f in accumulators (HT x NT tiles of 32 x 32).  Per 64 m the
+// block stages xk[h][m] and dcurr[n][m] as bf16 in LDS (shared by its waves, loaded one chunk ahead
+// into registers); a wave forms its A operand x0[f,m] * xk[h,m] from the LDS fragment and its own
+// f's factors (fp32 product, rounded to bf16 once), B = dcurr.  Partial tiles per split go to the
+// workspace and are added in split order by cin_bf16_dw_reduce_kernel.
+constexpr int kDwKM = 64;     // m per staged chunk (4 k steps)
+constexpr int kDwPitch = 36;  // uint32 per LDS row: 64 bf16 + 16 bytes, so 32 rows spread over all banks
+
+template <int HT, int NT>
+__global__ __launch_bounds__(256, 1) void cin_bf16_dw_kernel(Dims c, const float* __restrict__ x0,
+                                                              const float* __restrict__ xk,
+                                                              const float* __restrict__ d_xnext,
+                                                              float* __restrict__ part, int S, int OGn,
+                                                              int chunks_per_split) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  constexpr int kXs = HT * 32 * kDwPitch, kDs = NT * 32 * kDwPitch, kBuf = kXs + kDs + 4 * kDwKM;  // uint32 units
+  uint32_t* lds = reinterpret_cast<uint32_t*>(smem);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, r = lane & 31;
+  // blocks of one split sit on one XCD (block id modulo 8) and share its L2 for the streamed inputs
+  int split, og;
+  if ((S & 7) == 0) {
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    split = xcd + 8 * (slot / OGn);
+    og = slot % OGn;
+  } else {
+    split = blockIdx.x / OGn;
+    og = blockIdx.x % OGn;
+  }
+  const int f = og * 4 + wave;
+  const int64_t total_chunks = (c.cols + kDwKM - 1) / kDwKM;
+  const int64_t ch0 = (int64_t)split * chunks_per_split;
+  int nch = (int)(total_chunks - ch0 < chunks_per_split ? total_chunks - ch0 : chunks_per_split);
+  if (nch < 0) nch = 0;
+
+  // staging: a thread owns one pair of m (columns 2*pc, 2*pc+1) of rows r0 + 8i
+  const int pc = tid & 31, r0 = tid >> 5;
+  float xv[HT * 4][2], dv[NT * 4][2], x0v;
+  auto issue = [&](int64_t ch) {
+    const int64_t m = ch * kDwKM + 2 * pc;
+    const bool ok0 = m < c.cols, ok1 = m + 1 < c.cols;
+    const int64_t b0 = ok0 ? m / c.D : 0;
+    const int d0 = ok0 ? (int)(m - b0 * c.D) : 0;
+    const int64_t b1 = (d0 + 1 < c.D) ? b0 : b0 + 1;
+    const int d1 = (d0 + 1 < c.D) ? d0 + 1 : 0;
+#pragma unroll
+    for (int i = 0; i < HT * 4; ++i) {
+      const int row = r0 + 8 * i;
+      xv[i][0] = (ok0 && row < c.H) ? xk[(b0 * c.H + row) * c.D + d0] : 0.f;
+      xv[i][1] = (ok1 && row < c.H) ? xk[(b1 * c.H + row) * c.D + d1] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < NT * 4; ++i) {
+      const int row = r0 + 8 * i;
+      dv[i][0] = (ok0 && row < c.L) ? d_xnext[(b0 * c.L + row) * c.D + d0] : 0.f;
+      dv[i][1] = (ok1 && row < c.L) ? d_xnext[(b1 * c.L + row) * c.D + d1] : 0.f;
+    }
+    const int64_t mm = ch * kDwKM + lane;  // the block's four f: one factor per thread
+    x0v = 0.f;
+    if (mm < c.cols && f < c.F) {
+      const int64_t b = mm / c.D;
+      x0v = x0[(b * c.F + f) * c.D + (int)(mm - b * c.D)];
+    }
+  };
+  auto stash = [&](int buf) {
+    uint32_t* xs = lds + buf * kBuf;
+    uint32_t* ds = xs + kXs;
+    float* xc = reinterpret_cast<float*>(ds + kDs);
+#pragma unroll
+    for (int i = 0; i < HT * 4; ++i) xs[(r0 + 8 * i) * kDwPitch + pc] = pack_bf16(xv[i][0], xv[i][1]);
+#pragma unroll
+    for (int i = 0; i < NT * 4; ++i) ds[(r0 + 8 * i) * kDwPitch + pc] = pack_bf16(dv[i][0], dv[i][1]);
+    xc[wave * kDwKM + lane] = x0v;
+  };
+
+  f32x16 acc[HT][NT];
+#pragma unroll
+  for (int ht = 0; ht < HT; ++ht)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[ht][nt][i] = 0.f;
+
+  if (nch > 0) {
+    issue(ch0);
+    stash(0);
+  }
+  __syncthreads();
+  for (int ch = 0; ch < nch; ++ch) {
+    const bool more = ch + 1 < nch;
+    if (more) issue(ch0 + ch + 1);
+    const uint32_t* xs = lds + (ch & 1) * kBuf;
+    const uint32_t* ds = xs + kXs;
+    const float* xc = reinterpret_cast<const float*>(ds + kDs) + wave * kDwKM;
+#pragma unroll
+    for (int ks = 0; ks < kDwKM / 16; ++ks) {
+      const int col = 8 * ks + 4 * half;  // uint32 column of this lane's 8 m
+      const float4 m0 = *reinterpret_cast<const float4*>(xc + 16 * ks + 8 * half);
+      const float4 m1 = *reinterpret_cast<const float4*>(xc + 16 * ks + 8 * half + 4);
+      bf16x8 a[HT];
+#pragma unroll
+      for (int ht = 0; ht < HT; ++ht) {
+        const uint4 raw = *reinterpret_cast<const uint4*>(xs + (32 * ht + r) * kDwPitch + col);
+        uint4 z;
+        z.x = pack_bf16(__uint_as_float(raw.x << 16) * m0.x, __uint_as_float(raw.x & 0xffff0000u) * m0.y);
+        z.y = pack_bf16(__uint_as_float(raw.y << 16) * m0.z, __uint_as_float(raw.y & 0xffff0000u) * m0.w);
+        z.z = pack_bf16(__uint_as_float(raw.z << 16) * m1.x, __uint_as_float(raw.z & 0xffff0000u) * m1.y);
+        z.w = pack_bf16(__uint_as_float(raw.w << 16) * m1.z, __uint_as_float(raw.w & 0xffff0000u) * m1.w);
+        a[ht] = as_frag(z);
+      }
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const bf16x8 b = as_frag(*reinterpret_cast<const uint4*>(ds + (32 * nt + r) * kDwPitch + col));
+#pragma unroll
+        for (int ht = 0; ht < HT; ++ht) acc[ht][nt] = mfma(a[ht], b, acc[ht][nt]);
+      }
+    }
+    if (more) stash((ch + 1) & 1);
+    __syncthreads();
+  }
+  if (f < c.F) {
+    float* dst = part + ((size_t)split * (OGn * 4) + f) * (HT * 32) * (NT * 32);
+#pragma unroll
+    for (int ht = 0; ht < HT; ++ht)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+          dst[(size_t)(32 * ht + tile_row(i, half)) * (NT * 32) + 32 * nt + r] = acc[ht][nt][i];
+  }
+}
+
+__global__ void cin_bf16_dw_reduce_kernel(Dims c, const float* __restrict__ part, int S, int OGn, int Hp, int Lp,
+                                          float* __restrict__ d_w, int ldw) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)c.F * c.H * c.L) return;
+  const int n = (int)(idx % c.L);
+  const int64_t t = idx / c.L;
+  const int h = (int)(t % c.H), f = (int)(t / c.H);
+  if (c.masked && h <= f) return;
+  const size_t stride = (size_t)(OGn * 4) * Hp * Lp;
+  const float* src = part + ((size_t)f * Hp + h) * Lp + n;
+  float sum = 0.f;
+  for (int k = 0; k < S; ++k) sum += src[k * stride];  // split order: the same bits on every run
+  d_w[(int64_t)(f * c.H + h) * ldw + n] = c.masked ? 2.f * sum : sum;
+}
+
+// splits of the m range for the filter gradient: enough blocks for two rounds over the chip, at
+// least four staged chunks each
+void dw_geometry(int64_t cols, int F, int* S, int* OGn, int* chunks_per_split) {
+  const int64_t chunks = (cols + kDwKM - 1) / kDwKM;
+  *OGn = (F + 3) / 4;
+  int64_t s = chunks / 4;
+  if (s > 64) s = 64;
+  if (s >= 8) s &= ~(int64_t)7;
+  if (s < 1) s = 1;
+  *S = (int)s;
+  *chunks_per_split = (int)((chunks + s - 1) / s);
+}
+
+}  // namespace
+
+extern "C" int xdfm_cin_bf16_bwd_dw_workspace_floats(int64_t B, int32_t F, int32_t H, int32_t D, int32_t L,
+                                                     size_t* floats) {
+  XDFM_REQUIRE(floats && B >= 0 && F > 0 && H > 0 && D > 0 && L > 0, "xdfm_cin_bf16_bwd_dw_workspace_floats: bad argument");
+  XDFM_REQUIRE(H <= 128 && L <= 128, "xdfm_cin_bf16: at most 128 inputs per side and 128 channels per call (H=%d, L=%d)", H, L);
+  int S, OGn, cps;
+  dw_geometry(B * D, F, &S, &OGn, &cps);
+  const int HT = H <= 32 ? 1 : (H <= 64 ? 2 : 4), NT = L <= 32 ? 1 : (L <= 64 ? 2 : 4);
+  *floats = (size_t)S * OGn * 4 * HT * 32 * NT * 32;
+  return XDFM_OK;
+}
+
+extern "C" int xdfm_cin_bf16_bwd_dw(const float* x0, const float* xk, const float* d_xnext, int64_t B, int32_t F,
+                                    int32_t H, int32_t D, int32_t L, int32_t masked, float* d_w, int32_t ldw,
+                                    float* workspace, void* stream) {
+  XDFM_REQUIRE(H <= 128 && L <= 128, "xdfm_cin_bf16: at most 128 inputs per side and 128 channels per call (H=%d, L=%d)", H, L);
+  Dims c;
+  int rc = make_dims(B, F, H, D, L, masked, 8, &c);
+  if (rc) return rc;
+  XDFM_REQUIRE(d_w, "xdfm_cin_bf16_bwd_dw: null d_w");
+  if (ldw == 0) ldw = L;
+  int S, OGn, cps;
+  dw_geometry(c.cols, F, &S, &OGn, &cps);
+  const int HT = H <= 32 ? 1 : (H <= 64 ? 2 : 4), NT = L <= 32 ? 1 : (L <= 64 ? 2 : 4);
+  XDFM_REQUIRE(B == 0 || (x0 && xk && d_xnext && workspace), "xdfm_cin_bf16_bwd_dw: null argument");
+  if (B == 0) S = 0;
+  const size_t lds = (size_t)2 * ((HT + NT) * 32 * kDwPitch + 4 * kDwKM) * 4;
+  const dim3 grid((unsigned)(S * OGn));
+#define DW(HTV, NTV)                                                                                                 \
+  do {                                                                                                               \
+    if (lds > 64 * 1024)                                                                                             \
+      XDFM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(cin_bf16_dw_kernel<HTV, NTV>),                      \
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                           \
+    XDFM_LAUNCH("cin_bf16_dw_kernel<" #HTV ", " #NTV ">", stream, (cin_bf16_dw_kernel<HTV, NTV>), grid, dim3(256),   \
+                lds, c, x0, xk, d_xnext, workspace, S, OGn, cps);                                                    \
+  } while (0)
+#define DW_N(HTV)            \
+  do {                       \
+    if (NT == 1)             \
+      DW(HTV, 1);            \
+    else if (NT == 2)        \
+      DW(HTV, 2);            \
+    else                     \
+      DW(HTV, 4);            \
+  } while (0)
+  if (S > 0) {
+    if (HT == 1)
+      DW_N(1);
+    else if (HT == 2)
+      DW_N(2);
+    else
+      DW_N(4);
+  }
+#undef DW_N
+#undef DW
+  const int64_t total = (int64_t)F * H * L;
+  XDFM_LAUNCH("cin_bf16_dw_reduce_kernel", stream, cin_bf16_dw_reduce_kernel, dim3((unsigned)((total + 255) / 256)),
+              dim3(256), 0, c, workspace, S, OGn, HT * 32, NT * 32, d_w, ldw);
+  XDFM_LAUNCH_CHECK();
+  return XDFM_OK;
+}
