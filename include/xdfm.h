@@ -423,7 +423,7 @@ int xdfm_cin_pool_unpack(const float* dwp, int32_t F, int32_t H, int32_t L, int3
  *   xdfm_cin_bf16_bwd_dx: d_xk[B,H,D] written (NULL on the masked layer, where both roles are x0);
  *                         d_x0[B,F,D] written, or added to when accumulate_x0 != 0.
  *   xdfm_cin_bf16_bwd_dw: d_w[(f,h), 0..L) written with row stride ldw (masked layer: rows f < h,
- *                         times 2; other rows untouched); workspace of
+ *                         times 2, zero elsewhere); workspace of
  *                         xdfm_cin_bf16_bwd_dw_workspace_floats elements.
  * ---------------------------------------------------------------------- */
 int xdfm_cin_bf16_image_bytes(int32_t F, int32_t H, int32_t L, size_t* fwd_bytes, size_t* dx_bytes);
@@ -491,6 +491,19 @@ int xdfm_dense_bwd_workspace_floats(int64_t B, int32_t K, int32_t Nout, size_t* 
 int xdfm_dense_bwd(const float* x, const float* w, const float* y, const float* dy, int64_t B,
                    int32_t K, int32_t Nout, int32_t act, float* dx, int32_t accumulate_dx,
                    float* dw, float* db, float* part, void* stream);
+
+/* The same layer on the bf16 matrix cores (fp32 accumulation; x, w and the upstream gradient are
+ * rounded to bf16 on their way into the product: 2e-2 relative bar), for wide layers
+ * (BASELINE configs[4]: 2496 -> 1024 -> 512) and the pooled-channel products of the CIN.
+ * Arguments as xdfm_dense_fwd / xdfm_dense_bwd; workspace: float scratch of
+ * xdfm_dense_bf16_workspace_floats(...) elements (products with few output tiles are split along
+ * their reduction and summed in split order), may be NULL when that size is 0. */
+int xdfm_dense_bf16_workspace_floats(int64_t B, int32_t K, int32_t Nout, size_t* floats);
+int xdfm_dense_bf16_fwd(const float* x, const float* w, const float* b, int64_t B, int32_t K,
+                        int32_t Nout, int32_t act, float* y, float* workspace, void* stream);
+int xdfm_dense_bf16_bwd(const float* x, const float* w, const float* y, const float* dy, int64_t B,
+                        int32_t K, int32_t Nout, int32_t act, float* dx, int32_t accumulate_dx,
+                        float* dw, float* db, float* workspace, void* stream);
 
 /* Dropout of a DNN layer (user_dropout, base_model.py:324-337, :355-365): tf.nn.dropout on the
  * pre-activation, then the activation.  Run xdfm_dense_fwd with act = identity, then

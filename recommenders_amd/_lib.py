@@ -139,6 +139,9 @@ SIGNATURES = {
     "xdfm_softmax_bwd": [_P, _P, _I64, _I32, _I32, _P, _P],
     "xdfm_bn_bwd": [_P, _P, _P, _I64, _I32, _I32, _P, _P, _I32, _P, _P, _P, _P],
     "xdfm_dense_fwd": [_P, _P, _P, _I64, _I32, _I32, _I32, _P, _P],
+    "xdfm_dense_bf16_workspace_floats": [_I64, _I32, _I32, _PSZ],
+    "xdfm_dense_bf16_fwd": [_P, _P, _P, _I64, _I32, _I32, _I32, _P, _P, _P],
+    "xdfm_dense_bf16_bwd": [_P, _P, _P, _P, _I64, _I32, _I32, _I32, _P, _I32, _P, _P, _P, _P],
     "xdfm_dense_bwd_workspace_floats": [_I64, _I32, _I32, _PSZ],
     "xdfm_dense_bwd": [_P, _P, _P, _P, _I64, _I32, _I32, _I32, _P, _I32, _P, _P, _P, _P],
     "xdfm_cin_act_fwd": [_P, _I64, _I32, _I32, _I32, _I32, _P, _P, _I32, _I32, _P],

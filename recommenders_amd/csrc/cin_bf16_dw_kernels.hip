@@ -153,7 +153,10 @@ __global__ void cin_bf16_dw_reduce_kernel(Dims c, const float* __restrict__ part
   const int n = (int)(idx % c.L);
   const int64_t t = idx / c.L;
   const int h = (int)(t % c.H), f = (int)(t / c.H);
-  if (c.masked && h <= f) return;
+  if (c.masked && h <= f) {  // not part of the layer: its gradient is zero
+    d_w[(int64_t)(f * c.H + h) * ldw + n] = 0.f;
+    return;
+  }
   const size_t stride = (size_t)(OGn * 4) * Hp * Lp;
   const float* src = part + ((size_t)f * Hp + h) * Lp + n;
   float sum = 0.f;

@@ -1,0 +1,270 @@
+// Dense layer y = act(x W + b) and its backward on the bf16 matrix cores
+// (v_mfma_f32_32x32x16_bf16, fp32 accumulation) for the wide DNN tower of BASELINE configs[4]
+// (2496 -> 1024 -> 512) and the pooled-channel products of the CIN.  Reference:
+// xDeepFM.py:491-507 (xw_plus_b + activation).  Same arguments and results as xdfm_dense_fwd /
+// xdfm_dense_bwd up to the bf16 rounding of the operands (2e-2 relative bar).
+//
+// One kernel, three operand conventions (C[M,N] = sum_k A(m,k) B(k,n)):
+//   forward          A = x[m][k]                     B = w[k][n]        C = act(. + b[n]) -> y
+//   input gradient   A = dz[m][k] = dy * act'(y)     B = w[n][k]        C -> dx (written or added to)
+//   weight gradient  A = x[k][m], row K_in = ones    B = dz[k][n]       C -> dw, last row -> db
+// The operands are read as fp32 from where the fp32 path keeps them, dz is formed while staging (no
+// buffer of its own), and tiles are rounded to bf16 on their way into LDS.  Block tile 128 x 128,
+// k step 32, four waves of 64 x 64; the next tile's global loads fly during the current tile's
+// products.  Products whose output has too few tiles to fill the chip are split along k into a
+// workspace and summed in split order (bit-identical reruns).
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "act.h"
+#include "cin_bf16.h"
+#include "xdfm_common.h"
+
+using namespace xdfm_bf16;
+
+namespace {
+
+enum { kFwd = 0, kDx = 1, kDw = 2 };
+constexpr int kBM = 128, kBN = 128, kBK = 32;
+constexpr int kPitch = 20;  // uint32 per LDS row: 32 bf16 + 16 bytes
+
+struct GemmArgs {
+  const float* x;
+  const float* w;
+  const float* bias;
+  const float* y;
+  const float* dy;
+  float* out;   // y / dx / dw (or the split workspace)
+  float* out2;  // db
+  int64_t B;
+  int K, Nout, act, accumulate;
+  int M, N, R;          // the product's sizes: C[M,N], reduction length R
+  int splits, r_per_split;
+};
+
+template <int MODE>
+__device__ __forceinline__ float a_at(const GemmArgs& g, int m, int k) {
+  if (m >= g.M || k >= g.R) return 0.f;
+  if (MODE == kFwd) return g.x[(int64_t)m * g.K + k];
+  if (MODE == kDx) {
+    const int64_t i = (int64_t)m * g.Nout + k;
+    return g.dy[i] * act_grad(g.y[i], g.act);
+  }
+  return m < g.K ? g.x[(int64_t)k * g.K + m] : 1.f;
+}
+template <int MODE>
+__device__ __forceinline__ float b_at(const GemmArgs& g, int k, int n) {
+  if (n >= g.N || k >= g.R) return 0.f;
+  if (MODE == kFwd) return g.w[(int64_t)k * g.Nout + n];
+  if (MODE == kDx) return g.w[(int64_t)n * g.Nout + k];
+  const int64_t i = (int64_t)k * g.Nout + n;
+  return g.dy[i] * act_grad(g.y[i], g.act);
+}
+
+template <int MODE>
+__device__ __forceinline__ void emit(const GemmArgs& g, int m, int n, float v) {
+  if (m >= g.M || n >= g.N) return;
+  if (MODE == kFwd) {
+    g.out[(int64_t)m * g.Nout + n] = activate(v + g.bias[n], g.act);
+  } else if (MODE == kDx) {
+    float* dst = g.out + (int64_t)m * g.K + n;
+    *dst = g.accumulate ? *dst + v : v;
+  } else if (m < g.K) {
+    g.out[(int64_t)m * g.Nout + n] = v;
+  } else {
+    g.out2[n] = v;
+  }
+}
+
+// A_KFAST / B_KFAST: which index is contiguous in global memory decides which one consecutive
+// threads walk (coalescing); either way a thread packs pairs along k.
+template <int MODE>
+__global__ __launch_bounds__(256, 2) void dense_bf16_kernel(GemmArgs g, float* __restrict__ part) {
+  __shared__ __align__(16) uint32_t as[2][kBM * kPitch];
+  __shared__ __align__(16) uint32_t bs[2][kBN * kPitch];
+  constexpr bool A_KFAST = MODE != kDw, B_KFAST = MODE == kDx;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, r = lane & 31;
+  const int m0 = blockIdx.y * kBM, n0 = blockIdx.x * kBN;
+  const int split = blockIdx.z;
+  const int k_lo = split * g.r_per_split;
+  int k_hi = k_lo + g.r_per_split;
+  if (k_hi > g.R) k_hi = g.R;
+  const int steps = k_hi > k_lo ? (k_hi - k_lo + kBK - 1) / kBK : 0;
+  // the split's k range is cut off through R: rows past k_hi read as zero
+  GemmArgs gs = g;
+  gs.R = k_hi;
+
+  float av[8][2], bv[8][2];
+  auto issue = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int row = A_KFAST ? (tid >> 4) + 16 * i : (tid & 127);
+      const int kp = A_KFAST ? (tid & 15) : (tid >> 7) + 2 * i;
+      av[i][0] = a_at<MODE>(gs, m0 + row, k0 + 2 * kp);
+      av[i][1] = a_at<MODE>(gs, m0 + row, k0 + 2 * kp + 1);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int row = B_KFAST ? (tid >> 4) + 16 * i : (tid & 127);
+      const int kp = B_KFAST ? (tid & 15) : (tid >> 7) + 2 * i;
+      bv[i][0] = b_at<MODE>(gs, k0 + 2 * kp, n0 + row);
+      bv[i][1] = b_at<MODE>(gs, k0 + 2 * kp + 1, n0 + row);
+    }
+  };
+  auto stash = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int row = A_KFAST ? (tid >> 4) + 16 * i : (tid & 127);
+      const int kp = A_KFAST ? (tid & 15) : (tid >> 7) + 2 * i;
+      as[buf][row * kPitch + kp] = pack_bf16(av[i][0], av[i][1]);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int row = B_KFAST ? (tid >> 4) + 16 * i : (tid & 127);
+      const int kp = B_KFAST ? (tid & 15) : (tid >> 7) + 2 * i;
+      bs[buf][row * kPitch + kp] = pack_bf16(bv[i][0], bv[i][1]);
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+
+  if (steps > 0) {
+    issue(k_lo);
+    stash(0);
+  }
+  __syncthreads();
+  for (int s = 0; s < steps; ++s) {
+    const bool more = s + 1 < steps;
+    if (more) issue(k_lo + (s + 1) * kBK);
+    const uint32_t* A = as[s & 1];
+    const uint32_t* Bt = bs[s & 1];
+#pragma unroll
+    for (int ks = 0; ks < kBK / 16; ++ks) {
+      const int col = 8 * ks + 4 * half;
+      bf16x8 a[2], b[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) a[i] = as_frag(*reinterpret_cast<const uint4*>(A + (wm + 32 * i + r) * kPitch + col));
+#pragma unroll
+      for (int j = 0; j < 2; ++j) b[j] = as_frag(*reinterpret_cast<const uint4*>(Bt + (wn + 32 * j + r) * kPitch + col));
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = mfma(a[i], b[j], acc[i][j]);
+    }
+    if (more) stash((s + 1) & 1);
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int m = m0 + wm + 32 * i + tile_row(e, half), n = n0 + wn + 32 * j + r;
+        if (g.splits == 1)
+          emit<MODE>(g, m, n, acc[i][j][e]);
+        else if (m < g.M && n < g.N)
+          part[((int64_t)split * g.M + m) * g.N + n] = acc[i][j][e];
+      }
+}
+
+template <int MODE>
+__global__ void dense_bf16_reduce_kernel(GemmArgs g, const float* __restrict__ part) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)g.M * g.N) return;
+  float s = 0.f;
+  for (int k = 0; k < g.splits; ++k) s += part[(int64_t)k * g.M * g.N + idx];
+  emit<MODE>(g, (int)(idx / g.N), (int)(idx % g.N), s);
+}
+
+int splits_for(int M, int N, int R) {
+  const int64_t tiles = (int64_t)((M + kBM - 1) / kBM) * ((N + kBN - 1) / kBN);
+  if (tiles >= 192) return 1;
+  int64_t s = (384 + tiles - 1) / tiles;
+  const int64_t by_len = R / 256;
+  if (s > by_len) s = by_len;
+  if (s > 8) s = 8;
+  return (int)(s < 1 ? 1 : s);
+}
+
+template <int MODE>
+int launch(GemmArgs g, float* workspace, hipStream_t st) {
+  g.splits = splits_for(g.M, g.N, g.R);
+  g.r_per_split = ((g.R + g.splits - 1) / g.splits + kBK - 1) / kBK * kBK;
+  XDFM_REQUIRE(g.splits == 1 || workspace, "xdfm_dense_bf16: this product is split along k and needs the workspace");
+  const dim3 grid((unsigned)((g.N + kBN - 1) / kBN), (unsigned)((g.M + kBM - 1) / kBM), (unsigned)g.splits);
+  const char* name = MODE == kFwd ? "dense_bf16_kernel<fwd>" : (MODE == kDx ? "dense_bf16_kernel<dx>" : "dense_bf16_kernel<dw>");
+  XDFM_LAUNCH(name, st, dense_bf16_kernel<MODE>, grid, dim3(256), 0, g, workspace);
+  if (g.splits > 1) {
+    const int64_t total = (int64_t)g.M * g.N;
+    XDFM_LAUNCH("dense_bf16_reduce_kernel", st, dense_bf16_reduce_kernel<MODE>, dim3((unsigned)((total + 255) / 256)),
+                dim3(256), 0, g, workspace);
+  }
+  XDFM_LAUNCH_CHECK();
+  return XDFM_OK;
+}
+
+size_t ws_for(int M, int N, int R) {
+  const int s = splits_for(M, N, R);
+  return s > 1 ? (size_t)s * M * N : 0;
+}
+
+bool sizes_ok(int64_t B, int K, int Nout) {
+  return B >= 0 && B < ((int64_t)1 << 31) && K > 0 && Nout > 0 && (int64_t)K * Nout < ((int64_t)1 << 31) &&
+         B * (int64_t)(K > Nout ? K : Nout) < ((int64_t)1 << 40);
+}
+
+}  // namespace
+
+extern "C" int xdfm_dense_bf16_workspace_floats(int64_t B, int32_t K, int32_t Nout, size_t* floats) {
+  XDFM_REQUIRE(floats && sizes_ok(B, K, Nout), "xdfm_dense_bf16_workspace_floats: bad argument");
+  size_t a = ws_for((int)B, Nout, K), b = ws_for((int)B, K, Nout), c = ws_for(K + 1, Nout, (int)B);
+  *floats = a > b ? (a > c ? a : c) : (b > c ? b : c);
+  return XDFM_OK;
+}
+
+extern "C" int xdfm_dense_bf16_fwd(const float* x, const float* w, const float* b, int64_t B, int32_t K,
+                                   int32_t Nout, int32_t act, float* y, float* workspace, void* stream) {
+  XDFM_REQUIRE(x && w && b && y, "xdfm_dense_bf16_fwd: null argument");
+  XDFM_REQUIRE(sizes_ok(B, K, Nout), "xdfm_dense_bf16_fwd: bad sizes");
+  XDFM_REQUIRE(act >= XDFM_ACT_IDENTITY && act <= XDFM_ACT_ELU, "xdfm_dense_bf16_fwd: unknown activation %d", act);
+  if (B == 0) return XDFM_OK;
+  GemmArgs g{x, w, b, nullptr, nullptr, y, nullptr, B, K, Nout, act, 0, (int)B, Nout, K, 1, 0};
+  return launch<kFwd>(g, workspace, (hipStream_t)stream);
+}
+
+extern "C" int xdfm_dense_bf16_bwd(const float* x, const float* w, const float* y, const float* dy, int64_t B,
+                                   int32_t K, int32_t Nout, int32_t act, float* dx, int32_t accumulate_dx,
+                                   float* dw, float* db, float* workspace, void* stream) {
+  XDFM_REQUIRE(x && w && y && dy, "xdfm_dense_bf16_bwd: null argument");
+  XDFM_REQUIRE((dw && db) || (!dw && !db && dx), "xdfm_dense_bf16_bwd: dw and db come together; without them dx must be given");
+  XDFM_REQUIRE(sizes_ok(B, K, Nout), "xdfm_dense_bf16_bwd: bad sizes");
+  XDFM_REQUIRE(act >= XDFM_ACT_IDENTITY && act <= XDFM_ACT_ELU, "xdfm_dense_bf16_bwd: unknown activation %d", act);
+  hipStream_t st = (hipStream_t)stream;
+  if (B == 0) {
+    if (dw) {
+      XDFM_HIP(hipMemsetAsync(dw, 0, (size_t)K * Nout * sizeof(float), st));
+      XDFM_HIP(hipMemsetAsync(db, 0, (size_t)Nout * sizeof(float), st));
+    }
+    return XDFM_OK;
+  }
+  if (dw) {
+    GemmArgs g{x, w, nullptr, y, dy, dw, db, B, K, Nout, act, 0, K + 1, Nout, (int)B, 1, 0};
+    int rc = launch<kDw>(g, workspace, st);
+    if (rc) return rc;
+  }
+  if (dx) {
+    GemmArgs g{x, w, nullptr, y, dy, dx, nullptr, B, K, Nout, act, accumulate_dx, (int)B, K, Nout, 1, 0};
+    int rc = launch<kDx>(g, workspace, st);
+    if (rc) return rc;
+  }
+  return XDFM_OK;
+}

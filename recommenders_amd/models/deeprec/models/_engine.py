@@ -111,7 +111,8 @@ class DeviceBatch(object):
 
 
 class XDeepFMEngine(object):
-    def __init__(self, hp, device=None, seed=None, embedding_update="dense_exact", table_rows=None):
+    def __init__(self, hp, device=None, seed=None, embedding_update="dense_exact", table_rows=None,
+                 compute_dtype=None):
         if not torch.cuda.is_available():
             raise RuntimeError(
                 "recommenders_amd needs a ROCm GPU: the xDeepFM path runs in HIP kernels "
@@ -158,6 +159,23 @@ class XDeepFMEngine(object):
                     raise ValueError("this activations not defined {0}".format(hp.activation[k]))
         if not (hp.use_Linear_part or hp.use_FM_part or hp.use_CIN_part or hp.use_DNN_part):
             raise ValueError("xDeepFM needs at least one of the Linear/FM/CIN/DNN parts")
+        # compute_dtype "bf16": CIN and DNN products on the bf16 matrix cores (fp32 accumulation, fp32
+        # parameters, gradients and optimizer state) -- the wide shapes of BASELINE configs[4]
+        if compute_dtype is None:
+            compute_dtype = hp.values().get("compute_dtype", os.environ.get("XDFM_COMPUTE_DTYPE", "fp32"))
+        if compute_dtype not in ("fp32", "bf16"):
+            raise ValueError("compute_dtype must be fp32 or bf16")
+        self.bf16 = compute_dtype == "bf16"
+        if self.bf16:
+            if self.fast_d or self.cross_path or self.use_bn or self.use_dropout or any(
+                    _ACT[hp.activation[k]] == _SOFTMAX for k in range(len(hp.layer_sizes)) if hp.use_DNN_part):
+                raise ValueError("compute_dtype=bf16 serves the plain xDeepFM layers (no fast_CIN, cross_activation, "
+                                 "batch norm, dropout or softmax)")
+            if hp.use_CIN_part:
+                for (H, L, nh) in cin_shapes(hp):
+                    if H > 128 or nh > 128:
+                        raise ValueError("compute_dtype=bf16: at most 128 hidden channels per CIN layer "
+                                         "(cross_layer_sizes up to 256 with split_half)")
         if embedding_update not in ("dense_exact", "sparse_rows", "sparse_lazy"):
             raise ValueError("embedding_update must be dense_exact, sparse_rows or sparse_lazy")
         self.embedding_update = embedding_update
@@ -286,7 +304,9 @@ class XDeepFMEngine(object):
         self.split_dw = os.environ.get("XDFM_SPLIT_DW", "1") != "0"
         self._late_event = None
         self._fold_dx = False
-        self.overlap_dnn = self.overlap_dnn_wanted(hp)
+        self.overlap_dnn = self.overlap_dnn_wanted(hp) and not self.bf16
+        if self.bf16:
+            self.early_reg = False
         self.mean_count = 0  # set by the sharded engine: global batch size of the step
         self.init_parameters(seed)
 
@@ -463,6 +483,7 @@ class XDeepFMEngine(object):
         _lib.check(self.lib.xdfm_dense_bwd_workspace_floats(B, 1, 1, ctypes.byref(sz)))
         part_floats = sz.value
         pool_part_floats = 1
+        bf16_floats = 1
         self._split = {}
         if hp.use_CIN_part:
             shapes = cin_shapes(hp)
@@ -496,6 +517,29 @@ class XDeepFMEngine(object):
                 # then carry the nh hidden channels only.  Needs the packed path for that narrower
                 # layer (or no hidden channel at all: the last layer).
                 Lk = L
+                if self.bf16:
+                    # every layer: pooled channels through the pair sums and a bf16 product, hidden
+                    # channels through the bf16 layer kernels
+                    if L - nh > 0:
+                        npair = ctypes.c_int64()
+                        _lib.check(self.lib.xdfm_cin_pair_count(F, H, 1 if k == 0 else 0, ctypes.byref(npair)))
+                        P, Lp = int(npair.value), L - nh
+                        self._split[k] = (P, Lp)
+                        max_pairs = max(max_pairs, P)
+                        buf("S_%d" % k, B, P)
+                        buf("wp_%d" % k, P, Lp)
+                        buf("dwp_%d" % k, P, Lp)
+                        buf("pool_%d" % k, B, Lp)
+                        _lib.check(self.lib.xdfm_dense_bf16_workspace_floats(B, P, Lp, ctypes.byref(sz)))
+                        bf16_floats = max(bf16_floats, sz.value)
+                    if nh > 0:
+                        fb, db = ctypes.c_size_t(), ctypes.c_size_t()
+                        _lib.check(self.lib.xdfm_cin_bf16_image_bytes(F, H, nh, ctypes.byref(fb), ctypes.byref(db)))
+                        buf("bimg_f_%d" % k, fb.value, dtype=torch.uint8)
+                        buf("bimg_d_%d" % k, db.value, dtype=torch.uint8)
+                        _lib.check(self.lib.xdfm_cin_bf16_bwd_dw_workspace_floats(B, F, H, D, nh, ctypes.byref(sz)))
+                        bf16_floats = max(bf16_floats, sz.value)
+                    continue
                 if self.pool_split and self.prepack and not self.cross_path and L - nh > 0:
                     fsz, bsz = ctypes.c_size_t(), ctypes.c_size_t()
                     if nh > 0:
@@ -549,11 +593,16 @@ class XDeepFMEngine(object):
                     buf("drop_%d" % k, B, int(size))
                 _lib.check(self.lib.xdfm_dense_bwd_workspace_floats(B, last, int(size), ctypes.byref(sz)))
                 dnn_part_floats = max(dnn_part_floats, sz.value)
+                if self.bf16:
+                    _lib.check(self.lib.xdfm_dense_bf16_workspace_floats(B, last, int(size), ctypes.byref(sz)))
+                    bf16_floats = max(bf16_floats, sz.value)
                 last = int(size)
             buf("dnn_out", B)
             _lib.check(self.lib.xdfm_dense_bwd_workspace_floats(B, last, 1, ctypes.byref(sz)))
             dnn_part_floats = max(dnn_part_floats, sz.value)
         buf("part", max(part_floats, 1))
+        if self.bf16:
+            buf("bf16_ws", bf16_floats)
         # the DNN tower runs on its own stream beside the CIN: its partial sums get their own space
         # (the lin_b / CIN head weight gradients run there too)
         _lib.check(self.lib.xdfm_dense_bwd_workspace_floats(B, 1, 1, ctypes.byref(sz)))
@@ -755,6 +804,20 @@ class XDeepFMEngine(object):
                 # with a cross_activation the layer writes raw curr for all L channels; the
                 # activation kernel then produces the hidden / pooled split
                 out_h, out_nh = (ws["cur_%d" % k], L) if self.cross_path else (xnext, nh)
+                if self.bf16:
+                    masked = 1 if k == 0 else 0
+                    if nh > 0:
+                        _lib.check(lib.xdfm_cin_bf16_fwd(_ptr(x0), _ptr(xk), _ptr(ws["bimg_f_%d" % k]), B, F, H, D, nh,
+                                                         masked, _ptr(xnext), st))
+                    if k in self._split:
+                        P, Lp = self._split[k]
+                        _lib.check(lib.xdfm_cin_pair_sum(_ptr(x0), _ptr(xk), B, F, H, D, masked, _ptr(ws["S_%d" % k]), st))
+                        _lib.check(lib.xdfm_dense_bf16_fwd(_ptr(ws["S_%d" % k]), _ptr(ws["wp_%d" % k]), _ptr(ws["zeros"]),
+                                                           B, P, Lp, 0, _ptr(ws["pool_%d" % k]), _ptr(ws["bf16_ws"]), st))
+                        ws["pooled"][:B, off:off + Lp].copy_(ws["pool_%d" % k][:B])
+                    off += L - nh
+                    xk = xnext
+                    continue
                 if k in self._split:
                     P, Lp = self._split[k]
                     if nh > 0:
@@ -872,6 +935,18 @@ class XDeepFMEngine(object):
         """One launch packs the filter images of every CIN layer for this step."""
         ws = self.ws
         shapes = cin_shapes(self.hp)
+        if self.bf16:
+            for k, (H, L, nh) in enumerate(shapes):
+                masked = 1 if k == 0 else 0
+                if k in self._split:
+                    _lib.check(self.lib.xdfm_cin_pool_pack(_ptr(self.views["cin_f_%d" % k]), self.F, H, L, nh, masked,
+                                                           _ptr(ws["wp_%d" % k]), self._stream()))
+                if nh > 0:
+                    _lib.check(self.lib.xdfm_cin_bf16_pack(_ptr(self.views["cin_f_%d" % k]), self.F, H, nh, L, masked,
+                                                           _ptr(ws["bimg_f_%d" % k]),
+                                                           _ptr(ws["bimg_d_%d" % k]) if with_grad else None,
+                                                           self._stream()))
+            return
         jobs = (_lib.CinPackJob * len(shapes))()
         n = 0
         for k, (H, L, nh) in enumerate(shapes):
@@ -910,6 +985,13 @@ class XDeepFMEngine(object):
             soft = act == _SOFTMAX
             if soft:
                 act = 0
+            if self.bf16 and K >= 32 and int(size) >= 32:
+                _lib.check(
+                    lib.xdfm_dense_bf16_fwd(_ptr(x), _ptr(self.views["dnn_w_%d" % k]), _ptr(self.views["dnn_b_%d" % k]),
+                                            B, K, int(size), act, _ptr(ws["h_%d" % k]), _ptr(ws["bf16_ws"]), st)
+                )
+                x, K = ws["h_%d" % k], int(size)
+                continue
             _lib.check(
                 lib.xdfm_dense_fwd(_ptr(x), _ptr(self.views["dnn_w_%d" % k]),
                                    _ptr(self.views["dnn_b_%d" % k]), B, K, int(size),
@@ -998,6 +1080,14 @@ class XDeepFMEngine(object):
             if self.use_bn:
                 self._bn_bwd(ws["z_%d" % k], acts[k + 1], d_acts[k + 1], "dnn", k, B, sizes[k + 1], 1, act)
                 act = 0
+            if self.bf16 and sizes[k] >= 32 and sizes[k + 1] >= 32:
+                _lib.check(
+                    lib.xdfm_dense_bf16_bwd(_ptr(acts[k]), _ptr(self.views["dnn_w_%d" % k]), _ptr(acts[k + 1]),
+                                            _ptr(d_acts[k + 1]), B, sizes[k], sizes[k + 1], act, _ptr(dx), acc,
+                                            _ptr(gv["dnn_w_%d" % k]), _ptr(gv["dnn_b_%d" % k]),
+                                            _ptr(ws["bf16_ws"]), st)
+                )
+                continue
             _lib.check(
                 lib.xdfm_dense_bwd(_ptr(acts[k]), _ptr(self.views["dnn_w_%d" % k]), _ptr(acts[k + 1]),
                                    _ptr(d_acts[k + 1]), B, sizes[k], sizes[k + 1], act, _ptr(dx), acc,
@@ -1113,6 +1203,27 @@ class XDeepFMEngine(object):
                                               _ptr(gv["fcin_v_%d" % k]) if k > 0 else None,
                                               _ptr(ws["part"]), st)
                     )
+                    continue
+                if self.bf16:
+                    masked = 1 if k == 0 else 0
+                    if k in self._split:
+                        P, Lp = self._split[k]
+                        ws["pool_%d" % k][:B].copy_(ws["d_pooled"][:B, offs[k]:offs[k] + Lp])
+                        _lib.check(
+                            lib.xdfm_dense_bf16_bwd(_ptr(ws["S_%d" % k]), _ptr(ws["wp_%d" % k]), _ptr(ws["pool_%d" % k]),
+                                                    _ptr(ws["pool_%d" % k]), B, P, Lp, 0, _ptr(ws["dS"]), 0,
+                                                    _ptr(ws["dwp_%d" % k]), _ptr(ws["db_pool"]), _ptr(ws["bf16_ws"]), st)
+                        )
+                        _lib.check(lib.xdfm_cin_pool_unpack(_ptr(ws["dwp_%d" % k]), F, H, L, nh, masked,
+                                                            _ptr(gv["cin_f_%d" % k]), st))
+                    if nh > 0:
+                        _lib.check(lib.xdfm_cin_bf16_bwd_dx(_ptr(x0), _ptr(xk), _ptr(ws["bimg_d_%d" % k]), _ptr(d_xnext),
+                                                            B, F, H, D, nh, masked, _ptr(d_xk), _ptr(d_emb), 1, st))
+                        _lib.check(lib.xdfm_cin_bf16_bwd_dw(_ptr(x0), _ptr(xk), _ptr(d_xnext), B, F, H, D, nh, masked,
+                                                            _ptr(gv["cin_f_%d" % k]), L, _ptr(ws["bf16_ws"]), st))
+                    if k in self._split:
+                        _lib.check(lib.xdfm_cin_pair_bwd(_ptr(x0), _ptr(xk), _ptr(ws["dS"]), B, F, H, D, masked,
+                                                         _ptr(d_emb), 1, _ptr(d_xk), 1 if nh > 0 else 0, st))
                     continue
                 fold = self.overlap_dnn and self._fold_dx
                 first_writer = fold and k == len(shapes) - 1  # nothing has been put into d_emb yet

