@@ -64,6 +64,7 @@ def traffic_of(name):
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 F32_MATRIX_PEAK_TFLOPS = 157.3  # same guide: fp32 MFMA / vector peak
+BF16_MATRIX_PEAK_TFLOPS = 2500.0  # same guide: bf16 MFMA, dense
 
 
 def workload_hparams(args):
@@ -76,7 +77,7 @@ def workload_hparams(args):
         use_Linear_part=True, use_FM_part=True, use_CIN_part=True, use_DNN_part=True,
         init_method="tnormal", init_value=0.1, learning_rate=0.002, optimizer="adam",
         embed_l2=0.0, layer_l2=0.0, cross_l2=0.01, batch_size=args.batch, save_model=False,
-        embedding_update="sparse_rows")
+        embedding_update="sparse_rows", compute_dtype=args.dtype)
 
 
 def synth_batches(hp, n_batches, seed):
@@ -114,6 +115,27 @@ def kernel_models(hp, nnz, uniq):
 
     H = F
     n_layers = len(hp.cross_layer_sizes)
+    if hp.values().get("compute_dtype", "fp32") == "bf16":
+        # bf16 layer kernels carry the hidden channels; algorithmic flops = the reference's pairs
+        # (the masked layer's f < h only) x channels, per (sample, d) row
+        rows = B * D
+
+        def nks(K):
+            n = (K + 15) // 16
+            return 2 if n <= 2 else 3 if n <= 3 else 4 if n <= 4 else 6 if n <= 6 else 8
+
+        def tiles(K):
+            return 1 if K <= 32 else 2 if K <= 64 else 4
+
+        for k, L in enumerate(hp.cross_layer_sizes):
+            nh = L // 2 if k != n_layers - 1 else 0
+            pairs = F * (F - 1) // 2 if k == 0 else F * H
+            if nh:
+                add("cin_bf16_fwd_kernel<%d>" % nks(H), "mfma16", 2.0 * rows * pairs * nh)
+                add("cin_bf16_dx_kernel<%d>" % nks(nh), "mfma16", 2.0 * rows * pairs * nh)
+                add("cin_bf16_dw_kernel<%d, %d>" % (tiles(H), tiles(nh)), "mfma16", 2.0 * rows * pairs * nh)
+            H = nh
+        return m
     for k, L in enumerate(hp.cross_layer_sizes):
         masked = k == 0
         pairs = F * (F - 1) // 2 if masked else F * H  # masked pairs (f >= h) are never computed
@@ -186,6 +208,8 @@ def main():
     ap.add_argument("--workload", choices=["criteo", "wide"], default="criteo",
                     help="criteo = BASELINE configs[2] (the bench line); wide = configs[4]'s layer sizes "
                          "(dim 64, CIN [256,256,256], DNN [1024,512]) at --batch per GPU, a side measurement")
+    ap.add_argument("--dtype", choices=["fp32", "bf16"], default=None,
+                    help="arithmetic of the CIN / DNN products (default: fp32 for criteo, bf16 for wide)")
     ap.add_argument("--batches", type=int, default=64, help="distinct synthetic batches cycled through")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly in the timed region")
@@ -194,6 +218,8 @@ def main():
     ap.add_argument("--profile-steps", type=int, default=20,
                     help="eager steps after the timed region with per-kernel HIP events")
     args = ap.parse_args()
+    if args.dtype is None:
+        args.dtype = "bf16" if args.workload == "wide" else "fp32"
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -332,6 +358,8 @@ def main():
             work = sum(works) / len(works)
             if bound == "hbm":
                 return bound, work / avg_s / 1e9, HBM_PEAK_GBS, "GB/s", avg_s
+            if bound == "mfma16":
+                return "mfma", work / avg_s / 1e12, BF16_MATRIX_PEAK_TFLOPS, "TFLOP/s", avg_s
             return bound, work / avg_s / 1e12, F32_MATRIX_PEAK_TFLOPS, "TFLOP/s", avg_s
 
         roofline = None
@@ -356,12 +384,13 @@ def main():
             "metric": "train samples/sec, xDeepFM Criteo-shape", "value": round(world * hp.batch_size * args.steps / elapsed, 1),
             "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "bf16" if args.dtype == "bf16" else "f32", "data": "synthetic",
             "config": {"workload": ("BASELINE configs[2]: Criteo-shape synthetic, 39 fields, 2^25 rows, dim %d, "
                                     "batch %d per GPU, linear+FM+CIN[20,10]+DNN[20,20], sparse-row Adam"
                                     if args.workload == "criteo" else
-                                    "SIDE MEASUREMENT, layer sizes of BASELINE configs[4] in fp32: 39 fields, dim %d, "
-                                    "batch %d per GPU, CIN[256,256,256]+DNN[1024,512]") % (hp.dim, hp.batch_size),
+                                    "SIDE MEASUREMENT, one GPU's share of BASELINE configs[4] (" + args.dtype +
+                                    " products, fp32 accumulation): 39 fields, dim %d, batch %d per GPU, "
+                                    "CIN[256,256,256]+DNN[1024,512]") % (hp.dim, hp.batch_size),
                        "FEATURE_COUNT": hp.FEATURE_COUNT, "FIELD_COUNT": 39, "dim": hp.dim,
                        "global_batch": world * hp.batch_size,
                        "parallelism": "single GPU" if world == 1 else "table row-sharded x%d (all-to-all) + dense all-reduce%s" % (
@@ -375,7 +404,7 @@ def main():
             "kernels": kernels,
             "final_loss": round(final_loss, 5),
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.workload == "criteo":
             line["cpu_baseline"] = run_cpu_baseline(hp, host_batches)
         print(json.dumps(line))
     if dist is not None:

@@ -59,17 +59,36 @@ __global__ __launch_bounds__(256, 1) void cin_bf16_dw_kernel(Dims c, const float
     const int d0 = ok0 ? (int)(m - b0 * c.D) : 0;
     const int64_t b1 = (d0 + 1 < c.D) ? b0 : b0 + 1;
     const int d1 = (d0 + 1 < c.D) ? d0 + 1 : 0;
+    if ((c.D & 1) == 0 && ok1) {  // an even m and its neighbour lie in one row: 8-byte loads
 #pragma unroll
-    for (int i = 0; i < HT * 4; ++i) {
-      const int row = r0 + 8 * i;
-      xv[i][0] = (ok0 && row < c.H) ? xk[(b0 * c.H + row) * c.D + d0] : 0.f;
-      xv[i][1] = (ok1 && row < c.H) ? xk[(b1 * c.H + row) * c.D + d1] : 0.f;
-    }
+      for (int i = 0; i < HT * 4; ++i) {
+        const int row = r0 + 8 * i;
+        const float2 v = row < c.H ? *reinterpret_cast<const float2*>(xk + (b0 * c.H + row) * c.D + d0)
+                                   : make_float2(0.f, 0.f);
+        xv[i][0] = v.x;
+        xv[i][1] = v.y;
+      }
 #pragma unroll
-    for (int i = 0; i < NT * 4; ++i) {
-      const int row = r0 + 8 * i;
-      dv[i][0] = (ok0 && row < c.L) ? d_xnext[(b0 * c.L + row) * c.D + d0] : 0.f;
-      dv[i][1] = (ok1 && row < c.L) ? d_xnext[(b1 * c.L + row) * c.D + d1] : 0.f;
+      for (int i = 0; i < NT * 4; ++i) {
+        const int row = r0 + 8 * i;
+        const float2 v = row < c.L ? *reinterpret_cast<const float2*>(d_xnext + (b0 * c.L + row) * c.D + d0)
+                                   : make_float2(0.f, 0.f);
+        dv[i][0] = v.x;
+        dv[i][1] = v.y;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < HT * 4; ++i) {
+        const int row = r0 + 8 * i;
+        xv[i][0] = (ok0 && row < c.H) ? xk[(b0 * c.H + row) * c.D + d0] : 0.f;
+        xv[i][1] = (ok1 && row < c.H) ? xk[(b1 * c.H + row) * c.D + d1] : 0.f;
+      }
+#pragma unroll
+      for (int i = 0; i < NT * 4; ++i) {
+        const int row = r0 + 8 * i;
+        dv[i][0] = (ok0 && row < c.L) ? d_xnext[(b0 * c.L + row) * c.D + d0] : 0.f;
+        dv[i][1] = (ok1 && row < c.L) ? d_xnext[(b1 * c.L + row) * c.D + d1] : 0.f;
+      }
     }
     const int64_t mm = ch * kDwKM + lane;  // the block's four f: one factor per thread
     x0v = 0.f;

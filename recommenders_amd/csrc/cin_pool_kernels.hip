@@ -26,6 +26,13 @@ __host__ __device__ inline int n_pairs(int F, int H, int masked) { return masked
 // first pair index of row f in the strict upper triangle of an F x F matrix
 __host__ __device__ inline int tri_row_start(int f, int F) { return f * (2 * F - f - 1) / 2; }
 
+// LDS floats of a sample's dS row in the backward kernel: compact on the masked layer (triangle),
+// [Fp][Hp + 1] zero-padded otherwise (rows one bank apart: 16 lanes read 16 different f at one h;
+// no bounds to test in the product loop)
+__host__ __device__ inline int g_floats(int F, int H, int masked) {
+  return ((masked ? n_pairs(F, H, 1) : ((F + 15) & ~15) * (((H + 15) & ~15) + 1)) + 3) & ~3;
+}
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 struct PairDims {
@@ -45,6 +52,45 @@ __device__ __forceinline__ void stage_rows(const float* __restrict__ src, int64_
   const int tile = Rp * Dp, total = ns * tile;
   const float inv_tile = 1.0f / (float)tile, inv_dp = 1.0f / (float)Dp;
   constexpr int U = 8;
+  if ((D & 3) == 0 && (sample_stride & 3) == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0) {
+    // rows of whole float4s: 16-byte loads, eight in flight; the padding is cleared first
+    for (int i = threadIdx.x; i < total; i += blockDim.x) {
+      int s = (int)((float)i * inv_tile);
+      s += ((s + 1) * tile <= i) - (s * tile > i);
+      const int j = i - s * tile;
+      int r = (int)((float)j * inv_dp);
+      r += ((r + 1) * Dp <= j) - (r * Dp > j);
+      if (r >= R || j - r * Dp >= D) dst[s * per + j] = 0.f;
+    }
+    const int q = D >> 2, per_s = R * q, n4 = ns * per_s;
+    const float inv_ps = 1.0f / (float)per_s, inv_q = 1.0f / (float)q;
+    for (int i0 = threadIdx.x; i0 < n4; i0 += blockDim.x * U) {
+      float4 v[U];
+      int at[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int i = i0 + u * blockDim.x;
+        int s = (int)((float)i * inv_ps);
+        s += ((s + 1) * per_s <= i) - (s * per_s > i);
+        const int j = i - s * per_s;
+        int r = (int)((float)j * inv_q);
+        r += ((r + 1) * q <= j) - (r * q > j);
+        const int d4 = j - r * q;
+        at[u] = i < n4 ? s * per + r * Dp + 4 * d4 : -1;
+        v[u] = i < n4 ? *reinterpret_cast<const float4*>(src + s * sample_stride + r * D + 4 * d4)
+                      : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (at[u] >= 0) {
+          dst[at[u]] = v[u].x;
+          dst[at[u] + 1] = v[u].y;
+          dst[at[u] + 2] = v[u].z;
+          dst[at[u] + 3] = v[u].w;
+        }
+    }
+    return;
+  }
   for (int i0 = threadIdx.x; i0 < total; i0 += blockDim.x * U) {
     float v[U];
     int at[U];
@@ -84,12 +130,16 @@ __global__ __launch_bounds__(256) void cin_pair_sum_kernel(PairDims c, const flo
   const int li = lane & 15, lk = lane >> 4;
   const int nft = c.Fp >> 4, nht = c.Hp >> 4, nks = (c.D + 3) >> 2;
   const int P = n_pairs(c.F, c.H, c.masked);
-  for (int s = wave; s < ns; s += 4) {
+  // (sample, f tile, h tile) items dealt to the block's waves in turn
+  for (int it = wave; it < ns * nft * nht; it += 4) {
+    const int s = it / (nft * nht), t = it - s * (nft * nht);
+    const int ft = t / nht, ht = t - ft * nht;
+    if (c.masked && ht < ft) continue;
     const float* a = lds + s * per;
     const float* bq = c.shared_x ? a : a + per_a;
     float* out = S + (b0 + s) * P;
-    for (int ft = 0; ft < nft; ++ft) {
-      for (int ht = c.masked ? ft : 0; ht < nht; ++ht) {
+    {
+      {
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         const float* ap = a + (16 * ft + li) * c.Dp + lk;
         const float* bp = bq + (16 * ht + li) * c.Dp + lk;
@@ -113,7 +163,7 @@ __global__ __launch_bounds__(256) void cin_pair_sum_kernel(PairDims c, const flo
 // sample's compact dS row in LDS.  x0_mode / xk_mode: 0 = write, 1 = add.
 __device__ __forceinline__ float g_at(const float* __restrict__ g, const PairDims& c, int f, int h) {
   if (f >= c.F || h >= c.H) return 0.f;
-  if (!c.masked) return g[f * c.H + h];
+  if (!c.masked) return g[f * (c.Hp + 1) + h];
   if (f == h) return 0.f;
   const int lo = f < h ? f : h, hi = f < h ? h : f;
   return g[tri_row_start(lo, c.F) + hi - lo - 1];
@@ -126,58 +176,96 @@ __global__ __launch_bounds__(256) void cin_pair_bwd_kernel(PairDims c, const flo
   extern __shared__ float lds[];
   const int per_a = c.Fp * c.Dp, per_b = c.shared_x ? 0 : c.Hp * c.Dp;
   const int P = n_pairs(c.F, c.H, c.masked);
-  const int Pp = (P + 3) & ~3;
+  const int Pp = g_floats(c.F, c.H, c.masked);
   const int per = per_a + per_b + 16 + Pp;
   const int64_t b0 = (int64_t)blockIdx.x * c.NS;
   const int ns = (int)(c.B - b0 < c.NS ? c.B - b0 : c.NS);
   stage_rows(x0 + b0 * c.F * c.D, (int64_t)c.F * c.D, ns, c.F, c.Fp, c.D, c.Dp, lds, per);
   if (!c.shared_x) stage_rows(xk + b0 * c.H * c.D, (int64_t)c.H * c.D, ns, c.H, c.Hp, c.D, c.Dp, lds + per_a, per);
-  stage_rows(dS + b0 * P, (int64_t)P, ns, 1, 1, P, Pp, lds + per_a + per_b + 16, per);
+  if (c.masked)
+    stage_rows(dS + b0 * P, (int64_t)P, ns, 1, 1, P, Pp, lds + per_a + per_b + 16, per);
+  else
+    stage_rows(dS + b0 * P, (int64_t)P, ns, c.F, c.Fp, c.H, c.Hp + 1, lds + per_a + per_b + 16, per);
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int li = lane & 15, lk = lane >> 4;
   const int nft = c.Fp >> 4, nht = c.Hp >> 4, ndt = (c.D + 15) >> 4;
-  for (int s = wave; s < ns; s += 4) {
+  // (sample, output tile) items dealt to the block's waves in turn: first the d_x0 = G * xk tiles
+  // (f tile x d tile), then the d_xk = G^T * x0 tiles (h tile x d tile)
+  const int n0 = nft * ndt, n1 = c.shared_x ? 0 : nht * ndt;
+  for (int it = wave; it < ns * (n0 + n1); it += 4) {
+    const int s = it / (n0 + n1), t = it - s * (n0 + n1);
     const float* a = lds + s * per;
     const float* bq = c.shared_x ? a : a + per_a;
     const float* g = a + per_a + per_b + 16;
-    // d_x0 = G * xk
-    for (int ft = 0; ft < nft; ++ft)
-      for (int dt = 0; dt < ndt; ++dt) {
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        const float* xp = bq + lk * c.Dp + 16 * dt + li;
-        for (int ks = 0; ks < (c.Hp >> 2); ++ks)
-          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(g_at(g, c, 16 * ft + li, 4 * ks + lk), xp[4 * ks * c.Dp], acc, 0,
-                                                     0, 0);
-        const int d = 16 * dt + li;
+    if (t < n0) {
+      const int ft = t / ndt, dt = t - ft * ndt;
+      const int d = 16 * dt + li;
+      // the values to add to are requested before the products, not after them
+      float old[4] = {0.f, 0.f, 0.f, 0.f};
+      if (x0_mode) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int f = 16 * ft + 4 * lk + r;
-          if (f < c.F && d < c.D) {
-            float* dst = d_x0 + ((b0 + s) * c.F + f) * c.D + d;
-            *dst = x0_mode ? *dst + acc[r] : acc[r];
-          }
+          if (f < c.F && d < c.D) old[r] = d_x0[((b0 + s) * c.F + f) * c.D + d];
         }
       }
-    if (c.shared_x) continue;
-    // d_xk = G^T * x0
-    for (int ht = 0; ht < nht; ++ht)
-      for (int dt = 0; dt < ndt; ++dt) {
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        const float* xp = a + lk * c.Dp + 16 * dt + li;
-        for (int ks = 0; ks < (c.Fp >> 2); ++ks)
-          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(g_at(g, c, 4 * ks + lk, 16 * ht + li), xp[4 * ks * c.Dp], acc, 0,
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      const float* xp = bq + lk * c.Dp + 16 * dt + li;
+      if (!c.masked) {
+        // zero-padded [Fp][Hp + 1] image: plain strided reads, two independent chains (Hp / 4 is even)
+        const int Gp = c.Hp + 1;
+        const float* gp = g + (16 * ft + li) * Gp + lk;
+        f32x4 acc1 = {0.f, 0.f, 0.f, 0.f};
+        for (int ks = 0; ks < (c.Hp >> 2); ks += 2) {
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(gp[4 * ks], xp[4 * ks * c.Dp], acc, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(gp[4 * ks + 4], xp[(4 * ks + 4) * c.Dp], acc1, 0, 0, 0);
+        }
+        acc += acc1;
+      } else {
+        for (int ks = 0; ks < (c.Hp >> 2); ++ks)
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(g_at(g, c, 16 * ft + li, 4 * ks + lk), xp[4 * ks * c.Dp], acc, 0,
                                                      0, 0);
-        const int d = 16 * dt + li;
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int f = 16 * ft + 4 * lk + r;
+        if (f < c.F && d < c.D) d_x0[((b0 + s) * c.F + f) * c.D + d] = old[r] + acc[r];
+      }
+    } else {
+      const int u = t - n0;
+      const int ht = u / ndt, dt = u - ht * ndt;
+      const int d = 16 * dt + li;
+      float old[4] = {0.f, 0.f, 0.f, 0.f};
+      if (xk_mode) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int h = 16 * ht + 4 * lk + r;
-          if (h < c.H && d < c.D) {
-            float* dst = d_xk + ((b0 + s) * c.H + h) * c.D + d;
-            *dst = xk_mode ? *dst + acc[r] : acc[r];
-          }
+          if (h < c.H && d < c.D) old[r] = d_xk[((b0 + s) * c.H + h) * c.D + d];
         }
       }
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      const float* xp = a + lk * c.Dp + 16 * dt + li;
+      if (!c.masked) {
+        const int Gp = c.Hp + 1;
+        const float* gp = g + lk * Gp + 16 * ht + li;
+        f32x4 acc1 = {0.f, 0.f, 0.f, 0.f};
+        for (int ks = 0; ks < (c.Fp >> 2); ks += 2) {  // Fp / 4 is even as well
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(gp[4 * ks * Gp], xp[4 * ks * c.Dp], acc, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(gp[(4 * ks + 4) * Gp], xp[(4 * ks + 4) * c.Dp], acc1, 0, 0, 0);
+        }
+        acc += acc1;
+      } else {
+        for (int ks = 0; ks < (c.Fp >> 2); ++ks)
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(g_at(g, c, 4 * ks + lk, 16 * ht + li), xp[4 * ks * c.Dp], acc, 0,
+                                                     0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int h = 16 * ht + 4 * lk + r;
+        if (h < c.H && d < c.D) d_xk[((b0 + s) * c.H + h) * c.D + d] = old[r] + acc[r];
+      }
+    }
   }
 }
 
@@ -223,7 +311,7 @@ PairDims pair_dims(int64_t B, int F, int H, int D, int masked, bool shared_x, bo
   c.Dp = ((D + 3) & ~3) + 1;
   c.shared_x = shared_x ? 1 : 0;
   size_t per = (size_t)c.Fp * c.Dp + (shared_x ? 0 : (size_t)c.Hp * c.Dp) + 16;
-  if (bwd) per += ((size_t)n_pairs(F, H, masked) + 3) & ~(size_t)3;
+  if (bwd) per += (size_t)g_floats(F, H, masked);
   // one wave per sample; fewer samples per block when four do not fit 64 KB
   c.NS = 4;
   while (c.NS > 1 && per * c.NS * sizeof(float) > 64 * 1024) c.NS >>= 1;

@@ -49,7 +49,7 @@ __device__ __forceinline__ float a_at(const GemmArgs& g, int m, int k) {
   if (MODE == kFwd) return g.x[(int64_t)m * g.K + k];
   if (MODE == kDx) {
     const int64_t i = (int64_t)m * g.Nout + k;
-    return g.dy[i] * act_grad(g.y[i], g.act);
+    return g.act == XDFM_ACT_IDENTITY ? g.dy[i] : g.dy[i] * act_grad(g.y[i], g.act);
   }
   return m < g.K ? g.x[(int64_t)k * g.K + m] : 1.f;
 }
@@ -59,7 +59,7 @@ __device__ __forceinline__ float b_at(const GemmArgs& g, int k, int n) {
   if (MODE == kFwd) return g.w[(int64_t)k * g.Nout + n];
   if (MODE == kDx) return g.w[(int64_t)n * g.Nout + k];
   const int64_t i = (int64_t)k * g.Nout + n;
-  return g.dy[i] * act_grad(g.y[i], g.act);
+  return g.act == XDFM_ACT_IDENTITY ? g.dy[i] : g.dy[i] * act_grad(g.y[i], g.act);
 }
 
 template <int MODE>
