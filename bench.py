@@ -77,7 +77,7 @@ def workload_hparams(args):
         use_Linear_part=True, use_FM_part=True, use_CIN_part=True, use_DNN_part=True,
         init_method="tnormal", init_value=0.1, learning_rate=0.002, optimizer="adam",
         embed_l2=0.0, layer_l2=0.0, cross_l2=0.01, batch_size=args.batch, save_model=False,
-        embedding_update="sparse_rows", compute_dtype=args.dtype)
+        embedding_update="sparse_rows", compute_dtype=getattr(args, "dtype", None) or "fp32")
 
 
 def synth_batches(hp, n_batches, seed):

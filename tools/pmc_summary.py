@@ -55,6 +55,10 @@ def main():
             out.append("hbm_read_MB=%.2f" % (c["FETCH_SIZE"] * 1024 * 2 / 1e6))
         if "WRITE_SIZE" in c:
             out.append("hbm_write_MB=%.2f" % (c["WRITE_SIZE"] * 1024 / 1e6))
+        if "SQ_VALU_MFMA_BUSY_CYCLES" in c and c.get("GRBM_GUI_ACTIVE"):
+            # GRBM_GUI_ACTIVE is summed over the 8 XCDs, SQ_VALU_MFMA_BUSY_CYCLES over the 1024 SIMDs
+            # (32 cycles per v_mfma_f32_32x32x16_bf16): share of SIMD cycles with the matrix core busy
+            out.append("mfma_busy_pct=%.1f" % (100.0 * c["SQ_VALU_MFMA_BUSY_CYCLES"] / (c["GRBM_GUI_ACTIVE"] / 8 * 1024)))
         for n_, v in sorted(c.items()):
             if n_ not in ("FETCH_SIZE", "WRITE_SIZE"):
                 out.append("%s=%.4g" % (n_, v))
