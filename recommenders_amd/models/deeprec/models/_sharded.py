@@ -253,7 +253,7 @@ class ShardedXDeepFMEngine(XDeepFMEngine):
     rank's part of the global batch; all ranks must call it with equally sized batches."""
 
     def __init__(self, hp, device=None, seed=None, group=None, virtual_world=1, embedding_update="sparse_rows",
-                 force_collectives=False):
+                 force_collectives=False, compute_dtype=None):
         self.exchange = RowShardExchange(group, virtual_world=virtual_world, force_collectives=force_collectives)
         self.world, self.rank = self.exchange.world, self.exchange.rank
         if hp.loss == "square_loss":
@@ -265,7 +265,8 @@ class ShardedXDeepFMEngine(XDeepFMEngine):
         self.global_rows = int(hp.FEATURE_COUNT)
         rows = local_rows(self.global_rows, self.rank, self.world)
         XDeepFMEngine.__init__(self, hp, device=device, seed=None if seed is None else seed + 7919 * self.rank,
-                               embedding_update=embedding_update, table_rows=max(rows, 1))
+                               embedding_update=embedding_update, table_rows=max(rows, 1),
+                               compute_dtype=compute_dtype)
         if self.world > 1:
             self.exchange.broadcast(self.dense, 0)  # replicated parameters start identical
         self.dropout_seed ^= (0x632BE59BD9B4E019 * self.rank) & (2 ** 64 - 1)  # ranks draw different masks
