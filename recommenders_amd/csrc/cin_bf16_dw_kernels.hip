@@ -17,32 +17,31 @@ namespace {
 // the matrix product.  A block = 4 waves = 4 consecutive f over one split of the m range; a wave
 // keeps the whole [h][n] tile of its f in accumulators (HT x NT tiles of 32 x 32).  Per 64 m the
 // block stages xk[h][m] and dcurr[n][m] as bf16 in LDS (shared by its waves, loaded one chunk ahead
-// into registers); a wave forms its A operand x0[f,m] * xk[h,m] from the LDS fragment and its own
-// f's factors (fp32 product, rounded to bf16 once), B = dcurr.  Partial tiles per split go to the
+// into registers; xk stays fp32 there); a wave forms its A operand x0[f,m] * xk[h,m] from the LDS
+// fragment and its own f's factors (packed fp32 products, rounded to bf16 once), B = dcurr.  Partial tiles per split go to the
 // workspace and are added in split order by cin_bf16_dw_reduce_kernel.
 constexpr int kDwKM = 64;     // m per staged chunk (4 k steps)
-constexpr int kDwPitch = 36;  // uint32 per LDS row: 64 bf16 + 16 bytes, so 32 rows spread over all banks
+constexpr int kDwPitch = 36;  // uint32 per LDS row of dcurr: 64 bf16 + 16 bytes, so 32 rows spread over all banks
+constexpr int kDwXPitch = 68; // floats per LDS row of xk (kept fp32: the product with x0 needs no unpacking)
 
-template <int HT, int NT>
+// FAST: D even and B*D a multiple of 64 -- every staged m exists, so the staging is plain 8-byte loads
+// at a per-chunk base + per-thread row offsets computed once (the general form spends more
+// instructions on masks and addresses than on everything else together).
+template <int HT, int NT, bool FAST>
 __global__ __launch_bounds__(256, 1) void cin_bf16_dw_kernel(Dims c, const float* __restrict__ x0,
                                                               const float* __restrict__ xk,
                                                               const float* __restrict__ d_xnext,
                                                               float* __restrict__ part, int S, int OGn,
                                                               int chunks_per_split) {
   extern __shared__ __align__(16) unsigned char smem[];
-  constexpr int kXs = HT * 32 * kDwPitch, kDs = NT * 32 * kDwPitch, kBuf = kXs + kDs + 4 * kDwKM;  // uint32 units
+  constexpr int kXs = HT * 32 * kDwXPitch, kDs = NT * 32 * kDwPitch, kBuf = kXs + kDs + 4 * kDwKM;  // 4-byte units
   uint32_t* lds = reinterpret_cast<uint32_t*>(smem);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, r = lane & 31;
   // blocks of one split sit on one XCD (block id modulo 8) and share its L2 for the streamed inputs
-  int split, og;
-  if ((S & 7) == 0) {
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    split = xcd + 8 * (slot / OGn);
-    og = slot % OGn;
-  } else {
-    split = blockIdx.x / OGn;
-    og = blockIdx.x % OGn;
-  }
+  // (the grid holds 8 * ceil(S / 8) * OGn blocks; those whose split does not exist leave at once)
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int split = xcd + 8 * (slot / OGn), og = slot % OGn;
+  if (split >= S) return;
   const int f = og * 4 + wave;
   const int64_t total_chunks = (c.cols + kDwKM - 1) / kDwKM;
   const int64_t ch0 = (int64_t)split * chunks_per_split;
@@ -52,7 +51,49 @@ __global__ __launch_bounds__(256, 1) void cin_bf16_dw_kernel(Dims c, const float
   // staging: a thread owns one pair of m (columns 2*pc, 2*pc+1) of rows r0 + 8i
   const int pc = tid & 31, r0 = tid >> 5;
   float xv[HT * 4][2], dv[NT * 4][2], x0v;
+  bool livef = false;
+  // Loads without branches: rows past the end are clamped to the last row and zeroed by a select,
+  // addresses are one 32-bit multiply and one 64-bit add away from the chunk's base pointer.
+  // FAST: offsets of this thread's rows from a sample's base (rows past the end read the last row and
+  // are zeroed when stored), computed once
+  int offx[HT * 4], offd[NT * 4];
+  uint32_t keepx = 0, keepd = 0;
+#pragma unroll
+  for (int i = 0; i < HT * 4; ++i) {
+    const int row = r0 + 8 * i;
+    offx[i] = (row < c.H ? row : c.H - 1) * c.D;
+    keepx |= (row < c.H ? 1u : 0u) << i;
+  }
+#pragma unroll
+  for (int i = 0; i < NT * 4; ++i) {
+    const int row = r0 + 8 * i;
+    offd[i] = (row < c.L ? row : c.L - 1) * c.D;
+    keepd |= (row < c.L ? 1u : 0u) << i;
+  }
   auto issue = [&](int64_t ch) {
+    if (FAST) {
+      const uint32_t m = (uint32_t)(ch * kDwKM) + 2 * pc;  // host checked: B*D < 2^31
+      const uint32_t b0 = m / (uint32_t)c.D, d0 = m - b0 * (uint32_t)c.D;
+      const float* px = xk + (int64_t)b0 * c.H * c.D + d0;
+      const float* pd = d_xnext + (int64_t)b0 * c.L * c.D + d0;
+#pragma unroll
+      for (int i = 0; i < HT * 4; ++i) {
+        const float2 v = *reinterpret_cast<const float2*>(px + offx[i]);
+        xv[i][0] = v.x;
+        xv[i][1] = v.y;
+      }
+#pragma unroll
+      for (int i = 0; i < NT * 4; ++i) {
+        const float2 v = *reinterpret_cast<const float2*>(pd + offd[i]);
+        dv[i][0] = v.x;
+        dv[i][1] = v.y;
+      }
+      const uint32_t mm = (uint32_t)(ch * kDwKM) + lane;
+      const uint32_t bb = mm / (uint32_t)c.D;
+      x0v = x0[((int64_t)bb * c.F + (f < c.F ? f : 0)) * c.D + (mm - bb * (uint32_t)c.D)];
+      livef = f < c.F;
+      return;
+    }
     const int64_t m = ch * kDwKM + 2 * pc;
     const bool ok0 = m < c.cols, ok1 = m + 1 < c.cols;
     const int64_t b0 = ok0 ? m / c.D : 0;
@@ -101,8 +142,25 @@ __global__ __launch_bounds__(256, 1) void cin_bf16_dw_kernel(Dims c, const float
     uint32_t* xs = lds + buf * kBuf;
     uint32_t* ds = xs + kXs;
     float* xc = reinterpret_cast<float*>(ds + kDs);
+    if (FAST) {
 #pragma unroll
-    for (int i = 0; i < HT * 4; ++i) xs[(r0 + 8 * i) * kDwPitch + pc] = pack_bf16(xv[i][0], xv[i][1]);
+      for (int i = 0; i < HT * 4; ++i) {
+        const bool in = (keepx >> i) & 1;
+        *reinterpret_cast<float2*>(reinterpret_cast<float*>(xs) + (r0 + 8 * i) * kDwXPitch + 2 * pc) =
+            make_float2(in ? xv[i][0] : 0.f, in ? xv[i][1] : 0.f);
+      }
+#pragma unroll
+      for (int i = 0; i < NT * 4; ++i) {
+        const bool in = (keepd >> i) & 1;
+        ds[(r0 + 8 * i) * kDwPitch + pc] = pack_bf16(in ? dv[i][0] : 0.f, in ? dv[i][1] : 0.f);
+      }
+      xc[wave * kDwKM + lane] = livef ? x0v : 0.f;
+      return;
+    }
+#pragma unroll
+    for (int i = 0; i < HT * 4; ++i)
+      *reinterpret_cast<float2*>(reinterpret_cast<float*>(xs) + (r0 + 8 * i) * kDwXPitch + 2 * pc) =
+          make_float2(xv[i][0], xv[i][1]);
 #pragma unroll
     for (int i = 0; i < NT * 4; ++i) ds[(r0 + 8 * i) * kDwPitch + pc] = pack_bf16(dv[i][0], dv[i][1]);
     xc[wave * kDwKM + lane] = x0v;
@@ -129,18 +187,21 @@ __global__ __launch_bounds__(256, 1) void cin_bf16_dw_kernel(Dims c, const float
     const float* xc = reinterpret_cast<const float*>(ds + kDs) + wave * kDwKM;
 #pragma unroll
     for (int ks = 0; ks < kDwKM / 16; ++ks) {
-      const int col = 8 * ks + 4 * half;  // uint32 column of this lane's 8 m
-      const float4 m0 = *reinterpret_cast<const float4*>(xc + 16 * ks + 8 * half);
-      const float4 m1 = *reinterpret_cast<const float4*>(xc + 16 * ks + 8 * half + 4);
+      const int col = 8 * ks + 4 * half;  // uint32 column of this lane's 8 m in the bf16 image
+      typedef float f32x4v __attribute__((ext_vector_type(4)));
+      const f32x4v m0 = *reinterpret_cast<const f32x4v*>(xc + 16 * ks + 8 * half);
+      const f32x4v m1 = *reinterpret_cast<const f32x4v*>(xc + 16 * ks + 8 * half + 4);
       bf16x8 a[HT];
 #pragma unroll
       for (int ht = 0; ht < HT; ++ht) {
-        const uint4 raw = *reinterpret_cast<const uint4*>(xs + (32 * ht + r) * kDwPitch + col);
+        const float* xr = reinterpret_cast<const float*>(xs) + (32 * ht + r) * kDwXPitch + 16 * ks + 8 * half;
+        const f32x4v p0 = *reinterpret_cast<const f32x4v*>(xr) * m0;  // packed fp32 multiplies
+        const f32x4v p1 = *reinterpret_cast<const f32x4v*>(xr + 4) * m1;
         uint4 z;
-        z.x = pack_bf16(__uint_as_float(raw.x << 16) * m0.x, __uint_as_float(raw.x & 0xffff0000u) * m0.y);
-        z.y = pack_bf16(__uint_as_float(raw.y << 16) * m0.z, __uint_as_float(raw.y & 0xffff0000u) * m0.w);
-        z.z = pack_bf16(__uint_as_float(raw.z << 16) * m1.x, __uint_as_float(raw.z & 0xffff0000u) * m1.y);
-        z.w = pack_bf16(__uint_as_float(raw.w << 16) * m1.z, __uint_as_float(raw.w & 0xffff0000u) * m1.w);
+        z.x = pack_bf16(p0.x, p0.y);
+        z.y = pack_bf16(p0.z, p0.w);
+        z.z = pack_bf16(p1.x, p1.y);
+        z.w = pack_bf16(p1.z, p1.w);
         a[ht] = as_frag(z);
       }
 #pragma unroll
@@ -183,14 +244,14 @@ __global__ void cin_bf16_dw_reduce_kernel(Dims c, const float* __restrict__ part
   d_w[(int64_t)(f * c.H + h) * ldw + n] = c.masked ? 2.f * sum : sum;
 }
 
-// splits of the m range for the filter gradient: enough blocks for two rounds over the chip, at
-// least four staged chunks each
+// splits of the m range for the filter gradient: at least four staged chunks each
 void dw_geometry(int64_t cols, int F, int* S, int* OGn, int* chunks_per_split) {
   const int64_t chunks = (cols + kDwKM - 1) / kDwKM;
   *OGn = (F + 3) / 4;
-  int64_t s = chunks / 4;
-  if (s > 64) s = 64;
-  if (s >= 8) s &= ~(int64_t)7;
+  // one block per CU at a time (256 accumulators per lane) and the blocks of a split share an XCD:
+  // per XCD (32 CUs) at most 64 blocks, i.e. two full rounds, in whole splits
+  int64_t s = 8 * (64 / *OGn > 0 ? 64 / *OGn : 1);
+  if (s > chunks / 4) s = chunks / 4;
   if (s < 1) s = 1;
   *S = (int)s;
   *chunks_per_split = (int)((chunks + s - 1) / s);
@@ -223,15 +284,25 @@ extern "C" int xdfm_cin_bf16_bwd_dw(const float* x0, const float* xk, const floa
   const int HT = H <= 32 ? 1 : (H <= 64 ? 2 : 4), NT = L <= 32 ? 1 : (L <= 64 ? 2 : 4);
   XDFM_REQUIRE(B == 0 || (x0 && xk && d_xnext && workspace), "xdfm_cin_bf16_bwd_dw: null argument");
   if (B == 0) S = 0;
-  const size_t lds = (size_t)2 * ((HT + NT) * 32 * kDwPitch + 4 * kDwKM) * 4;
-  const dim3 grid((unsigned)(S * OGn));
+  const size_t lds = (size_t)2 * (HT * 32 * kDwXPitch + NT * 32 * kDwPitch + 4 * kDwKM) * 4;
+  const dim3 grid((unsigned)(8 * ((S + 7) / 8) * OGn));
+  // rows past H / L would be loaded only to be zeroed: those shapes take the general form, which skips them
+  const bool fast = (D & 1) == 0 && H == HT * 32 && L == NT * 32 && (c.cols % kDwKM) == 0 &&
+                    c.cols < ((int64_t)1 << 31) && (int64_t)(H > L ? H : L) * D < ((int64_t)1 << 31);
 #define DW(HTV, NTV)                                                                                                 \
   do {                                                                                                               \
-    if (lds > 64 * 1024)                                                                                             \
-      XDFM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(cin_bf16_dw_kernel<HTV, NTV>),                      \
+    if (lds > 64 * 1024) {                                                                                           \
+      XDFM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(cin_bf16_dw_kernel<HTV, NTV, true>),                \
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                           \
-    XDFM_LAUNCH("cin_bf16_dw_kernel<" #HTV ", " #NTV ">", stream, (cin_bf16_dw_kernel<HTV, NTV>), grid, dim3(256),   \
-                lds, c, x0, xk, d_xnext, workspace, S, OGn, cps);                                                    \
+      XDFM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(cin_bf16_dw_kernel<HTV, NTV, false>),               \
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                           \
+    }                                                                                                                \
+    if (fast)                                                                                                        \
+      XDFM_LAUNCH("cin_bf16_dw_kernel<" #HTV ", " #NTV ">", stream, (cin_bf16_dw_kernel<HTV, NTV, true>), grid,      \
+                  dim3(256), lds, c, x0, xk, d_xnext, workspace, S, OGn, cps);                                       \
+    else                                                                                                             \
+      XDFM_LAUNCH("cin_bf16_dw_kernel<" #HTV ", " #NTV ">", stream, (cin_bf16_dw_kernel<HTV, NTV, false>), grid,     \
+                  dim3(256), lds, c, x0, xk, d_xnext, workspace, S, OGn, cps);                                       \
   } while (0)
 #define DW_N(HTV)            \
   do {                       \

@@ -282,6 +282,11 @@ __global__ __launch_bounds__(256, 2) void cin_bf16_dx_kernel(Dims c, const float
         }
     }
     const uint4* wb = wbuf + (ci & 1) * chunk + lane;
+    // the d_x0 values this chunk adds to are requested now and used after the products
+    float prev[kMT];
+#pragma unroll
+    for (int mt = 0; mt < kMT; ++mt)
+      prev[mt] = (half == 0 && live[mt] && (accumulate_x0 || ht > 0)) ? d_x0[(mb[mt] * c.F + f) * c.D + md[mt]] : 0.f;
     f32x16 T[kMT];
 #pragma unroll
     for (int mt = 0; mt < kMT; ++mt)
@@ -304,11 +309,7 @@ __global__ __launch_bounds__(256, 2) void cin_bf16_dx_kernel(Dims c, const float
         for (int i = 0; i < 16; ++i) dxk[mt][i] = fmaf(xo, T[mt][i], dxk[mt][i]);
       }
       p += __shfl_xor(p, 32);
-      if (half == 0 && live[mt]) {
-        float* dst = d_x0 + (mb[mt] * c.F + f) * c.D + md[mt];
-        const float prev = (accumulate_x0 || ht > 0) ? *dst : 0.f;
-        *dst = prev + pscale * p;
-      }
+      if (half == 0 && live[mt]) d_x0[(mb[mt] * c.F + f) * c.D + md[mt]] = prev[mt] + pscale * p;
     }
     if (f == c.F - 1 && want_xk) {
 #pragma unroll
