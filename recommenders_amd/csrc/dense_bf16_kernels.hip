@@ -79,7 +79,11 @@ __device__ __forceinline__ void emit(const GemmArgs& g, int m, int n, float v) {
 
 // A_KFAST / B_KFAST: which index is contiguous in global memory decides which one consecutive
 // threads walk (coalescing); either way a thread packs pairs along k.
-template <int MODE>
+// FAST (reduction length a multiple of 32 per split, operands below 2^31 elements): staging without
+// branches -- rows past the end read the last row and are zeroed (or set to the bias row's ones) when
+// stored, addresses are a per-thread offset computed once plus a pointer that advances per k step, and no
+// select sits between a load and the products it is meant to fly beside.
+template <int MODE, bool FAST>
 __global__ __launch_bounds__(256, 2) void dense_bf16_kernel(GemmArgs g, float* __restrict__ part) {
   __shared__ __align__(16) uint32_t as[2][kBM * kPitch];
   __shared__ __align__(16) uint32_t bs[2][kBN * kPitch];
@@ -96,7 +100,111 @@ __global__ __launch_bounds__(256, 2) void dense_bf16_kernel(GemmArgs g, float* _
   gs.R = k_hi;
 
   float av[8][2], bv[8][2];
+  float ay[8][2], by[8][2];  // FAST: the saved outputs that go with dy (act' is applied when stored)
+  // FAST: operand pointers at this thread's first element of the split, element offsets of its 8 loads
+  const float* pa = nullptr;
+  const float* pa2 = nullptr;
+  const float* pb = nullptr;
+  const float* pb2 = nullptr;
+  int offa[8], offb[8];
+  uint32_t keepa = 0, keepb = 0, onesa = 0;
+  int stepa = 0, stepb = 0;
+  if (FAST) {
+    // k-fast operands: 8 rows x one pair of k; row-fast operands: one row x 8 pairs of k
+    const int lda = MODE == kFwd ? g.K : (MODE == kDx ? g.Nout : g.K);
+    const int ldb = g.Nout;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      if (A_KFAST) {
+        const int row = m0 + (tid >> 4) + 16 * i;
+        offa[i] = (row < g.M ? row : g.M - 1) * lda + 2 * (tid & 15);
+        keepa |= (row < g.M ? 1u : 0u) << i;
+      } else {  // kDw: A(m,k) = x[k][m], row K_in = ones
+        const int row = m0 + (tid & 127);
+        const int rc = row < g.K ? row : g.K - 1;
+        offa[i] = 2 * ((tid >> 7) + 2 * i) * lda + rc;
+        keepa |= (row < g.K ? 1u : 0u) << i;
+        onesa |= (row == g.K ? 1u : 0u) << i;
+      }
+      if (B_KFAST) {  // kDx: B(k,n) = w[n][k]
+        const int row = n0 + (tid >> 4) + 16 * i;
+        offb[i] = (row < g.N ? row : g.N - 1) * ldb + 2 * (tid & 15);
+        keepb |= (row < g.N ? 1u : 0u) << i;
+      } else {  // kFwd: w[k][n]; kDw: dz[k][n]
+        const int row = n0 + (tid & 127);
+        offb[i] = 2 * ((tid >> 7) + 2 * i) * ldb + (row < g.N ? row : g.N - 1);
+        keepb |= (row < g.N ? 1u : 0u) << i;
+      }
+    }
+    pa = (MODE == kDx ? g.dy : g.x) + (A_KFAST ? (int64_t)k_lo : (int64_t)k_lo * lda);
+    pa2 = MODE == kDx ? g.y + k_lo : nullptr;
+    pb = (MODE == kDw ? g.dy : g.w) + (B_KFAST ? (int64_t)k_lo : (int64_t)k_lo * ldb);
+    pb2 = MODE == kDw ? g.y + (int64_t)k_lo * ldb : nullptr;
+    stepa = A_KFAST ? kBK : kBK * lda;
+    stepb = B_KFAST ? kBK : kBK * ldb;
+  }
+  const bool with_act = g.act != XDFM_ACT_IDENTITY;
+  auto issue_fast = [&]() {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      if (A_KFAST) {
+        const float2 v = *reinterpret_cast<const float2*>(pa + offa[i]);
+        av[i][0] = v.x;
+        av[i][1] = v.y;
+        if (MODE == kDx && with_act) {
+          const float2 u = *reinterpret_cast<const float2*>(pa2 + offa[i]);
+          ay[i][0] = u.x;
+          ay[i][1] = u.y;
+        }
+      } else {
+        av[i][0] = pa[offa[i]];
+        av[i][1] = pa[offa[i] + g.K];
+      }
+      if (B_KFAST) {
+        const float2 v = *reinterpret_cast<const float2*>(pb + offb[i]);
+        bv[i][0] = v.x;
+        bv[i][1] = v.y;
+      } else {
+        bv[i][0] = pb[offb[i]];
+        bv[i][1] = pb[offb[i] + g.Nout];
+        if (MODE == kDw && with_act) {
+          by[i][0] = pb2[offb[i]];
+          by[i][1] = pb2[offb[i] + g.Nout];
+        }
+      }
+    }
+    pa += stepa;
+    pb += stepb;
+    if (MODE == kDx) pa2 += stepa;
+    if (MODE == kDw) pb2 += stepb;
+  };
+  auto stash_fast = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      float a0 = av[i][0], a1 = av[i][1], b0 = bv[i][0], b1 = bv[i][1];
+      if (MODE == kDx && with_act) {
+        a0 *= act_grad(ay[i][0], g.act);
+        a1 *= act_grad(ay[i][1], g.act);
+      }
+      if (MODE == kDw && with_act) {
+        b0 *= act_grad(by[i][0], g.act);
+        b1 *= act_grad(by[i][1], g.act);
+      }
+      const bool ka = (keepa >> i) & 1, kb = (keepb >> i) & 1;
+      const float fill = (MODE == kDw && ((onesa >> i) & 1)) ? 1.f : 0.f;
+      const int rowa = A_KFAST ? (tid >> 4) + 16 * i : (tid & 127);
+      const int kpa = A_KFAST ? (tid & 15) : (tid >> 7) + 2 * i;
+      as[buf][rowa * kPitch + kpa] = pack_bf16(ka ? a0 : fill, ka ? a1 : fill);
+      const int rowb = B_KFAST ? (tid >> 4) + 16 * i : (tid & 127);
+      const int kpb = B_KFAST ? (tid & 15) : (tid >> 7) + 2 * i;
+      bs[buf][rowb * kPitch + kpb] = pack_bf16(kb ? b0 : 0.f, kb ? b1 : 0.f);
+    }
+  };
   auto issue = [&](int k0) {
+    if (FAST) {
+      issue_fast();
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const int row = A_KFAST ? (tid >> 4) + 16 * i : (tid & 127);
@@ -113,6 +221,10 @@ __global__ __launch_bounds__(256, 2) void dense_bf16_kernel(GemmArgs g, float* _
     }
   };
   auto stash = [&](int buf) {
+    if (FAST) {
+      stash_fast(buf);
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const int row = A_KFAST ? (tid >> 4) + 16 * i : (tid & 127);
@@ -202,7 +314,14 @@ int launch(GemmArgs g, float* workspace, hipStream_t st) {
   XDFM_REQUIRE(g.splits == 1 || workspace, "xdfm_dense_bf16: this product is split along k and needs the workspace");
   const dim3 grid((unsigned)((g.N + kBN - 1) / kBN), (unsigned)((g.M + kBM - 1) / kBM), (unsigned)g.splits);
   const char* name = MODE == kFwd ? "dense_bf16_kernel<fwd>" : (MODE == kDx ? "dense_bf16_kernel<dx>" : "dense_bf16_kernel<dw>");
-  XDFM_LAUNCH(name, st, dense_bf16_kernel<MODE>, grid, dim3(256), 0, g, workspace);
+  const int64_t lim = (int64_t)1 << 31;
+  // even leading dimensions where pairs of k are loaded as 8 bytes; R a multiple of 32 (so is every split)
+  const bool fast = g.R % kBK == 0 && g.B * (int64_t)g.K < lim && g.B * (int64_t)g.Nout < lim &&
+                    (MODE == kFwd ? g.K % 2 == 0 : (MODE == kDx ? g.Nout % 2 == 0 : true));
+  if (fast)
+    XDFM_LAUNCH(name, st, (dense_bf16_kernel<MODE, true>), grid, dim3(256), 0, g, workspace);
+  else
+    XDFM_LAUNCH(name, st, (dense_bf16_kernel<MODE, false>), grid, dim3(256), 0, g, workspace);
   if (g.splits > 1) {
     const int64_t total = (int64_t)g.M * g.N;
     XDFM_LAUNCH("dense_bf16_reduce_kernel", st, dense_bf16_reduce_kernel<MODE>, dim3((unsigned)((total + 255) / 256)),

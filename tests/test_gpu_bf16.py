@@ -145,3 +145,88 @@ def test_bf16_through_the_row_sharded_engine(virtual_world):
     shard.check_errors()
     table, _ = shard.gather_global_table()
     assert np.abs(plain.state_dict()["embedding"].cpu().numpy() - table.cpu().numpy()).max() <= 1e-6
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr() if t is not None else 0)
+
+
+@pytest.mark.parametrize("B,K,N,act", [
+    (37, 50, 70, 1),        # nothing a multiple of anything: the general staging path everywhere
+    (256, 96, 40, 3),       # forward and weight gradient on the branch-free path with ragged tiles
+    (320, 70, 64, 2),       # input gradient on it, ragged rows and columns
+    (1024, 160, 288, 1),    # all three on it, several tiles, the split reduction of the weight gradient
+    (512, 2496, 128, 0),    # the first DNN layer's width; identity (the pooled-channel products)
+])
+def test_bf16_dense_products_against_fp64(B, K, N, act):
+    """xdfm_dense_bf16_fwd / bwd through the C ABI against float64 (2e-2 bar; measured 2-8e-3),
+    with dx accumulated into a non-zero buffer."""
+    lib = _lib.lib
+    g = torch.Generator(device="cuda").manual_seed(B + K)
+    x = torch.randn(B, K, device="cuda", generator=g)
+    w = torch.randn(K, N, device="cuda", generator=g) / K ** 0.5
+    b = torch.randn(N, device="cuda", generator=g)
+    dy = torch.randn(B, N, device="cuda", generator=g)
+    base = torch.randn(B, K, device="cuda", generator=g)
+    n = ctypes.c_size_t()
+    _lib.check(lib.xdfm_dense_bf16_workspace_floats(B, K, N, ctypes.byref(n)))
+    ws = torch.empty(max(n.value, 1), device="cuda")
+    y = torch.empty(B, N, device="cuda")
+    _lib.check(lib.xdfm_dense_bf16_fwd(_p(x), _p(w), _p(b), B, K, N, act, _p(y), _p(ws), None))
+    xd, wd, bd = (t.double().requires_grad_(True) for t in (x, w, b))
+    z = xd @ wd + bd
+    yr = {0: z, 1: torch.relu(z), 2: torch.sigmoid(z), 3: torch.tanh(z)}[act]
+    close(y.cpu().numpy(), yr.detach().cpu().numpy(), "y")
+    ysave = yr.detach().float()
+    dx, dw, db = base.clone(), torch.empty(K, N, device="cuda"), torch.empty(N, device="cuda")
+    _lib.check(lib.xdfm_dense_bf16_bwd(_p(x), _p(w), _p(ysave), _p(dy), B, K, N, act, _p(dx), 1, _p(dw), _p(db),
+                                       _p(ws), None))
+    yr.backward(dy.double())
+    close(dx.cpu().numpy(), (xd.grad + base.double()).cpu().numpy(), "dx")
+    close(dw.cpu().numpy(), wd.grad.cpu().numpy(), "dw")
+    close(db.cpu().numpy(), bd.grad.cpu().numpy(), "db")
+
+
+@pytest.mark.parametrize("B,F,H,D,L,Lfull,masked", [
+    (5, 6, 6, 8, 20, 34, 1), (7, 6, 20, 16, 40, 40, 0), (33, 39, 39, 64, 128, 256, 1), (33, 39, 128, 64, 128, 256, 0),
+    (300, 5, 33, 10, 70, 70, 0), (64, 39, 128, 64, 128, 256, 0),
+])
+def test_bf16_cin_layer_kernels_against_fp64(B, F, H, D, L, Lfull, masked):
+    """xdfm_cin_bf16_fwd / bwd_dx / bwd_dw through the C ABI on their own (a layer's L hidden channels
+    of a filter Lfull wide) against float64 einsums; (64, ..) has B*D a multiple of 64 and full tiles:
+    the filter gradient's mask-free staging path."""
+    lib = _lib.lib
+    g = torch.Generator(device="cuda").manual_seed(B + H)
+    x0 = torch.randn(B, F, D, device="cuda", generator=g)
+    xk = x0 if masked else torch.randn(B, H, D, device="cuda", generator=g)
+    w = torch.randn(F * H, Lfull, device="cuda", generator=g) * 0.1
+    dy = torch.randn(B, L, D, device="cuda", generator=g)
+    fb, dbs, wsn = ctypes.c_size_t(), ctypes.c_size_t(), ctypes.c_size_t()
+    _lib.check(lib.xdfm_cin_bf16_image_bytes(F, H, L, ctypes.byref(fb), ctypes.byref(dbs)))
+    fimg = torch.empty(fb.value, dtype=torch.uint8, device="cuda")
+    dimg = torch.empty(dbs.value, dtype=torch.uint8, device="cuda")
+    _lib.check(lib.xdfm_cin_bf16_pack(_p(w), F, H, L, Lfull, masked, _p(fimg), _p(dimg), None))
+    xn = torch.empty(B, L, D, device="cuda")
+    _lib.check(lib.xdfm_cin_bf16_fwd(_p(x0), _p(xk), _p(fimg), B, F, H, D, L, masked, _p(xn), None))
+    base = torch.randn(B, F, D, device="cuda", generator=g)
+    dx0 = base.clone()
+    dxk = None if masked else torch.empty(B, H, D, device="cuda")
+    _lib.check(lib.xdfm_cin_bf16_bwd_dx(_p(x0), _p(xk), _p(dimg), _p(dy), B, F, H, D, L, masked, _p(dxk), _p(dx0), 1, None))
+    _lib.check(lib.xdfm_cin_bf16_bwd_dw_workspace_floats(B, F, H, D, L, ctypes.byref(wsn)))
+    ws = torch.empty(max(wsn.value, 1), device="cuda")
+    dw = torch.full((F * H, Lfull), 5.0, device="cuda")
+    _lib.check(lib.xdfm_cin_bf16_bwd_dw(_p(x0), _p(xk), _p(dy), B, F, H, D, L, masked, _p(dw), Lfull, _p(ws), None))
+    torch.cuda.synchronize()
+    a = x0.double().requires_grad_(True)
+    bq = a if masked else xk.double().requires_grad_(True)
+    W = w.double().view(F, H, Lfull)[:, :, :L].clone().requires_grad_(True)
+    Wm = W * (torch.triu(torch.ones(F, H, device="cuda", dtype=torch.float64), 1) * 2)[:, :, None] if masked else W
+    yref = torch.einsum("bfd,bhd,fhn->bnd", a, bq, Wm)
+    yref.backward(dy.double())
+    close(xn.cpu().numpy(), yref.detach().cpu().numpy(), "xnext")
+    close(dx0.cpu().numpy(), (a.grad + base.double()).cpu().numpy(), "d_x0")
+    if not masked:
+        close(dxk.cpu().numpy(), bq.grad.cpu().numpy(), "d_xk")
+    got = dw.view(F, H, Lfull)
+    close(got[:, :, :L].cpu().numpy(), W.grad.cpu().numpy(), "d_w")        # zero where the mask is
+    assert bool((got[:, :, L:] == 5.0).all())                               # the other columns untouched
