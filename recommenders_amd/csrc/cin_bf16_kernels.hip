@@ -77,34 +77,57 @@ __global__ void cin_bf16_pack_kernel(const float* __restrict__ w, int F, int H, 
 template <int NKS>
 __device__ __forceinline__ void load_frags(const float* __restrict__ src, int R, int D, int64_t b, int d, bool live,
                                            int half, bf16x8 (&frag)[NKS]) {
+  // (b, d) of a lane without a column are (0, 0): every address below is valid, so the loads carry no
+  // branch and no select until a batch of them (4 k steps = 32 loads) is in flight
+  const float* base = src + b * R * D + d;
 #pragma unroll
-  for (int ks = 0; ks < NKS; ++ks) {
-    float v[8];
+  for (int ks0 = 0; ks0 < NKS; ks0 += 4) {
+    float v[4][8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int r = 16 * ks + 8 * half + j;
-      v[j] = (live && r < R) ? src[(b * R + r) * D + d] : 0.f;
-    }
-    uint4 p;
-    p.x = pack_bf16(v[0], v[1]);
-    p.y = pack_bf16(v[2], v[3]);
-    p.z = pack_bf16(v[4], v[5]);
-    p.w = pack_bf16(v[6], v[7]);
-    frag[ks] = as_frag(p);
+    for (int q = 0; q < 4; ++q)
+      if (ks0 + q < NKS) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int r = 16 * (ks0 + q) + 8 * half + j;
+          v[q][j] = base[(r < R ? r : R - 1) * D];
+        }
+      }
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (ks0 + q < NKS) {
+        float w[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) w[j] = (live && 16 * (ks0 + q) + 8 * half + j < R) ? v[q][j] : 0.f;
+        uint4 p;
+        p.x = pack_bf16(w[0], w[1]);
+        p.y = pack_bf16(w[2], w[3]);
+        p.z = pack_bf16(w[4], w[5]);
+        p.w = pack_bf16(w[6], w[7]);
+        frag[ks0 + q] = as_frag(p);
+      }
   }
 }
 
-// x0[f][m] of the block's m range as fp32 in LDS: the factors of the sum over f
+// x0[f][m] of the block's m range as fp32 in LDS: the factors of the sum over f.  Eight loads in flight
+// per thread (clamped addresses, masks applied when stored).
 __device__ __forceinline__ void stage_x0(const Dims& c, const float* __restrict__ x0, int64_t m0, float* __restrict__ x0s) {
-  for (int idx = threadIdx.x; idx < c.Fp * kMB; idx += blockDim.x) {
-    const int f = idx / kMB, ml = idx - f * kMB;
-    const int64_t m = m0 + ml;
-    float v = 0.f;
-    if (f < c.F && m < c.cols) {
-      const int64_t b = m / c.D;
-      v = x0[(b * c.F + f) * c.D + (int)(m - b * c.D)];
+  const int ml = threadIdx.x & (kMB - 1);  // kMB == blockDim.x: a thread keeps its column, f advances
+  const int64_t m = m0 + ml;
+  const bool ok = m < c.cols;
+  const int64_t b = ok ? m / c.D : 0;
+  const float* base = x0 + b * c.F * c.D + (ok ? (int)(m - b * c.D) : 0);
+  for (int f0 = 0; f0 < c.Fp; f0 += 8) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int f = f0 + u;
+      v[u] = base[(f < c.F ? f : c.F - 1) * c.D];
     }
-    x0s[idx] = v;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int f = f0 + u;
+      if (f < c.Fp) x0s[f * kMB + ml] = (ok && f < c.F) ? v[u] : 0.f;
+    }
   }
 }
 
@@ -277,9 +300,14 @@ __global__ __launch_bounds__(256, 2) void cin_bf16_dx_kernel(Dims c, const float
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
           const int h = 32 * ht + tile_row(i, half);
-          xkv[mt][i] = (live[mt] && h < c.H) ? xk[(mb[mt] * c.H + h) * c.D + md[mt]] : 0.f;
+          xkv[mt][i] = xk[(mb[mt] * c.H + (h < c.H ? h : c.H - 1)) * c.D + md[mt]];  // masked below
           dxk[mt][i] = 0.f;
         }
+#pragma unroll
+      for (int mt = 0; mt < kMT; ++mt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+          if (!(live[mt] && 32 * ht + tile_row(i, half) < c.H)) xkv[mt][i] = 0.f;
     }
     const uint4* wb = wbuf + (ci & 1) * chunk + lane;
     // the d_x0 values this chunk adds to are requested now and used after the products
