@@ -215,6 +215,9 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly in the timed region")
     ap.add_argument("--sharded", action="store_true",
                     help="one GPU, but through the row-sharded engine (the N > 1 code path without peers)")
+    ap.add_argument("--force-collectives", action="store_true",
+                    help="with --sharded on one GPU: run every exchange through RCCL anyway (a process group of "
+                         "one rank): the launch cost of the collectives without peers, a side measurement")
     ap.add_argument("--profile-steps", type=int, default=20,
                     help="eager steps after the timed region with per-kernel HIP events")
     args = ap.parse_args()
@@ -256,7 +259,13 @@ def main():
     else:
         from recommenders_amd.models.deeprec.models._sharded import ShardedXDeepFMEngine
 
-        eng = ShardedXDeepFMEngine(hp, device=dev, seed=7)
+        if world == 1 and args.force_collectives:
+            import torch.distributed as dist1
+
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            dist1.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        eng = ShardedXDeepFMEngine(hp, device=dev, seed=7, force_collectives=bool(world == 1 and args.force_collectives))
 
     resident = []
     for hb in host_batches:
