@@ -407,6 +407,23 @@ int xdfm_cin_pool_pack(const float* w, int32_t F, int32_t H, int32_t L, int32_t 
 int xdfm_cin_pool_unpack(const float* dwp, int32_t F, int32_t H, int32_t L, int32_t n_hidden,
                          int32_t masked, float* d_w, void* stream);
 
+/* A layer whose channels are ALL pooled (n_hidden = 0: the last layer of the network,
+ * xDeepFM.py:253-270), unmasked, small shapes (F <= 64, H <= 16, D <= 16 and a multiple of 4, L <= 16),
+ * as ONE forward and ONE backward kernel on the f32 matrix cores with the sum over the embedding
+ * dimension taken first (the pair sums never leave the registers).  Same arguments as xdfm_cin_fwd /
+ * xdfm_cin_bwd with n_hidden = 0 and masked = 0; the same sums in another association (1e-6).
+ *   xdfm_cin_pooled_workspace_floats: 0 = this shape is not served (use xdfm_cin_fwd / xdfm_cin_bwd).
+ *   xdfm_cin_pooled_bwd: d_xk[B,H,D] written, d_x0[B,F,D] written or added to (accumulate_x0),
+ *     d_w[(f,h), 0..L) written with row stride ldw (0 = L). */
+int xdfm_cin_pooled_workspace_floats(int64_t B, int32_t F, int32_t H, int32_t D, int32_t L, size_t* floats);
+int xdfm_cin_pooled_fwd(const float* x0, const float* xk, const float* w, int64_t B, int32_t F, int32_t H,
+                        int32_t D, int32_t L, int32_t ldw, float* pooled, int32_t pool_stride, int32_t pool_off,
+                        void* stream);
+int xdfm_cin_pooled_bwd(const float* x0, const float* xk, const float* w, const float* d_pooled,
+                        int32_t pool_stride, int32_t pool_off, int64_t B, int32_t F, int32_t H, int32_t D,
+                        int32_t L, int32_t ldw, float* d_xk, float* d_x0, int32_t accumulate_x0, float* d_w,
+                        float* workspace, void* stream);
+
 /* ------------------------------------------------------------------------
  * The same layer on the bf16 matrix cores (v_mfma_f32_32x32x16_bf16, fp32 accumulation), for the
  * wide shapes: embedding dim 64, up to 128 inputs per side and 128 channels per call

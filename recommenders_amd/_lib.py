@@ -132,6 +132,9 @@ SIGNATURES = {
     "xdfm_cin_bf16_bwd_dx": [_P, _P, _P, _P, _I64, _I32, _I32, _I32, _I32, _I32, _P, _P, _I32, _P],
     "xdfm_cin_bf16_bwd_dw_workspace_floats": [_I64, _I32, _I32, _I32, _I32, _PSZ],
     "xdfm_cin_bf16_bwd_dw": [_P, _P, _P, _I64, _I32, _I32, _I32, _I32, _I32, _P, _I32, _P, _P],
+    "xdfm_cin_pooled_workspace_floats": [_I64, _I32, _I32, _I32, _I32, _PSZ],
+    "xdfm_cin_pooled_fwd": [_P, _P, _P, _I64, _I32, _I32, _I32, _I32, _I32, _P, _I32, _I32, _P],
+    "xdfm_cin_pooled_bwd": [_P, _P, _P, _P, _I32, _I32, _I64, _I32, _I32, _I32, _I32, _I32, _P, _P, _I32, _P, _P, _P],
     "xdfm_cin_pool_pack": [_P, _I32, _I32, _I32, _I32, _I32, _P, _P],
     "xdfm_cin_pool_unpack": [_P, _I32, _I32, _I32, _I32, _I32, _P, _P],
     "xdfm_bn_fwd": [_P, _I64, _I32, _I32, _P, _P, _P, _P, ctypes.c_float, ctypes.c_float, _I32, _I32, _P, _P, _P],

@@ -300,7 +300,9 @@ class XDeepFMEngine(object):
         # measured slower on configs[2] (0.629 against 0.572 ms/step: the layer kernels do not shrink
         # with the channel count and the pair kernels sit at 24/38 us) -- opt-in until they do
         self.pool_split = os.environ.get("XDFM_POOL_SPLIT", "0") != "0"
+        self.pooled_layer = os.environ.get("XDFM_POOLED_LAYER", "1") != "0"
         self._split = {}
+        self._fused_pool = set()
         self.split_dw = os.environ.get("XDFM_SPLIT_DW", "1") != "0"
         self._late_event = None
         self._fold_dx = False
@@ -485,6 +487,7 @@ class XDeepFMEngine(object):
         pool_part_floats = 1
         bf16_floats = 1
         self._split = {}
+        self._fused_pool = set()
         if hp.use_CIN_part:
             shapes = cin_shapes(hp)
             final_len = sum(L - nh for (_, L, nh) in shapes)
@@ -505,6 +508,7 @@ class XDeepFMEngine(object):
             if self.cross_path:
                 buf("d_cur", B, max(L for (_, L, _) in shapes) * D)
             self._split = {}
+            self._fused_pool = set()
             max_pairs = 0
             for k, (H, L, nh) in enumerate(shapes):
                 if self.fast_d:
@@ -540,6 +544,14 @@ class XDeepFMEngine(object):
                         _lib.check(self.lib.xdfm_cin_bf16_bwd_dw_workspace_floats(B, F, H, D, nh, ctypes.byref(sz)))
                         bf16_floats = max(bf16_floats, sz.value)
                     continue
+                if nh == 0 and k > 0 and self.pooled_layer and not self.cross_path:
+                    # a last layer of small shape: one forward and one backward kernel on the f32
+                    # matrix cores, sum over the embedding dimension first (cin_pooled_layer_kernels)
+                    _lib.check(self.lib.xdfm_cin_pooled_workspace_floats(B, F, H, D, L, ctypes.byref(sz)))
+                    if sz.value:
+                        self._fused_pool.add(k)
+                        part_floats = max(part_floats, sz.value)
+                        continue
                 if self.pool_split and self.prepack and not self.cross_path and L - nh > 0:
                     fsz, bsz = ctypes.c_size_t(), ctypes.c_size_t()
                     if nh > 0:
@@ -778,6 +790,7 @@ class XDeepFMEngine(object):
             self._fold_dx = bool(with_grad and hp.use_CIN_part and not self.fast_d and not self.cross_path
                                  and "img_b_0" in ws
                                  and all(("img_b_%d" % k) in ws or (k in self._split and nh == 0)
+                                         or k in self._fused_pool
                                          for k, (_, _, nh) in enumerate(cin_shapes(hp)))
                                  and self._dnn_plain() and os.environ.get("XDFM_FOLD_DX", "1") != "0")
             with torch.cuda.stream(side):
@@ -816,6 +829,12 @@ class XDeepFMEngine(object):
                                                            B, P, Lp, 0, _ptr(ws["pool_%d" % k]), _ptr(ws["bf16_ws"]), st))
                         ws["pooled"][:B, off:off + Lp].copy_(ws["pool_%d" % k][:B])
                     off += L - nh
+                    xk = xnext
+                    continue
+                if k in self._fused_pool:
+                    _lib.check(lib.xdfm_cin_pooled_fwd(_ptr(x0), _ptr(xk), _ptr(self.views["cin_f_%d" % k]), B, F, H,
+                                                       D, L, 0, _ptr(ws["pooled"]), final_len, off, st))
+                    off += L
                     xk = xnext
                     continue
                 if k in self._split:
@@ -1227,6 +1246,14 @@ class XDeepFMEngine(object):
                     continue
                 fold = self.overlap_dnn and self._fold_dx
                 first_writer = fold and k == len(shapes) - 1  # nothing has been put into d_emb yet
+                if k in self._fused_pool:
+                    _lib.check(
+                        lib.xdfm_cin_pooled_bwd(_ptr(x0), _ptr(xk), _ptr(self.views["cin_f_%d" % k]),
+                                                _ptr(ws["d_pooled"]), final_len, offs[k], B, F, H, D, L, 0,
+                                                _ptr(d_xk), _ptr(d_emb), 0 if first_writer else 1,
+                                                _ptr(gv["cin_f_%d" % k]), _ptr(ws["part"]), st)
+                    )
+                    continue
                 Lk, pair_after = L, False
                 if k in self._split:
                     # pooled channels: dS = d_pooled Wp^T and dWp = S^T d_pooled as one dense-layer

@@ -314,6 +314,90 @@ def test_pooled_channels_summed_over_d_first_equal_the_layer_kernels(name):
         close(x.cpu().numpy(), y.cpu().numpy(), rtol=2e-5, what=what)
 
 
+@pytest.mark.parametrize("name", ["all_parts", "criteo_shape", "many_fields"])
+def test_fused_last_layer_equals_the_layer_kernels(name):
+    """A last CIN layer (every channel pooled) through xdfm_cin_pooled_fwd / xdfm_cin_pooled_bwd (sum over
+    the embedding dimension first, f32 matrix cores) against the layer kernels: another association of
+    the same fp32 sums, 2e-5 apart at most."""
+    hp = make_hp(**CONFIGS[name])
+    rng = np.random.default_rng(5)
+    b = random_batch(rng, hp, 70)
+    p32 = X.init_params(hp, seed=6)
+    outs = []
+    for fused in (True, False):
+        eng = load_engine(hp, p32)
+        eng.pooled_layer = fused
+        db = upload(eng, b)
+        eng.forward(db, with_loss=True, with_grad=True)
+        eng.backward(db)
+        torch.cuda.synchronize()
+        assert bool(eng._fused_pool) == fused, name
+        d_emb = eng.ws["d_emb"][:70].clone()
+        if eng.d_emb2() is not None:
+            d_emb = d_emb + eng.d_emb2()[:70]
+        outs.append((eng.ws["logit"][:70].clone(), eng.dense_grad.clone(), d_emb))
+    for x, y, what in zip(outs[0], outs[1], ("logit", "dense gradients", "d emb_out")):
+        close(x.cpu().numpy(), y.cpu().numpy(), rtol=2e-5, what=what)
+
+
+@pytest.mark.parametrize("B,F,H,D,L,acc", [(5, 6, 6, 8, 7, 0), (37, 7, 5, 12, 9, 1), (100, 39, 10, 16, 10, 0),
+                                           (70, 12, 12, 8, 16, 1), (33, 64, 16, 4, 8, 1), (1000, 33, 16, 16, 12, 0),
+                                           (0, 8, 8, 8, 8, 0)])
+def test_cin_pooled_entry_points_match_float64(B, F, H, D, L, acc):
+    """xdfm_cin_pooled_fwd / _bwd through the C-ABI against the same sums in float64 (ragged tiles:
+    fields, maps, columns and channels short of the 16 x 16 x 16 x L' the kernels compute on; a strided
+    pooled array whose other columns must stay untouched; d_x0 written or added to)."""
+    lib = _lib.lib
+    g = torch.Generator(device="cuda").manual_seed(1)
+    x0 = torch.randn(B, F, D, device="cuda", generator=g)
+    xk = torch.randn(B, H, D, device="cuda", generator=g)
+    w = torch.randn(F * H, L, device="cuda", generator=g) * 0.1
+    off, stride = 3, L + 5
+    pooled = torch.full((B, stride), 7.0, device="cuda")
+    d_pooled = torch.randn(B, stride, device="cuda", generator=g)
+    n = ctypes.c_size_t()
+    _lib.check(lib.xdfm_cin_pooled_workspace_floats(B, F, H, D, L, ctypes.byref(n)))
+    assert n.value > 0
+    work = torch.empty(n.value, device="cuda")
+    _lib.check(lib.xdfm_cin_pooled_fwd(_ptr(x0), _ptr(xk), _ptr(w), B, F, H, D, L, 0, _ptr(pooled), stride, off, None))
+    base = torch.randn(B, F, D, device="cuda", generator=g)
+    d_x0 = base.clone() if acc else torch.full((B, F, D), 9.0, device="cuda")
+    d_xk = torch.full((B, H, D), 9.0, device="cuda")
+    d_w = torch.full((F * H, L), 5.0, device="cuda")
+    _lib.check(lib.xdfm_cin_pooled_bwd(_ptr(x0), _ptr(xk), _ptr(w), _ptr(d_pooled), stride, off, B, F, H, D, L, 0,
+                                       _ptr(d_xk), _ptr(d_x0), acc, _ptr(d_w), _ptr(work), None))
+    torch.cuda.synchronize()
+    if B == 0:
+        assert bool((d_w == 0).all())
+        return
+    a = x0.double().requires_grad_(True)
+    c = xk.double().requires_grad_(True)
+    W = w.double().view(F, H, L).clone().requires_grad_(True)
+    y = torch.einsum("bfd,bhd,fhn->bn", a, c, W)
+    y.backward(d_pooled[:, off:off + L].double())
+
+    def rel(got, exp):
+        return float((got.double() - exp).abs().max() / exp.abs().max())
+
+    assert rel(pooled[:, off:off + L], y.detach()) < 2e-6
+    assert bool((pooled[:, :off] == 7).all()) and bool((pooled[:, off + L:] == 7).all())
+    assert rel(d_x0, a.grad + (base.double() if acc else 0)) < 2e-6
+    assert rel(d_xk, c.grad) < 2e-6
+    assert rel(d_w.view(F, H, L), W.grad) < 2e-6
+
+
+def test_cin_pooled_refuses_what_it_does_not_serve():
+    lib = _lib.lib
+    n = ctypes.c_size_t(1)
+    for shape in [(8, 65, 8, 8, 8), (8, 8, 17, 8, 8), (8, 8, 8, 10, 8), (8, 8, 8, 20, 8), (8, 8, 8, 8, 17),
+                  (8, 64, 16, 16, 16)]:
+        _lib.check(lib.xdfm_cin_pooled_workspace_floats(*shape, ctypes.byref(n)))
+        assert n.value == 0, shape
+    x = torch.zeros(8 * 65 * 8, device="cuda")
+    with pytest.raises(_lib.XdfmError):
+        _lib.check(lib.xdfm_cin_pooled_fwd(_ptr(x), _ptr(x), _ptr(x), 8, 65, 8, 8, 8, 0, _ptr(x), 8, 0, None))
+
+
 def test_dropout_training_matches_oracle_given_the_masks():
     """user_dropout (base_model.py:335-336, :377): the masks come from the engine's own generator
     (TF's stream is not reproducible); with the same masks the oracle must take the same steps.
