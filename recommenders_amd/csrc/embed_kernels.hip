@@ -875,33 +875,42 @@ __device__ __forceinline__ void catchup_vals(const CatchArgs& a, RowVals<VEC>& r
     // backward pass's matrix kernels: 109 -> 59 us, and the step 0.571 -> 0.523 ms).  Tried and dropped:
     // handing only the runs' first positions out to the lane groups (a ballot per 64 positions) -- a
     // quarter of the waves, each with two dependent rounds: 112 us, the kernel is latency-bound after this.
+    // ... and the loop itself is kept to one reciprocal per element and step (the transcendental unit
+    // runs at a quarter of the rate): sqrt(v b2^k) is carried as sqrt(v) g^k, g = sqrt(b2), and m, v
+    // decay by one multiplication each (TF writes m + (0 - m)(1 - b1): the same number to an ulp).
+    const float g = sqrtf(a.b2);
+    float sv[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) sv[i] = __builtin_amdgcn_sqrtf(r.v[i]);
     for (int k = 0; k < kx; ++k) {
       const float alpha = o.lr * __builtin_amdgcn_sqrtf(1.f - b2j) * __builtin_amdgcn_rcpf(1.f - b1j);
 #pragma unroll
       for (int i = 0; i < VEC; ++i) {
-        r.m[i] = r.m[i] + (0.f - r.m[i]) * o.one_minus_b1;
-        r.v[i] = r.v[i] + (0.f - r.v[i]) * o.one_minus_b2;
-        r.p[i] = r.p[i] - (r.m[i] * alpha) * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(r.v[i]) + o.eps);
+        r.m[i] *= a.b1;
+        r.v[i] *= a.b2;
+        sv[i] *= g;
+        r.p[i] = fmaf(-(r.m[i] * alpha), __builtin_amdgcn_rcpf(sv[i] + o.eps), r.p[i]);
       }
       b1j *= a.b1;
       b2j *= a.b2;
     }
     const int gp = G - kx;
     if (gp > 0) {
-      // steps j1 = last + kx + 1 ... : sum_i alpha(j1 + i - 1) m b1^i / (sqrt(v) g^i + eps), g = sqrt(b2);
+      // steps j1 = last + kx + 1 ... : sum_i alpha(j1 + i - 1) m b1^i / (sqrt(v) g^i + eps);
       // f(i) = alpha / (sqrt(v) g^i + eps) is fitted as f(1) rho^(i-1) through i = 1 and i = 9
-      const float a1 = o.lr * sqrtf(1.f - b2j) / (1.f - b1j);
+      // (hardware log2 / exp2 / rcp / sqrt: 1 ulp each, far inside the fit's own 4e-6)
+      const float a1 = o.lr * __builtin_amdgcn_sqrtf(1.f - b2j) * __builtin_amdgcn_rcpf(1.f - b1j);
       const float b1j9 = b1j * exp2f(8.f * lb1), b2j9 = b2j * exp2f(8.f * lb2);
-      const float a9 = o.lr * sqrtf(1.f - b2j9) / (1.f - b1j9);
-      const float g1 = exp2f(0.5f * lb2), g9 = exp2f(4.5f * lb2);
+      const float a9 = o.lr * __builtin_amdgcn_sqrtf(1.f - b2j9) * __builtin_amdgcn_rcpf(1.f - b1j9);
+      const float g1 = g, g9 = exp2f(4.5f * lb2);
       const float pw1 = exp2f((float)gp * lb1), pw2 = exp2f((float)gp * lb2);
 #pragma unroll
       for (int i = 0; i < VEC; ++i) {
-        const float sv = sqrtf(r.v[i]);
-        const float f1 = a1 / (sv * g1 + o.eps), f9 = a9 / (sv * g9 + o.eps);
-        const float q = a.b1 * exp2f(log2f(f9 / f1) * 0.125f);
-        const float qg = exp2f((float)gp * log2f(q));
-        r.p[i] = r.p[i] - r.m[i] * f1 * a.b1 * (1.f - qg) / (1.f - q);
+        const float f1 = a1 * __builtin_amdgcn_rcpf(sv[i] * g1 + o.eps);
+        const float f9 = a9 * __builtin_amdgcn_rcpf(sv[i] * g9 + o.eps);
+        const float q = a.b1 * __builtin_amdgcn_exp2f(__builtin_amdgcn_logf(f9 * __builtin_amdgcn_rcpf(f1)) * 0.125f);
+        const float qg = __builtin_amdgcn_exp2f((float)gp * __builtin_amdgcn_logf(q));
+        r.p[i] = r.p[i] - r.m[i] * f1 * a.b1 * (1.f - qg) * __builtin_amdgcn_rcpf(1.f - q);
         r.m[i] = r.m[i] * pw1;
         r.v[i] = r.v[i] * pw2;
       }
