@@ -134,7 +134,8 @@ class FFMTextIterator(BaseIterator):
         0 = off) are kept and yielded again while the file is unchanged (same size and mtime).
         The feed dicts themselves are kept (their arrays read-only), so whatever the model attached
         to them (the batch in device memory, its sort plan) is reused as well; the model bounds
-        that device memory by XDFM_FFM_CACHE_DEVICE_MB (base_model._batch_from_feed)."""
+        that device memory by XDFM_FFM_CACHE_DEVICE_MB (base_model._batch_from_feed).
+        Behind it, XDFM_FFM_CACHE_DIR names an on-disk cache of the same batches (_disk_cached)."""
         budget = int(os.environ.get("XDFM_FFM_CACHE_MB", "4096")) << 20
         if budget <= 0:
             yield from self._read_ahead(self._load_native(infile))
@@ -151,7 +152,7 @@ class FFMTextIterator(BaseIterator):
             yield from hit
             return
         kept, held, size = [], sum(self._parsed_bytes.values()), 0
-        for item in self._read_ahead(self._load_native(infile)):
+        for item in self._disk_cached(infile, key):
             if kept is not None:
                 size += sum(v.nbytes for v in item[0].values() if isinstance(v, np.ndarray))
                 if held + size > budget:
@@ -170,6 +171,94 @@ class FFMTextIterator(BaseIterator):
                 del self._parsed_bytes[k]
             self._parsed[key] = kept
             self._parsed_bytes[key] = size
+
+    # ---------------------------------------------------------- on-disk cache
+    _DISK_VERSION = 1
+    _DISK_KEYS = ("labels", "fm_feat_indices", "fm_feat_values", "fm_feat_shape", "dnn_feat_indices",
+                  "dnn_feat_values", "dnn_feat_weights", "dnn_feat_shape")
+
+    def _disk_path(self, key):
+        root = os.environ.get("XDFM_FFM_CACHE_DIR", "")
+        if not root:
+            return None
+        import hashlib
+
+        tag = hashlib.sha1(repr((self._DISK_VERSION,) + tuple(key)).encode()).hexdigest()[:24]
+        return os.path.join(root, "ffm_%s.npz" % tag)
+
+    def _disk_cached(self, infile, key):
+        """The parsed batches of a file from / to XDFM_FFM_CACHE_DIR (off when unset): a re-run whose
+        file is unchanged (same path, size, mtime, batch size, FIELD_COUNT, FEATURE_COUNT) parses no
+        text at all, not even in its first epoch.  One uncompressed .npz per file, arrays written as
+        the batches stream by and read back one batch at a time (nothing unpickled, allow_pickle off);
+        the archive is renamed into place only when the whole file went through."""
+        path = self._disk_path(key)
+        if path is None:
+            yield from self._read_ahead(self._load_native(infile))
+            return
+        if os.path.exists(path):
+            try:
+                yield from self._read_ahead(self._load_disk(path))
+                return
+            except (OSError, ValueError, KeyError) as exc:  # damaged or foreign archive: parse again
+                import warnings
+
+                warnings.warn("ignoring the parsed-batch cache %s (%s)" % (path, exc))
+        import json
+        import zipfile
+
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        tmp = "%s.tmp.%d" % (path, os.getpid())
+        done = False
+        try:
+            with zipfile.ZipFile(tmp, "w", zipfile.ZIP_STORED, allowZip64=True) as zf:
+
+                def put(name, arr):
+                    with zf.open(name + ".npy", "w", force_zip64=True) as f:
+                        np.lib.format.write_array(f, np.ascontiguousarray(arr), allow_pickle=False)
+
+                count = 0
+                for feed, imps, n in self._read_ahead(self._load_native(infile)):
+                    res = {ph.name: v for ph, v in feed.items()}
+                    for name, ph in zip(self._DISK_KEYS, self._placeholders()):
+                        put("b%d_%s" % (count, name), res[ph.name])
+                    if feed.row_ptr is not None:
+                        put("b%d_row_ptr" % count, feed.row_ptr)
+                    if any(i != 0 for i in imps):
+                        put("b%d_imp" % count, np.frombuffer(json.dumps(imps).encode(), dtype=np.uint8))
+                    count += 1
+                    yield feed, imps, n
+                put("meta", np.asarray([self._DISK_VERSION, count], dtype=np.int64))
+                done = True
+        finally:
+            if done:
+                os.replace(tmp, path)
+            elif os.path.exists(tmp):
+                os.remove(tmp)
+
+    def _placeholders(self):
+        return (self.labels, self.fm_feat_indices, self.fm_feat_values, self.fm_feat_shape,
+                self.dnn_feat_indices, self.dnn_feat_values, self.dnn_feat_weights, self.dnn_feat_shape)
+
+    def _load_disk(self, path):
+        import json
+
+        with np.load(path, allow_pickle=False) as z:
+            version, count = (int(x) for x in z["meta"])
+            if version != self._DISK_VERSION:
+                raise ValueError("cache version %d" % version)
+            names = set(z.files)
+            for i in range(count):
+                res = {name: z["b%d_%s" % (i, name)] for name in self._DISK_KEYS}
+                feed = self.gen_feed_dict(res)
+                if "b%d_row_ptr" % i in names:
+                    feed.row_ptr = z["b%d_row_ptr" % i]
+                n = int(res["labels"].shape[0])
+                if "b%d_imp" % i in names:
+                    imps = json.loads(z["b%d_imp" % i].tobytes().decode())
+                else:
+                    imps = [0] * n
+                yield feed, imps, n
 
     @staticmethod
     def _read_ahead(gen, depth=2):

@@ -206,3 +206,60 @@ def test_parsed_batches_are_kept_while_the_file_is_unchanged(tmp_path, monkeypat
     a = list(it2.load_data_from_file(path))
     b = list(it2.load_data_from_file(path))
     assert a[0][0] is not b[0][0] and not it2._parsed
+
+
+def test_parsed_batches_on_disk_serve_a_second_run_without_parsing(tmp_path, monkeypatch):
+    """XDFM_FFM_CACHE_DIR: a second iterator (a re-run) over an unchanged file gets the same arrays,
+    impression ids and CSR offsets from the archive and never opens the text; a changed file is
+    parsed again; an interrupted first pass leaves no archive behind; a damaged archive is ignored."""
+    import os
+
+    from tests.util import random_features, write_libffm
+
+    cache = tmp_path / "cache"
+    monkeypatch.setenv("XDFM_FFM_CACHE_DIR", str(cache))
+    hp = make_hp(batch_size=16)
+    rng = np.random.default_rng(5)
+    labels, feats = random_features(rng, 40, hp.FIELD_COUNT, hp.FEATURE_COUNT)
+    path = write_libffm(str(tmp_path / "a.ffm"), labels, feats, imp_every=3)
+
+    def same(xs, ys):
+        assert len(xs) == len(ys)
+        for (fa, ia, na), (fb, ib, nb) in zip(xs, ys):
+            assert na == nb and ia == ib
+            assert (fa.row_ptr is None) == (fb.row_ptr is None)
+            assert fa.row_ptr is None or np.array_equal(fa.row_ptr, fb.row_ptr)
+            for (ka, va), (kb, vb) in zip(sorted(fa.items(), key=lambda kv: kv[0].name),
+                                          sorted(fb.items(), key=lambda kv: kv[0].name)):
+                assert ka.name == kb.name and va.dtype == vb.dtype and va.shape == vb.shape
+                assert np.array_equal(va, vb)
+
+    # a pass that stops early writes nothing
+    gen = FFMTextIterator(hp, None).load_data_from_file(path)
+    next(gen)
+    gen.close()
+    assert not cache.exists() or not os.listdir(cache)
+    first = list(FFMTextIterator(hp, None).load_data_from_file(path))
+    files = os.listdir(cache)
+    assert len(files) == 1 and files[0].endswith(".npz")
+    it = FFMTextIterator(hp, None)
+
+    def no_text(_):
+        raise AssertionError("the text was parsed again")
+
+    monkeypatch.setattr(it, "_load_native", no_text)
+    second = list(it.load_data_from_file(path))
+    same(first, second)
+    assert any(i != 0 for (_, imps, _) in second for i in imps)
+    # the file changes: parsed again, a second archive
+    labels2, feats2 = random_features(rng, 20, hp.FIELD_COUNT, hp.FEATURE_COUNT)
+    write_libffm(path, labels2, feats2)
+    third = list(FFMTextIterator(hp, None).load_data_from_file(path))
+    assert [n for (_, _, n) in third] == [16, 4] and len(os.listdir(cache)) == 2
+    # a damaged archive is ignored (with a warning) and the text parsed
+    for f in os.listdir(cache):
+        with open(cache / f, "wb") as fh:
+            fh.write(b"not a zip")
+    with pytest.warns(UserWarning):
+        again = list(FFMTextIterator(hp, None).load_data_from_file(path))
+    same(third, again)
