@@ -152,7 +152,11 @@ def kernel_models(hp, nnz, uniq):
         dx_flops = 2.0 * rows * pairs * L + 4.0 * rows * pairs
         dw_flops = 2.0 * rows * pairs * L
         add("cin_bwd_dx2_mfma_kernel<%d, %d>" % (nf, ss), "mfma", dx_flops)
-        add("cin_bwd_dw_mfma_kernel<%d, %d>" % (pt, nt_w), "mfma", dw_flops)
+        nh = L // 2 if k != n_layers - 1 else 0
+        # hidden | pooled cut of the channel tiles (csrc/cin_mfma_kernels.hip, dw_body): a pooled channel's
+        # products are summed over the sample's D rows first.  The ALGORITHMIC flops stay 2 rows pairs L.
+        sd = D // 8 if (0 < nh <= 16 and 0 < L - nh <= 16 and D in (8, 16, 32)) else 0
+        add("cin_bwd_dw_mfma_kernel<%d, %d, %d>" % (pt, 2 if sd else nt_w, sd), "mfma", dw_flops)
         H = L // 2 if k != n_layers - 1 else L
     return m
 

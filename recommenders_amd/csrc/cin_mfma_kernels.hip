@@ -796,9 +796,17 @@ struct DwArgs {
   float* part;
 };
 
-template <int PT, int NT, int XU>
+// SD > 0 (NT = 2, D = 8 SD rows per sample, chunks start on sample boundaries): the channel tiles are
+// re-cut as [hidden channels | pooled channels].  A pooled channel's upstream gradient is the same for
+// the D rows of a sample, so its filter gradient is sum_b d_pooled[b,n] (sum_d Z[(b,d),p]): the wave adds
+// the Z fragments of a sample's SD stages (one v_add beside each product of the hidden tile) and issues
+// ONE product per sample for the pooled tile instead of 2 SD -- 5 matrix instructions per sample and
+// pair tile instead of 8 at D = 16.  (The d-sum of a lane covers its own rows; the instruction's sum over
+// k joins the four lane groups.)
+template <int PT, int NT, int XU, int SD>
 __device__ __forceinline__ void dw_body(const BwdIn& in, const DwArgs& aw, int bx, int by, int bz,
                                         float* lds) {
+  static_assert(SD == 0 || NT == 2, "the hidden | pooled cut needs two channel tiles");
   const CinDims& c = in.c;
   const float* __restrict__ x0 = in.x0;
   const float* __restrict__ xk = in.xk;
@@ -856,6 +864,13 @@ __device__ __forceinline__ void dw_body(const BwdIn& in, const DwArgs& aw, int b
   // stores use immediate offsets, so nothing but the values themselves stays live over the loop.
   const int srow = threadIdx.x & 63;
   const int sq = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  // column of the channel tiles -> channel (>= L: none).  SD > 0: columns 0..15 are the hidden channels,
+  // 16..31 the pooled ones.
+  auto ch_of = [&](int col) {
+    if (SD == 0) return col;
+    if (col < 16) return col < c.n_hidden ? col : c.L;
+    return c.n_hidden + (col - 16);
+  };
   float vx[XU], va[XU], vd[NCH / 4];
   bool row_ok = false;  // of the fetched chunk; values are masked when they go to LDS, so that
                         // nothing waits for the loads before the multiply loop
@@ -883,7 +898,7 @@ __device__ __forceinline__ void dw_body(const BwdIn& in, const DwArgs& aw, int b
     const int no = b * c.n_hidden * c.D + d, po = b * pool_stride + pool_off - c.n_hidden;
 #pragma unroll
     for (int u = 0; u < NCH / 4; ++u) {
-      const int ch = c0 + 4 * u + sq;
+      const int ch = ch_of(c0 + 4 * u + sq);
       const int chc = ch < c.L ? ch : c.L - 1;  // uniform
       if (chc < c.n_hidden)
         vd[u] = (d_xnext + chc * c.D)[no];
@@ -903,7 +918,7 @@ __device__ __forceinline__ void dw_body(const BwdIn& in, const DwArgs& aw, int b
     }
 #pragma unroll
     for (int u = 0; u < NCH / 4; ++u)
-      base[dc_off + 4 * u * RCp] = (row_ok && c0 + 4 * u + sq < c.L) ? vd[u] : 0.f;
+      base[dc_off + 4 * u * RCp] = (row_ok && ch_of(c0 + 4 * u + sq) < c.L) ? vd[u] : 0.f;
   };
 
   fetch(r_beg);
@@ -921,6 +936,7 @@ __device__ __forceinline__ void dw_body(const BwdIn& in, const DwArgs& aw, int b
         f32x2 a[HP], x[HP];
       };
       f32x2 bS[2][NT];
+      float zs[SD > 0 ? PT : 1];  // SD > 0: this lane's Z summed over its rows of the current sample
       auto issue = [&](Unit& un, int s, int hf) {
 #pragma unroll
         for (int p = 0; p < HP; ++p) {
@@ -941,9 +957,16 @@ __device__ __forceinline__ void dw_body(const BwdIn& in, const DwArgs& aw, int b
           for (int p = 0; p < HP; ++p) {
             if (hf * HP + p < PT) {
               const float z = un.a[p][ks] * un.x[p][ks];
+              if constexpr (SD == 0) {
 #pragma unroll
-              for (int nt = 0; nt < NT; ++nt)
-                acc[hf * HP + p][nt] = mfma(z, bS[s & 1][nt][ks], acc[hf * HP + p][nt]);
+                for (int nt = 0; nt < NT; ++nt)
+                  acc[hf * HP + p][nt] = mfma(z, bS[s & 1][nt][ks], acc[hf * HP + p][nt]);
+              } else {
+                acc[hf * HP + p][0] = mfma(z, bS[s & 1][0][ks], acc[hf * HP + p][0]);
+                const bool first = (s % SD == 0) && ks == 0, last = (s % SD == SD - 1) && ks == 1;
+                zs[hf * HP + p] = first ? z : zs[hf * HP + p] + z;
+                if (last) acc[hf * HP + p][1] = mfma(zs[hf * HP + p], bS[s & 1][1][ks], acc[hf * HP + p][1]);
+              }
             }
           }
       };
@@ -981,7 +1004,7 @@ __device__ __forceinline__ void dw_body(const BwdIn& in, const DwArgs& aw, int b
     if (t0 + p < ntile) {
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
-        const int ch = c0 + nt * 16 + j;
+        const int ch = ch_of(c0 + nt * 16 + j);
         if (ch < c.L) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
@@ -1000,10 +1023,10 @@ __global__ __launch_bounds__(256) void cin_bwd_dx2_mfma_kernel(BwdIn in, Dx2Args
   dx2_body<NFT, S>(in, ax, blockIdx.x, lds);
 }
 
-template <int PT, int NT, int XU>
+template <int PT, int NT, int XU, int SD>
 __global__ __launch_bounds__(256) void cin_bwd_dw_mfma_kernel(BwdIn in, DwArgs aw) {
   extern __shared__ float lds[];
-  dw_body<PT, NT, XU>(in, aw, blockIdx.x, blockIdx.y, blockIdx.z, lds);
+  dw_body<PT, NT, XU, SD>(in, aw, blockIdx.x, blockIdx.y, blockIdx.z, lds);
 }
 
 // d_w[(f,h), n] = scale * sum over splits; masked pairs get 0.  A block sums 32 elements:
@@ -1189,10 +1212,20 @@ int bwd_mfma(const CinDims& c, const float* x0, const float* xk, const float* w,
 
   // ---- filter gradient geometry
   const int64_t rows = c.B * c.D;
-  const int n_splits = dw_splits(rows);
-  const int rows_per_split = (int)((rows + n_splits - 1) / n_splits);
+  int n_splits = dw_splits(rows);
+  int rows_per_split = (int)((rows + n_splits - 1) / n_splits);
+  // the hidden | pooled cut of the channel tiles (dw_body): both kinds present and at most 16 each, a
+  // sample = 1, 2 or 4 stages of 8 rows, splits (and with them the chunks of 64 rows) on sample boundaries
+  const int n_pooled = c.L - c.n_hidden;
+  int SD = 0;
+  if (d_pooled && c.n_hidden > 0 && c.n_hidden <= 16 && n_pooled > 0 && n_pooled <= 16 &&
+      (c.D == 8 || c.D == 16 || c.D == 32)) {
+    SD = c.D / 8;
+    rows_per_split = (rows_per_split + 63) / 64 * 64;
+    n_splits = (int)((rows + rows_per_split - 1) / rows_per_split);  // no split starts past the end
+  }
   const int ntile = n_tiles(nft, nht, c.masked);
-  const int nt_total = (c.L + 15) / 16;
+  const int nt_total = SD ? 2 : (c.L + 15) / 16;
   const int NT = nt_total >= 2 ? 2 : 1;
   // pair tiles per wave: 7 when that wastes fewer wave slots than 8 (55 tiles: 56 vs 64)
   const int maxp = Hp > Fp ? Hp : Fp;
@@ -1301,28 +1334,40 @@ int bwd_mfma(const CinDims& c, const float* x0, const float* xk, const float* w,
   }
   // ---- filter gradient
   if (dw_partial) {
-#define CALLW(PTV, NTV, XUV)                                                                          \
+#define CALLW(PTV, NTV, XUV, SDV)                                                                     \
   do {                                                                                                \
-    int rc = allow_lds(cin_bwd_dw_mfma_kernel<PTV, NTV, XUV>, dw_lds);                                \
+    int rc = allow_lds(cin_bwd_dw_mfma_kernel<PTV, NTV, XUV, SDV>, dw_lds);                           \
     if (rc) return rc;                                                                                \
-    XDFM_LAUNCH("cin_bwd_dw_mfma_kernel<" #PTV ", " #NTV ">", st,                                     \
-                (cin_bwd_dw_mfma_kernel<PTV, NTV, XUV>), dw_grid, dim3(256), dw_lds, in, aw);         \
+    XDFM_LAUNCH("cin_bwd_dw_mfma_kernel<" #PTV ", " #NTV ", " #SDV ">", st,                           \
+                (cin_bwd_dw_mfma_kernel<PTV, NTV, XUV, SDV>), dw_grid, dim3(256), dw_lds, in, aw);    \
+  } while (0)
+#define CALLW_SD(PTV, XUV)      \
+  do {                          \
+    if (SD == 1)                \
+      CALLW(PTV, 2, XUV, 1);    \
+    else if (SD == 2)           \
+      CALLW(PTV, 2, XUV, 2);    \
+    else if (SD == 4)           \
+      CALLW(PTV, 2, XUV, 4);    \
+    else                        \
+      CALLW(PTV, 2, XUV, 0);    \
   } while (0)
     if (NT == 2) {
       if (maxp > 40)
-        CALLW(8, 2, 32);
+        CALLW_SD(8, 32);
       else if (PT == 7)
-        CALLW(7, 2, 10);
+        CALLW_SD(7, 10);
       else
-        CALLW(8, 2, 10);
+        CALLW_SD(8, 10);
     } else {
       if (maxp > 40)
-        CALLW(8, 1, 32);
+        CALLW(8, 1, 32, 0);
       else if (PT == 7)
-        CALLW(7, 1, 10);
+        CALLW(7, 1, 10, 0);
       else
-        CALLW(8, 1, 10);
+        CALLW(8, 1, 10, 0);
     }
+#undef CALLW_SD
 #undef CALLW
   }
   if (dw_reduce) {
