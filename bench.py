@@ -151,7 +151,10 @@ def kernel_models(hp, nnz, uniq):
         nt_w = 2 if nt_total >= 2 else 1
         dx_flops = 2.0 * rows * pairs * L + 4.0 * rows * pairs
         dw_flops = 2.0 * rows * pairs * L
-        add("cin_bwd_dx2_mfma_kernel<%d, %d>" % (nf, ss), "mfma", dx_flops)
+        nh_k = L // 2 if k != n_layers - 1 else 0
+        shh, p0 = (nh_k + 3) // 4, nh_k // 4
+        cut = D % 4 == 0 and 0 < nh_k < L and ((ss == 5 and shh == 3 and p0 == 2) or (ss == 3 and shh == 2 and p0 == 1))
+        add("cin_bwd_dx2_mfma_kernel<%d, %d, %d>" % (nf, ss, shh if cut else ss), "mfma", dx_flops)
         nh = L // 2 if k != n_layers - 1 else 0
         # hidden | pooled cut of the channel tiles (csrc/cin_mfma_kernels.hip, dw_body): a pooled channel's
         # products are summed over the sample's D rows first.  The ALGORITHMIC flops stay 2 rows pairs L.

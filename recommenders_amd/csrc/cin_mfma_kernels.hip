@@ -587,8 +587,16 @@ struct BwdIn {  // what both backward kernels read
   int pool_stride, pool_off;
 };
 
-template <int NFT, int S>
+// SH < S ("cut", D a multiple of 4 so that a lane's 4 rows lie in one sample): a pooled channel's upstream
+// gradient is the same for every row of a sample, so the pooled channels' part of T is ONE product chain
+// per lane (steps P0..S-1, B = d_pooled of the lane's sample, hidden channels of a shared step zeroed)
+// and the 4 row tiles' chains run over the hidden channels only (steps 0..SH-1, pooled channels of a
+// shared step zeroed), starting from that part: SH 4 + (S - P0) matrix instructions per pair tile instead
+// of 4 S (15 for 20 at n_hidden = 10, L = 20).  The filter image is the same either way.
+template <int NFT, int S, int SH, int P0>
 __device__ __forceinline__ void dx2_body(const BwdIn& in, const Dx2Args& ax, int bid, float* lds) {
+  constexpr bool CUT = SH < S;
+  constexpr int SPL = CUT ? S - P0 : 1;
   const CinDims& c = in.c;
   const float* __restrict__ x0 = in.x0;
   const float* __restrict__ xk = in.xk;
@@ -620,7 +628,8 @@ __device__ __forceinline__ void dx2_body(const BwdIn& in, const Dx2Args& ax, int
   const int j = lane & 15, g = lane >> 4;
   const int m0 = wave * 64 + 4 * j;  // this lane's 4 rows
   // B operands: dcurr[row][4s + g] for the lane's 4 rows, straight from the upstream tensors
-  float dc[S][RT];
+  float dc[SH][RT];
+  float dcp[SPL];
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt) {
     const int m = m0 + rt;
@@ -629,13 +638,23 @@ __device__ __forceinline__ void dx2_body(const BwdIn& in, const Dx2Args& ax, int
     const int bl = fdiv(mc, 1.0f / (float)c.D), d = mc - bl * c.D;
     const int64_t b = b0 + bl;
 #pragma unroll
-    for (int s = 0; s < S; ++s) {
+    for (int s = 0; s < SH; ++s) {
       const int n = 4 * s + g;
       float v = 0.f;
-      if (valid && n < c.L)
+      if (CUT) {
+        if (valid && n < c.n_hidden) v = d_xnext[(b * c.n_hidden + n) * c.D + d];
+      } else if (valid && n < c.L) {
         v = n < c.n_hidden ? d_xnext[(b * c.n_hidden + n) * c.D + d]
                            : d_pooled[b * pool_stride + pool_off + n - c.n_hidden];
+      }
       dc[s][rt] = v;
+    }
+    if (CUT && rt == 0) {
+#pragma unroll
+      for (int s = P0; s < S; ++s) {
+        const int n = 4 * s + g;
+        dcp[s - P0] = (valid && n >= c.n_hidden && n < c.L) ? d_pooled[b * pool_stride + pool_off + n - c.n_hidden] : 0.f;
+      }
     }
   }
   __syncthreads();  // the X tiles are staged
@@ -680,11 +699,22 @@ __device__ __forceinline__ void dx2_body(const BwdIn& in, const Dx2Args& ax, int
 #pragma unroll
         for (int q = 0; q < S4; ++q) a_nxt[q] = img[(size_t)tn * 64 * S4 + q];
         x0v[ft & 1] = *reinterpret_cast<const f32x4*>(alane + 4 * ft * Tp);
+        if constexpr (CUT) {
+          f32x4 up = zero4;
 #pragma unroll
-        for (int s = 0; s < S; ++s)
+          for (int s = P0; s < S; ++s) up = mfma(a_cur[s >> 2][s & 3], dcp[s - P0], up);
 #pragma unroll
-          for (int rt = 0; rt < RT; ++rt)
-            U[ft & 1][rt] = mfma(a_cur[s >> 2][s & 3], dc[s][rt], s == 0 ? zero4 : U[ft & 1][rt]);
+          for (int s = 0; s < SH; ++s)
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+              U[ft & 1][rt] = mfma(a_cur[s >> 2][s & 3], dc[s][rt], s == 0 ? up : U[ft & 1][rt]);
+        } else {
+#pragma unroll
+          for (int s = 0; s < S; ++s)
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+              U[ft & 1][rt] = mfma(a_cur[s >> 2][s & 3], dc[s][rt], s == 0 ? zero4 : U[ft & 1][rt]);
+        }
 #pragma unroll
         for (int q = 0; q < S4; ++q) a_cur[q] = a_nxt[q];
         ++t;
@@ -1017,10 +1047,10 @@ __device__ __forceinline__ void dw_body(const BwdIn& in, const DwArgs& aw, int b
   }
 }
 
-template <int NFT, int S>
+template <int NFT, int S, int SH, int P0>
 __global__ __launch_bounds__(256) void cin_bwd_dx2_mfma_kernel(BwdIn in, Dx2Args ax) {
   extern __shared__ float lds[];
-  dx2_body<NFT, S>(in, ax, blockIdx.x, lds);
+  dx2_body<NFT, S, SH, P0>(in, ax, blockIdx.x, lds);
 }
 
 template <int PT, int NT, int XU, int SD>
@@ -1261,12 +1291,26 @@ int bwd_mfma(const CinDims& c, const float* x0, const float* xk, const float* w,
                     dim3(256), 0, c, w, nft, nht, ntiles, wpk);
     }
     {
-#define CALL2(NF, SS_)                                                                                 \
+#define CALL2X(NF, SS_, SH_, P0_)                                                                      \
   do {                                                                                                 \
-    int rc = allow_lds(cin_bwd_dx2_mfma_kernel<NF, SS_>, dx2_lds);                                     \
+    int rc = allow_lds(cin_bwd_dx2_mfma_kernel<NF, SS_, SH_, P0_>, dx2_lds);                           \
     if (rc) return rc;                                                                                 \
-    XDFM_LAUNCH("cin_bwd_dx2_mfma_kernel<" #NF ", " #SS_ ">", st, (cin_bwd_dx2_mfma_kernel<NF, SS_>),  \
-                dim3((unsigned)n_dx), dim3(256), dx2_lds, in, ax);                                     \
+    XDFM_LAUNCH("cin_bwd_dx2_mfma_kernel<" #NF ", " #SS_ ", " #SH_ ">", st,                            \
+                (cin_bwd_dx2_mfma_kernel<NF, SS_, SH_, P0_>), dim3((unsigned)n_dx), dim3(256), dx2_lds, in, ax); \
+  } while (0)
+      // the hidden | pooled cut of the channel steps (dx2_body): n_hidden in 9..11 of up to 20 channels,
+      // or 5..7 of up to 12
+      const bool can_cut = d_pooled && (c.D & 3) == 0 && c.n_hidden > 0 && c.n_hidden < c.L;
+      const int shh = (c.n_hidden + 3) / 4, p0 = c.n_hidden / 4;
+      const bool cut5 = can_cut && SS == 5 && shh == 3 && p0 == 2, cut3 = can_cut && SS == 3 && shh == 2 && p0 == 1;
+#define CALL2(NF, SS_)                   \
+  do {                                   \
+    if (SS_ == 5 && cut5)                \
+      CALL2X(NF, 5, 3, 2);               \
+    else if (SS_ == 3 && cut3)           \
+      CALL2X(NF, 3, 2, 1);               \
+    else                                 \
+      CALL2X(NF, SS_, SS_, SS_);         \
   } while (0)
       if (nft <= 3) {
         if (SS == 3)
@@ -1279,6 +1323,7 @@ int bwd_mfma(const CinDims& c, const float* x0, const float* xk, const float* w,
         else
           CALL2(10, 5);
       }
+#undef CALL2X
 #undef CALL2
     }
   } else {
