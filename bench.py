@@ -300,7 +300,8 @@ def main():
         # HIP graph launch; N > 1 stays eager (split sizes of the all-to-all are host values)
         graphed = eng.capture_step(*resident[0])
         # the resident batches in the graph's input layout: handing one over is a single copy
-        packed = [graphed.pack(*r) for r in resident]
+        # (each with its successor's ids, which the replay sorts one step ahead)
+        packed = [graphed.pack(*r, next_ids=resident[(i + 1) % n_batches][2]) for i, r in enumerate(resident)]
 
     def step(i):
         if graphed is not None:

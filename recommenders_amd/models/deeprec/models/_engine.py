@@ -681,6 +681,24 @@ class XDeepFMEngine(object):
         b.src_N = 0
         return b
 
+    def make_batch_csr(self, labels, row_ptr, tok_row, ids, weights):
+        """Device tensors with the lookup's CSR offsets (row_ptr[B*F + 1]) and token rows already
+        built (the text reader's `row_ptr`, a GraphedStep's packed input) -> DeviceBatch; no kernel."""
+        b = DeviceBatch()
+        b.B = int(labels.numel())
+        b.nnz = int(ids.numel())
+        b.labels, b.ids, b.weights = labels, ids, weights
+        b.row_ptr, b.tok_row = row_ptr, tok_row
+        b.sorted_ids = b.sorted_tok = b.sorted_row = b.sorted_w = None
+        b.planned = b.planned_gather = False
+        b.plan_event = None
+        b.ready_event = torch.cuda.Event()
+        b.ready_event.record(torch.cuda.current_stream(self.device))
+        b.route = None
+        b.src_table = b.src_lin = b.src_ids = None
+        b.src_N = 0
+        return b
+
     def _plan_complete(self, batch):
         if not batch.planned:
             return False
@@ -1574,55 +1592,83 @@ class XDeepFMEngine(object):
         return auc, logloss, n_pos
 
 
+class PackedBatch(object):
+    """A batch in a GraphedStep's input layout: one flat device buffer (`buf`).  `ids_src` /
+    `next_src` name the tensors its ids and its announced successor's ids were copied from."""
+
+    __slots__ = ("buf", "ids_src", "next_src")
+
+    def __init__(self, buf, ids_src, next_src):
+        self.buf, self.ids_src, self.next_src = buf, ids_src, next_src
+
+
 class GraphedStep(object):
-    """A captured train step.  The graph reads its batch from one flat device buffer (labels,
-    indices, ids, weights at 256-byte aligned offsets), so handing it a batch is one copy:
-    run_packed(buf) for a batch already laid out by pack(), run(...) for four arrays.
+    """A captured train step.  The graph reads its batch from one flat device buffer -- labels, the CSR
+    offsets and token rows of the lookup (what the text reader hands over as `row_ptr`; built once
+    from the index array by pack() / run(), which also validates it), ids, weights and, with the
+    look-ahead below, the NEXT batch's ids, at 256-byte aligned offsets -- so handing it a batch is ONE
+    copy and nothing but the step's own kernels sits on the replay's chain (every small operation in
+    front of the forward pass costs the step about 8 us): run_packed(pack(...)) for a batch laid out
+    ahead of time, run(...) for four arrays.
 
     With the catch-up of sparse_rows the id sort is needed before the forward pass; the graph
-    therefore sorts the NEXT batch's ids beside this batch's compute (run_packed(buf, next_buf) /
-    run(..., next_ids=)): every replay still does one sort, one step ahead.  A batch that was not
-    announced that way is sorted eagerly in front of the replay."""
+    therefore sorts the NEXT batch's ids beside this batch's compute (pack(..., next_ids=) +
+    run_packed(pb, next_pb) / run(..., next_ids=)): every replay still does one sort, one step ahead.
+    A batch that was not announced that way is sorted eagerly in front of the replay."""
 
     def __init__(self, engine, labels, dnn_idx, ids, weights):
         self.engine = engine
-        srcs = (labels, dnn_idx, ids, weights)
-        self._layout = []
-        off = 0
-        for t in srcs:
-            nbytes = t.numel() * t.element_size()
-            self._layout.append((off, nbytes, t.dtype, tuple(t.shape)))
-            off += (nbytes + 255) // 256 * 256
-        self.flat = torch.empty((max(off, 256),), dtype=torch.uint8, device=engine.device)
-        self.inputs = [self.flat[o:o + n].view(dt).view(shape) for (o, n, dt, shape) in self._layout]
-        for dst, src in zip(self.inputs, srcs):
-            dst.copy_(src)
         if engine.kernel_events is not None:
             raise RuntimeError("kernel event hooks cannot be captured")
         self.lookahead = bool(engine.catchup_on)
-        self._planned_for = None  # data_ptr of the ids the graph's plan_next was sorted from
-        nnz = max(int(ids.numel()), 1)
+        dev = engine.device
+        B, nnz = int(labels.numel()), int(ids.numel())
+        self._B, self._nnz = B, nnz
+        self._idx_shape, self._idx_dtype = tuple(dnn_idx.shape), dnn_idx.dtype
+        fields = [("labels", labels.dtype, tuple(labels.shape)),
+                  ("row_ptr", torch.int32, (B * engine.F + 1,)),
+                  ("tok_row", torch.int32, (max(nnz, 1),)),
+                  ("ids", ids.dtype, tuple(ids.shape)),
+                  ("weights", weights.dtype, tuple(weights.shape))]
         if self.lookahead:
-            dev = engine.device
-            self.next_ids = self.inputs[2].clone()  # always ids of a real batch: the replay sorts and reads rows by them
-            self.plan_cur = [torch.empty((nnz,), dtype=torch.int32, device=dev) for _ in range(2)]
-            self.plan_next = [torch.empty((nnz,), dtype=torch.int32, device=dev) for _ in range(2)]
+            fields.append(("next_ids", ids.dtype, tuple(ids.shape)))
+        self._layout = {}
+        off = 0
+        for name, dt, shape in fields:
+            n = 1
+            for d in shape:
+                n *= int(d)
+            nbytes = n * torch.empty((), dtype=dt).element_size()
+            self._layout[name] = (off, nbytes, dt, shape)
+            off += (nbytes + 255) // 256 * 256
+        self.flat = torch.empty((max(off, 256),), dtype=torch.uint8, device=dev)
+        self.views = self._views(self.flat)
+        self._fill(self.views, labels, dnn_idx, ids, weights, ids)
+        self._planned_for = None  # what the graph's plan_next was sorted from (PackedBatch / ids tensor)
+        if self.lookahead:
+            self.next_ids = self.views["next_ids"]  # always ids of a real batch: the replay sorts and reads rows by them
+            n1 = max(nnz, 1)
+            # (sorted ids, sorted token positions) as the two rows of one array: one copy hands the
+            # look-ahead sort's result to the step that uses it
+            self._plan_cur2 = torch.empty((2, n1), dtype=torch.int32, device=dev)
+            self._plan_next2 = torch.empty((2, n1), dtype=torch.int32, device=dev)
+            self.plan_cur = [self._plan_cur2[0], self._plan_cur2[1]]
+            self.plan_next = [self._plan_next2[0], self._plan_next2[1]]
         # warm up on a side stream (allocations, lazy module loads), as torch asks before a capture
-        s = torch.cuda.Stream(device=engine.device)
-        s.wait_stream(torch.cuda.current_stream(engine.device))
+        s = torch.cuda.Stream(device=dev)
+        s.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(s):
-            engine.train_step(engine.make_batch(*self.inputs))
-        torch.cuda.current_stream(engine.device).wait_stream(s)
-        torch.cuda.synchronize(engine.device)
+            engine.train_step(self._batch_of_views())
+        torch.cuda.current_stream(dev).wait_stream(s)
+        torch.cuda.synchronize(dev)
         engine.check_errors()
         self._ws_token = engine._ws_token
         mirrors = (engine.step, engine.b1p, engine.b2p)
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
-            self.batch = engine.make_batch(*self.inputs)
+            self.batch = self._batch_of_views()
             if self.lookahead:
-                for dst, src in zip(self.plan_cur, self.plan_next):
-                    dst.copy_(src)
+                self._plan_cur2.copy_(self._plan_next2)
                 self.batch.sorted_ids, self.batch.sorted_tok = self.plan_cur
                 self.batch.planned = True
                 engine._announced = self.batch  # its rows were caught up by the replay before (or eagerly)
@@ -1638,43 +1684,71 @@ class GraphedStep(object):
         engine.step, engine.b1p, engine.b2p = mirrors
         engine._announced = None
 
-    def pack(self, labels, dnn_idx, ids, weights):
-        """The four arrays of a batch in the graph's input layout (a new device buffer)."""
-        buf = torch.empty_like(self.flat)
-        for (o, n, dt, shape), src in zip(self._layout, (labels, dnn_idx, ids, weights)):
+    def _views(self, flat):
+        return {name: flat[o:o + n].view(dt).view(shape) for name, (o, n, dt, shape) in self._layout.items()}
+
+    def _batch_of_views(self):
+        v = self.views
+        return self.engine.make_batch_csr(v["labels"], v["row_ptr"], v["tok_row"], v["ids"], v["weights"])
+
+    def _check(self, labels, dnn_idx, ids, weights):
+        for name, src in (("labels", labels), ("ids", ids), ("weights", weights)):
+            _, _, dt, shape = self._layout[name]
             if tuple(src.shape) != shape or src.dtype != dt:
                 raise ValueError("batch array %s/%s does not match the captured shape %s/%s"
                                  % (tuple(src.shape), src.dtype, shape, dt))
-            buf[o:o + n].view(dt).view(shape).copy_(src)
-        return buf
+        if tuple(dnn_idx.shape) != self._idx_shape or dnn_idx.dtype != self._idx_dtype:
+            raise ValueError("batch array %s/%s does not match the captured shape %s/%s"
+                             % (tuple(dnn_idx.shape), dnn_idx.dtype, self._idx_shape, self._idx_dtype))
 
-    def _ids_of(self, buf):
-        o, n, dt, shape = self._layout[2]
-        return buf[o:o + n].view(dt).view(shape)
+    def _fill(self, views, labels, dnn_idx, ids, weights, next_ids):
+        """The arrays of a batch into the views of a flat buffer; the CSR offsets / token rows are
+        built from the index array here (xdfm_build_row_ptr, which also flags bad indices)."""
+        eng = self.engine
+        views["labels"].copy_(labels)
+        views["ids"].copy_(ids)
+        views["weights"].copy_(weights)
+        _lib.check(eng.lib.xdfm_build_row_ptr(_ptr(dnn_idx), self._nnz, self._B * eng.F, _ptr(views["row_ptr"]),
+                                              _ptr(views["tok_row"]), _ptr(eng.err_flag), eng._stream()))
+        if "next_ids" in views:
+            views["next_ids"].copy_(next_ids if next_ids is not None else ids)
 
-    def _replay(self, cur_ids, next_ids):
+    def pack(self, labels, dnn_idx, ids, weights, next_ids=None):
+        """A batch in the graph's input layout (a new device buffer).  next_ids: the ids of the batch
+        that will be announced as this one's successor (run_packed(pb, next_pb)); without them the
+        successor's ids are copied at run time."""
+        self._check(labels, dnn_idx, ids, weights)
+        buf = torch.empty_like(self.flat)
+        self._fill(self._views(buf), labels, dnn_idx, ids, weights, next_ids)
+        return PackedBatch(buf, ids, next_ids)
+
+    def _replay(self, cur_key, next_key, next_ids):
+        """cur_key / next_key: what identifies this batch and its announced successor (the objects
+        the caller passed); next_ids: the successor's ids when the graph's buffer does not hold them
+        yet (None: it does, or nothing is announced)."""
         eng = self.engine
         if eng._ws_token != self._ws_token:
             raise RuntimeError("the engine's workspace was re-allocated after this step was captured "
                                "(a larger batch went through the engine): capture it again")
         if self.lookahead:
-            if eng._announced is not self._nb or self._planned_for != cur_ids.data_ptr():
+            if eng._announced is not self._nb or self._planned_for is not cur_key:
                 # not announced by the replay before: take back whatever was, then sort and catch up now,
                 # into the buffer the graph copies from
                 if eng._announced is not None:
                     eng.catchup(eng._announced.sorted_ids, eng._announced.nnz, -1)
                 ws = eng.ws["plan_ws"]
-                n = int(self.inputs[2].numel())
-                _lib.check(eng.lib.xdfm_embed_plan(_ptr(self.inputs[2]), n, eng.N, _ptr(self.plan_next[0]),
+                n = int(self.views["ids"].numel())
+                _lib.check(eng.lib.xdfm_embed_plan(_ptr(self.views["ids"]), n, eng.N, _ptr(self.plan_next[0]),
                                                    _ptr(self.plan_next[1]), _ptr(ws), ws.numel(), eng._stream()))
                 eng.catchup(self.plan_next[0], n, 1)
-            if next_ids is not None:
-                self.next_ids.copy_(next_ids, non_blocking=True)
-                self._planned_for = next_ids.data_ptr()
+            if next_key is not None:
+                if next_ids is not None:
+                    self.next_ids.copy_(next_ids, non_blocking=True)
+                self._planned_for = next_key
             else:
                 # nothing announced: the replay's look-ahead prepares this batch's own rows again
                 # (valid ids, nothing to bring forward; the marks are taken back by the next call)
-                self.next_ids.copy_(cur_ids, non_blocking=True)
+                self.next_ids.copy_(self.views["ids"], non_blocking=True)
                 self._planned_for = None
             eng._announced = self._nb
         self.graph.replay()
@@ -1682,11 +1756,14 @@ class GraphedStep(object):
         eng._rows_stale = eng.catchup_on
         return self.loss, self.data_loss
 
-    def run_packed(self, buf, next_buf=None):
-        self.flat.copy_(buf, non_blocking=True)
-        return self._replay(self._ids_of(buf), self._ids_of(next_buf) if next_buf is not None else None)
+    def run_packed(self, pb, next_pb=None):
+        self.flat.copy_(pb.buf, non_blocking=True)
+        next_ids = None
+        if self.lookahead and next_pb is not None and (pb.next_src is None or pb.next_src is not next_pb.ids_src):
+            next_ids = self._views(next_pb.buf)["ids"]  # not packed with this successor's ids
+        return self._replay(pb, next_pb, next_ids)
 
     def run(self, labels, dnn_idx, ids, weights, next_ids=None):
-        for dst, src in zip(self.inputs, (labels, dnn_idx, ids, weights)):
-            dst.copy_(src, non_blocking=True)
-        return self._replay(ids, next_ids)
+        self._check(labels, dnn_idx, ids, weights)
+        self._fill(self.views, labels, dnn_idx, ids, weights, next_ids)
+        return self._replay(ids, next_ids, None)

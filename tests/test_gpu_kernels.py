@@ -274,7 +274,10 @@ def test_graphed_sparse_rows_step_sorts_one_batch_ahead_and_equals_eager():
     eager, graph = load_engine(hp, p32, "sparse_rows"), load_engine(hp, p32, "sparse_rows")
     eager.train_step(upload(eager, batches[0]))
     gs = graph.capture_step(*dev(batches[0]))  # runs batch 0 once while warming up
-    packed = [gs.pack(*dev(b)) for b in batches]
+    devs = [dev(b) for b in batches]
+    # odd batches carry their successor's ids in the packed buffer (one copy per step), even ones do not
+    # (the successor's ids are copied at run time)
+    packed = [gs.pack(*devs[k], next_ids=devs[k + 1][2] if (k % 2 == 1 and k + 1 < 9) else None) for k in range(9)]
     for k in range(1, 9):
         le = float(eager.train_step(upload(eager, batches[k]))[0])
         # batches 1-4 announce their successor, 5 does not (eager sort in front of the replay), 6-8 do
