@@ -256,8 +256,6 @@ class ShardedXDeepFMEngine(XDeepFMEngine):
                  force_collectives=False, compute_dtype=None):
         self.exchange = RowShardExchange(group, virtual_world=virtual_world, force_collectives=force_collectives)
         self.world, self.rank = self.exchange.world, self.exchange.rank
-        if hp.loss == "square_loss":
-            raise ValueError("square_loss (a root of a mean) cannot be split over ranks")
         if hp.enable_BN is True:
             raise NotImplementedError("batch statistics over a batch split between ranks are not built")
         if embedding_update == "dense_exact":
@@ -278,6 +276,12 @@ class ShardedXDeepFMEngine(XDeepFMEngine):
         # forward + backward + per-slot gradients have fixed shapes once the rows are fetched:
         # they replay as one HIP graph between the (variable-size) exchanges
         self.graph_local = True
+        # square_loss is a root of a mean over the GLOBAL batch: the ranks' sums of squares meet in an
+        # all-reduce between the forward and the backward pass (_square_loss_global), so that span
+        # cannot be one graph
+        self._square = hp.loss == "square_loss"
+        if self._square and self.exchange.collective:
+            self.graph_local = False
         self._local_graphs = {}
 
     # ------------------------------------------------------------------ helpers
@@ -477,9 +481,11 @@ class ShardedXDeepFMEngine(XDeepFMEngine):
         is the global mean loss (regularisation counted once, on rank 0's share).
         next_batch: the batch the next call will get: its routing is started beside this step's
         compute (prefetch_route)."""
-        self.mean_count = batch.B * self.world
+        # (square_loss: every rank first forms its own root mean square and gradient, see below)
+        self.mean_count = batch.B if self._square else batch.B * self.world
         self._ensure_ws(batch.B, batch.nnz)
         g = None
+        rmse = None
         if self.graph_local and self.kernel_events is None and batch.nnz > 0:
             g = self._local_graph(batch)  # None: too many shapes seen, stay eager
         if g is not None:
@@ -505,6 +511,7 @@ class ShardedXDeepFMEngine(XDeepFMEngine):
                 batch.src_table, batch.src_lin, batch.src_ids = g.src_table, g.src_lin, g.src_ids
                 batch.src_N = max(batch.nnz, 1)
                 self.forward(batch, with_loss=True, with_grad=True)
+                rmse = self._square_loss_global(batch)
                 self.backward(batch)
                 self.prefetch_route(next_batch)
                 self._advance_step()
@@ -512,6 +519,7 @@ class ShardedXDeepFMEngine(XDeepFMEngine):
         else:
             self.fetch_rows(batch)
             self.forward(batch, with_loss=True, with_grad=True)
+            rmse = self._square_loss_global(batch)
             self.backward(batch)
             self.prefetch_route(next_batch)
             self._advance_step()
@@ -525,8 +533,33 @@ class ShardedXDeepFMEngine(XDeepFMEngine):
         done = torch.cuda.Event()
         done.record(torch.cuda.current_stream(self.device))
         self._gen_free[batch.route.gen] = done
+        if self._square and self.exchange.collective and rmse is not None:
+            self.data_loss.copy_(rmse / self.world)  # shares that add up to the global root mean square
         reg = self.reg_loss if self.rank == 0 else torch.zeros_like(self.reg_loss)
         return (self.data_loss + reg)[0], self.data_loss[0].clone()
+
+    def _square_loss_global(self, batch):
+        """square_loss over a batch split between ranks: loss = sqrt(sum over ALL samples of (p - y)^2 /
+        B_global) and d loss / d logit_i = (p_i - y_i) p'_i / (B_global loss).  The forward pass has left this
+        rank's per-block sums of squares in loss_scratch and the LOCAL gradient (p_i - y_i) p'_i /
+        (B_local rmse_local) in g_logit (and, through the CIN head, in d_pooled, which is linear in it):
+        one scalar all-reduce gives the global sum, and both arrays are scaled by
+        (B_local rmse_local) / (B_global rmse_global).  Returns the global loss (a device scalar), or
+        None when nothing is split."""
+        if not (self._square and self.exchange.collective):
+            return None
+        B = batch.B
+        blocks = min((B + 255) // 256, 1024)
+        sse = self.loss_scratch[:blocks].sum().reshape(1)
+        tot = sse.clone()
+        self.exchange.all_reduce(tot)
+        rmse_l = torch.sqrt(sse / B)
+        rmse_g = torch.sqrt(tot / (B * self.world))
+        factor = torch.where(rmse_g > 0, rmse_l / (self.world * rmse_g), torch.zeros_like(rmse_g))
+        self.ws["g_logit"][:B].mul_(factor)
+        if self.hp.use_CIN_part:
+            self.ws["d_pooled"][:B].mul_(factor)
+        return rmse_g
 
     def predict_batch(self, batch):
         self.flush_rows()

@@ -97,7 +97,7 @@ def _free_port():
     return port
 
 
-def _two_rank_worker(rank, world, port, optimizer, out):
+def _two_rank_worker(rank, world, port, optimizer, loss, out):
     """One rank of a real multi-process step.  The ranks share cuda:0 (a one-GPU box) and talk
     over gloo with host-staged exchanges; everything else is the code of an N-GPU run."""
     import os
@@ -111,7 +111,8 @@ def _two_rank_worker(rank, world, port, optimizer, out):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        hp = make_hp(optimizer=optimizer, learning_rate=0.01, FEATURE_COUNT=301, cross_l2=0.01, cross_l1=0.001)
+        hp = make_hp(optimizer=optimizer, learning_rate=0.01, FEATURE_COUNT=301, cross_l2=0.01, cross_l1=0.001,
+                     loss=loss)
         F, N = hp.FIELD_COUNT, hp.FEATURE_COUNT
         p32 = X.init_params(hp, seed=9)
         eng = ShardedXDeepFMEngine(hp, seed=7)
@@ -159,18 +160,19 @@ def _two_rank_worker(rank, world, port, optimizer, out):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("optimizer", ["adam", "adagrad"])
-def test_two_ranks_sharing_the_gpu_match_the_oracle_on_the_global_batch(optimizer):
+@pytest.mark.parametrize("optimizer,loss", [("adam", "log_loss"), ("adagrad", "log_loss"), ("adam", "square_loss")])
+def test_two_ranks_sharing_the_gpu_match_the_oracle_on_the_global_batch(optimizer, loss):
     """world_size 2, one process per rank: ids to their owners, rows back, gradient rows to the
     owners, owner-side update, dense all-reduce -- against the oracle stepping on the
-    concatenated batch.  (RCCL needs one GPU per rank; the driver's scaling bench is that run.)"""
+    concatenated batch.  square_loss (a root of a mean over the GLOBAL batch) adds one scalar all-reduce
+    between the forward and the backward pass.  (RCCL needs one GPU per rank; the driver's scaling bench is that run.)"""
     import torch.multiprocessing as mp
 
     world = 2
     ctx = mp.get_context("spawn")
     out = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_two_rank_worker, args=(r, world, port, optimizer, out)) for r in range(world)]
+    procs = [ctx.Process(target=_two_rank_worker, args=(r, world, port, optimizer, loss, out)) for r in range(world)]
     for p in procs:
         p.start()
     res = [out.get(timeout=110) for _ in procs]
