@@ -119,6 +119,9 @@ CONFIGS = {
     "softmax_acts": dict(cross_activation="softmax", FIELD_COUNT=9, dim=8, cross_layer_sizes=[12, 8, 6],
                          layer_sizes=[10, 7], activation=["softmax", "relu"], loss="cross_entropy_loss"),
     # more than 40 fields: the input-gradient kernel's first form and the wide staging of the filter gradient
+    # dim 32: four 8-row stages per sample in the filter gradient's hidden | pooled cut
+    "dim32": dict(FIELD_COUNT=6, dim=32, FEATURE_COUNT=400, cross_layer_sizes=[20, 6], layer_sizes=[12],
+                  activation=["relu"], dropout=[0.0]),
     "many_fields": dict(FIELD_COUNT=45, dim=4, FEATURE_COUNT=2000, cross_layer_sizes=[8, 4],
                         layer_sizes=[16], activation=["relu"], dropout=[0.0]),
 }
@@ -354,7 +357,10 @@ def test_cin_pooled_entry_points_match_float64(B, F, H, D, L, acc):
     g = torch.Generator(device="cuda").manual_seed(1)
     x0 = torch.randn(B, F, D, device="cuda", generator=g)
     xk = torch.randn(B, H, D, device="cuda", generator=g)
-    w = torch.randn(F * H, L, device="cuda", generator=g) * 0.1
+    # the filter (and its gradient) as the leading columns of a wider array when B is odd: row stride ldw > L
+    ldw = L + 3 if B % 2 else 0
+    w_full = torch.randn(F * H, ldw or L, device="cuda", generator=g) * 0.1
+    w = w_full[:, :L]
     off, stride = 3, L + 5
     pooled = torch.full((B, stride), 7.0, device="cuda")
     d_pooled = torch.randn(B, stride, device="cuda", generator=g)
@@ -362,20 +368,22 @@ def test_cin_pooled_entry_points_match_float64(B, F, H, D, L, acc):
     _lib.check(lib.xdfm_cin_pooled_workspace_floats(B, F, H, D, L, ctypes.byref(n)))
     assert n.value > 0
     work = torch.empty(n.value, device="cuda")
-    _lib.check(lib.xdfm_cin_pooled_fwd(_ptr(x0), _ptr(xk), _ptr(w), B, F, H, D, L, 0, _ptr(pooled), stride, off, None))
+    _lib.check(lib.xdfm_cin_pooled_fwd(_ptr(x0), _ptr(xk), _ptr(w_full), B, F, H, D, L, ldw, _ptr(pooled), stride, off,
+                                       None))
     base = torch.randn(B, F, D, device="cuda", generator=g)
     d_x0 = base.clone() if acc else torch.full((B, F, D), 9.0, device="cuda")
     d_xk = torch.full((B, H, D), 9.0, device="cuda")
-    d_w = torch.full((F * H, L), 5.0, device="cuda")
-    _lib.check(lib.xdfm_cin_pooled_bwd(_ptr(x0), _ptr(xk), _ptr(w), _ptr(d_pooled), stride, off, B, F, H, D, L, 0,
-                                       _ptr(d_xk), _ptr(d_x0), acc, _ptr(d_w), _ptr(work), None))
+    d_w_full = torch.full((F * H, ldw or L), 5.0, device="cuda")
+    d_w = d_w_full[:, :L]
+    _lib.check(lib.xdfm_cin_pooled_bwd(_ptr(x0), _ptr(xk), _ptr(w_full), _ptr(d_pooled), stride, off, B, F, H, D, L, ldw,
+                                       _ptr(d_xk), _ptr(d_x0), acc, _ptr(d_w_full), _ptr(work), None))
     torch.cuda.synchronize()
     if B == 0:
         assert bool((d_w == 0).all())
         return
     a = x0.double().requires_grad_(True)
     c = xk.double().requires_grad_(True)
-    W = w.double().view(F, H, L).clone().requires_grad_(True)
+    W = w.double().reshape(F, H, L).clone().requires_grad_(True)
     y = torch.einsum("bfd,bhd,fhn->bn", a, c, W)
     y.backward(d_pooled[:, off:off + L].double())
 
@@ -386,7 +394,8 @@ def test_cin_pooled_entry_points_match_float64(B, F, H, D, L, acc):
     assert bool((pooled[:, :off] == 7).all()) and bool((pooled[:, off + L:] == 7).all())
     assert rel(d_x0, a.grad + (base.double() if acc else 0)) < 2e-6
     assert rel(d_xk, c.grad) < 2e-6
-    assert rel(d_w.view(F, H, L), W.grad) < 2e-6
+    assert rel(d_w.reshape(F, H, L), W.grad) < 2e-6
+    assert bool((d_w_full[:, L:] == 5).all())  # columns past L belong to somebody else
 
 
 def test_cin_pooled_refuses_what_it_does_not_serve():
