@@ -419,6 +419,21 @@ int xdfm_cin_pooled_workspace_floats(int64_t B, int32_t F, int32_t H, int32_t D,
 int xdfm_cin_pooled_fwd(const float* x0, const float* xk, const float* w, int64_t B, int32_t F, int32_t H,
                         int32_t D, int32_t L, int32_t ldw, float* pooled, int32_t pool_stride, int32_t pool_off,
                         void* stream);
+/* xdfm_cin_pooled_fwd with the rest of a training step's forward pass in the same launch: the CIN head over
+ * pooled[B, n] (n = pooled channels of ALL layers = the row length of pooled and d_pooled; the other layers'
+ * channels must be there already), logit, pred, g_logit, cin_out, d_pooled as xdfm_head_loss computes them
+ * (log_loss / cross_entropy_loss; the same expressions, the head's two sums as wave sums).  The mean of the
+ * loss is left as *n_partial per-block sums in scratch[<= 1024]: xdfm_loss_finish_partials(scratch, n_partial,
+ * mean_count or B, loss, stream) adds them in index order, on any stream ordered after this call.  At most
+ * 16384 samples per call.  No counterpart in the reference (one sess.run there). */
+int xdfm_cin_pooled_fwd_head(const float* x0, const float* xk, const float* w, int64_t B, int32_t F, int32_t H,
+                             int32_t D, int32_t L, int32_t ldw, float* pooled, int32_t pool_off,
+                             const float* part0, const float* part1, const float* part3, const float* bias,
+                             const float* head_w, const float* head_b, int32_t n, const float* labels,
+                             int64_t mean_count, int32_t classification, int32_t loss_kind, float* logit,
+                             float* pred, float* cin_out, float* g_logit, float* d_pooled, float* scratch,
+                             int32_t* n_partial, void* stream);
+int xdfm_loss_finish_partials(const float* scratch, int32_t n_partial, int64_t count, float* loss, void* stream);
 int xdfm_cin_pooled_bwd(const float* x0, const float* xk, const float* w, const float* d_pooled,
                         int32_t pool_stride, int32_t pool_off, int64_t B, int32_t F, int32_t H, int32_t D,
                         int32_t L, int32_t ldw, float* d_xk, float* d_x0, int32_t accumulate_x0, float* d_w,

@@ -134,6 +134,9 @@ SIGNATURES = {
     "xdfm_cin_bf16_bwd_dw": [_P, _P, _P, _I64, _I32, _I32, _I32, _I32, _I32, _P, _I32, _P, _P],
     "xdfm_cin_pooled_workspace_floats": [_I64, _I32, _I32, _I32, _I32, _PSZ],
     "xdfm_cin_pooled_fwd": [_P, _P, _P, _I64, _I32, _I32, _I32, _I32, _I32, _P, _I32, _I32, _P],
+    "xdfm_cin_pooled_fwd_head": [_P, _P, _P, _I64, _I32, _I32, _I32, _I32, _I32, _P, _I32, _P, _P, _P, _P, _P, _P,
+                                 _I32, _P, _I64, _I32, _I32, _P, _P, _P, _P, _P, _P, _P, _P],
+    "xdfm_loss_finish_partials": [_P, _I32, _I64, _P, _P],
     "xdfm_cin_pooled_bwd": [_P, _P, _P, _P, _I32, _I32, _I64, _I32, _I32, _I32, _I32, _I32, _P, _P, _I32, _P, _P, _P],
     "xdfm_cin_pool_pack": [_P, _I32, _I32, _I32, _I32, _I32, _P, _P],
     "xdfm_cin_pool_unpack": [_P, _I32, _I32, _I32, _I32, _I32, _P, _P],

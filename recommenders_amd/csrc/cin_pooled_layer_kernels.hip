@@ -23,6 +23,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <cstring>
 
 #include "xdfm_common.h"
 
@@ -153,12 +154,35 @@ __device__ __forceinline__ void pair_sums(const f32x4 (&xa)[T], const f32x4& xb,
     for (int t = 0; t < T; ++t) S[t] = mfma(b[s], xa[t][s], S[t]);
 }
 
-template <int T, int LN>
+// HEAD: the rest of the forward pass in the same launch (xdfm_head_loss's arithmetic, one sample per wave
+// pass instead of one per thread): the CIN head over the pooled channels of ALL layers (the other layers'
+// were written by their kernels before), the logit, the prediction, the sample's loss term, d loss / d logit
+// and d_pooled.  The mean of the loss is left as one partial sum per block (xdfm_loss_finish_partials).
+struct PoolHead {
+  const float *lin, *fm, *dnn, *bias;  // parts of the logit beside the CIN's (null: absent); bias goes with lin
+  const float *head_w, *head_b, *labels;
+  int n_total;  // pooled channels of all layers = row length of pooled / d_pooled (<= 64)
+  float inv_count;
+  int classification, loss_kind;
+  float *cin_out, *logit, *pred, *g_logit, *d_pooled, *partial;
+};
+
+constexpr float kLogEps = 1e-7f;  // tf.compat.v1.losses.log_loss default epsilon
+
+__device__ __forceinline__ float sigmoidf(float z) {
+  // same split as Eigen's logistic: no overflow for large |z|
+  if (z >= 0.f) return 1.f / (1.f + expf(-z));
+  const float e = expf(z);
+  return e / (1.f + e);
+}
+
+template <int T, int LN, bool HEAD>
 __global__ __launch_bounds__(256, (T * LN <= 30 ? 2 : 1)) void cin_pooled_fwd_kernel(
     PoolDims c, const float* __restrict__ x0, const float* __restrict__ xk, const float* __restrict__ w,
-    float* __restrict__ pooled, int pool_stride, int pool_off) {
+    float* __restrict__ pooled, int pool_stride, int pool_off, PoolHead hd) {
   extern __shared__ __align__(16) float lds[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float loss_acc = 0.f;  // HEAD: this wave's loss terms, in sample order
   const int FD = c.F * c.D, HD = c.H * c.D;
   int oa[T], ob;
   bool live_cols;
@@ -199,6 +223,57 @@ __global__ __launch_bounds__(256, (T * LN <= 30 ? 2 : 1)) void cin_pooled_fwd_ke
       if (lane == n) mine = v;
     }
     if (b < c.B && lane < c.L) pooled[b * pool_stride + pool_off + lane] = mine;
+    if constexpr (HEAD) {
+      // lane j < n_total holds pooled channel j of the sample: this layer's from the sums above
+      const int src = lane - pool_off;
+      const float own = __shfl(mine, src < 0 ? 0 : (src > 63 ? 63 : src));
+      if (b < c.B) {  // (wave-uniform)
+        float r = 0.f, wj = 0.f;
+        if (lane < hd.n_total) {
+          wj = hd.head_w[lane];
+          r = (src >= 0 && src < c.L) ? own : pooled[b * pool_stride + lane];
+        }
+        const float base = wave_sum(r), dot = wave_sum(r * wj);
+        const float cin = base + (dot + hd.head_b[0]);
+        float z = 0.f;
+        bool first = true;
+        if (hd.lin) {
+          z = hd.lin[b] + (hd.bias ? hd.bias[0] : 0.f);
+          first = false;
+        }
+        if (hd.fm) {
+          z = first ? hd.fm[b] : z + hd.fm[b];
+          first = false;
+        }
+        z = first ? cin : z + cin;
+        if (hd.dnn) z = z + hd.dnn[b];
+        const float p = hd.classification ? sigmoidf(z) : z;
+        const float y = hd.labels[b];
+        const float dp_dz = hd.classification ? p * (1.f - p) : 1.f;
+        float g;
+        if (hd.loss_kind == XDFM_LOSS_LOG) {
+          loss_acc += -y * logf(p + kLogEps) - (1.f - y) * logf(1.f - p + kLogEps);
+          g = (-y / (p + kLogEps) + (1.f - y) / (1.f - p + kLogEps)) * dp_dz * hd.inv_count;
+        } else {  // XDFM_LOSS_CROSS_ENTROPY
+          loss_acc += fmaxf(z, 0.f) - z * y + log1pf(expf(-fabsf(z)));
+          g = (sigmoidf(z) - y) * hd.inv_count;
+        }
+        if (lane == 0) {
+          hd.cin_out[b] = cin;
+          hd.logit[b] = z;
+          hd.pred[b] = p;
+          hd.g_logit[b] = g;
+        }
+        if (lane < hd.n_total) hd.d_pooled[b * hd.n_total + lane] = g + g * wj;
+      }
+    }
+  }
+  if constexpr (HEAD) {
+    // the block's share of the loss sum: its waves in wave order (the filter image in LDS is dead)
+    __syncthreads();
+    if (lane == 0) lds[wave] = loss_acc;
+    __syncthreads();
+    if (threadIdx.x == 0) hd.partial[blockIdx.x] = ((lds[0] + lds[1]) + lds[2]) + lds[3];
   }
 }
 
@@ -445,27 +520,28 @@ size_t lds_bytes(const PoolDims& c, bool bwd) {
 // kernels by (tiles of 16 fields, channels): a lane's registers hold 4 T LN filter values (and, backward,
 // as many gradient sums)
 template <int T, int LN>
-const void* kernel_of(bool bwd) {
+const void* kernel_of(bool bwd, bool head) {
   if constexpr (4 * T * LN > kMaxRegs) return nullptr;  // not served (supported())
   else return bwd ? reinterpret_cast<const void*>(cin_pooled_bwd_kernel<T, LN>)
-             : reinterpret_cast<const void*>(cin_pooled_fwd_kernel<T, LN>);
+                  : (head ? reinterpret_cast<const void*>(cin_pooled_fwd_kernel<T, LN, true>)
+                          : reinterpret_cast<const void*>(cin_pooled_fwd_kernel<T, LN, false>));
 }
 template <int T>
-const void* pick_l(int LN, bool bwd) {
+const void* pick_l(int LN, bool bwd, bool head) {
   switch (LN) {
-    case 4: return kernel_of<T, 4>(bwd);
-    case 8: return kernel_of<T, 8>(bwd);
-    case 10: return kernel_of<T, 10>(bwd);
-    case 12: return kernel_of<T, 12>(bwd);
-    default: return kernel_of<T, 16>(bwd);
+    case 4: return kernel_of<T, 4>(bwd, head);
+    case 8: return kernel_of<T, 8>(bwd, head);
+    case 10: return kernel_of<T, 10>(bwd, head);
+    case 12: return kernel_of<T, 12>(bwd, head);
+    default: return kernel_of<T, 16>(bwd, head);
   }
 }
-const void* pick(int F, int L, bool bwd) {
+const void* pick(int F, int L, bool bwd, bool head = false) {
   switch (tiles_for(F)) {
-    case 1: return pick_l<1>(ln_for(L), bwd);
-    case 2: return pick_l<2>(ln_for(L), bwd);
-    case 3: return pick_l<3>(ln_for(L), bwd);
-    default: return pick_l<4>(ln_for(L), bwd);
+    case 1: return pick_l<1>(ln_for(L), bwd, head);
+    case 2: return pick_l<2>(ln_for(L), bwd, head);
+    case 3: return pick_l<3>(ln_for(L), bwd, head);
+    default: return pick_l<4>(ln_for(L), bwd, head);
   }
 }
 
@@ -483,24 +559,74 @@ extern "C" int xdfm_cin_pooled_workspace_floats(int64_t B, int32_t F, int32_t H,
   return XDFM_OK;
 }
 
-extern "C" int xdfm_cin_pooled_fwd(const float* x0, const float* xk, const float* w, int64_t B, int32_t F,
-                                   int32_t H, int32_t D, int32_t L, int32_t ldw, float* pooled,
-                                   int32_t pool_stride, int32_t pool_off, void* stream) {
-  XDFM_REQUIRE(supported(F, H, D, L),
-               "xdfm_cin_pooled_fwd: shape not served (xdfm_cin_pooled_workspace_floats says 0)");
-  XDFM_REQUIRE(B >= 0, "xdfm_cin_pooled_fwd: bad sizes");
+namespace {
+int launch_fwd(const char* who, const float* x0, const float* xk, const float* w, int64_t B, int F, int H, int D,
+               int L, int ldw, float* pooled, int pool_stride, int pool_off, const PoolHead* head, void* stream) {
+  XDFM_REQUIRE(supported(F, H, D, L), "%s: shape not served (xdfm_cin_pooled_workspace_floats says 0)", who);
+  XDFM_REQUIRE(B >= 0, "%s: bad sizes", who);
   if (B == 0) return XDFM_OK;
-  XDFM_REQUIRE(x0 && xk && w && pooled, "xdfm_cin_pooled_fwd: null argument");
+  XDFM_REQUIRE(x0 && xk && w && pooled, "%s: null argument", who);
   const PoolDims c = make(B, F, H, D, L, ldw);
   const size_t lds = lds_bytes(c, false);
-  const void* fn = pick(F, L, false);
+  const void* fn = pick(F, L, false, head != nullptr);
   if (lds > 64 * 1024) XDFM_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  PoolHead hd;
+  memset(&hd, 0, sizeof(hd));
+  if (head) hd = *head;
   {
-    xdfm::ProfScope prof("cin_pooled_fwd_kernel", stream);
-    void* args[] = {(void*)&c, (void*)&x0, (void*)&xk, (void*)&w, (void*)&pooled, (void*)&pool_stride, (void*)&pool_off};
+    xdfm::ProfScope prof(head ? "cin_pooled_fwd_head_kernel" : "cin_pooled_fwd_kernel", stream);
+    void* args[] = {(void*)&c,      (void*)&x0,          (void*)&xk,       (void*)&w,
+                    (void*)&pooled, (void*)&pool_stride, (void*)&pool_off, (void*)&hd};
     XDFM_HIP(hipLaunchKernel(fn, dim3(n_blocks(B, kSpwFwd)), dim3(256), args, lds, (hipStream_t)stream));
   }
   return XDFM_OK;
+}
+}  // namespace
+
+extern "C" int xdfm_cin_pooled_fwd(const float* x0, const float* xk, const float* w, int64_t B, int32_t F,
+                                   int32_t H, int32_t D, int32_t L, int32_t ldw, float* pooled,
+                                   int32_t pool_stride, int32_t pool_off, void* stream) {
+  return launch_fwd("xdfm_cin_pooled_fwd", x0, xk, w, B, F, H, D, L, ldw, pooled, pool_stride, pool_off, nullptr,
+                    stream);
+}
+
+extern "C" int xdfm_cin_pooled_fwd_head(const float* x0, const float* xk, const float* w, int64_t B, int32_t F,
+                                        int32_t H, int32_t D, int32_t L, int32_t ldw, float* pooled,
+                                        int32_t pool_off, const float* part0, const float* part1,
+                                        const float* part3, const float* bias, const float* head_w,
+                                        const float* head_b, int32_t n, const float* labels, int64_t mean_count,
+                                        int32_t classification, int32_t loss_kind, float* logit, float* pred,
+                                        float* cin_out, float* g_logit, float* d_pooled, float* scratch,
+                                        int32_t* n_partial, void* stream) {
+  XDFM_REQUIRE(head_w && head_b && labels && logit && pred && cin_out && g_logit && d_pooled && scratch && n_partial,
+               "xdfm_cin_pooled_fwd_head: null argument");
+  XDFM_REQUIRE(n > 0 && n <= 64 && pool_off >= 0 && pool_off + L <= n, "xdfm_cin_pooled_fwd_head: bad channel counts");
+  XDFM_REQUIRE(loss_kind == XDFM_LOSS_LOG || loss_kind == XDFM_LOSS_CROSS_ENTROPY,
+               "xdfm_cin_pooled_fwd_head: log_loss or cross_entropy_loss (square_loss needs the mean first)");
+  XDFM_REQUIRE(B > 0 && (mean_count == 0 || mean_count >= B), "xdfm_cin_pooled_fwd_head: bad batch / mean_count");
+  XDFM_REQUIRE(!bias || part0, "xdfm_cin_pooled_fwd_head: bias belongs to part0 (the linear part)");
+  const unsigned blocks = n_blocks(B, kSpwFwd);
+  XDFM_REQUIRE(blocks <= 1024, "xdfm_cin_pooled_fwd_head: at most %d samples per call", 1024 * 4 * kSpwFwd);
+  PoolHead hd;
+  hd.lin = part0;
+  hd.fm = part1;
+  hd.dnn = part3;
+  hd.bias = bias;
+  hd.head_w = head_w;
+  hd.head_b = head_b;
+  hd.labels = labels;
+  hd.n_total = n;
+  hd.inv_count = 1.f / (float)(mean_count > 0 ? mean_count : B);
+  hd.classification = classification;
+  hd.loss_kind = loss_kind;
+  hd.cin_out = cin_out;
+  hd.logit = logit;
+  hd.pred = pred;
+  hd.g_logit = g_logit;
+  hd.d_pooled = d_pooled;
+  hd.partial = scratch;
+  *n_partial = (int32_t)blocks;
+  return launch_fwd("xdfm_cin_pooled_fwd_head", x0, xk, w, B, F, H, D, L, ldw, pooled, n, pool_off, &hd, stream);
 }
 
 extern "C" int xdfm_cin_pooled_bwd(const float* x0, const float* xk, const float* w, const float* d_pooled,

@@ -746,6 +746,15 @@ extern "C" int xdfm_loss_finish(const float* scratch, int64_t B, int64_t mean_co
   return XDFM_OK;
 }
 
+extern "C" int xdfm_loss_finish_partials(const float* scratch, int32_t n_partial, int64_t count, float* loss,
+                                         void* stream) {
+  XDFM_REQUIRE(scratch && loss && n_partial > 0 && count > 0, "xdfm_loss_finish_partials: bad argument");
+  XDFM_LAUNCH("loss_finish_kernel", (hipStream_t)stream, loss_finish_kernel, dim3(1), dim3(kHeadThreads), 0, scratch,
+              (int)n_partial, (float)count, 0, loss);
+  XDFM_LAUNCH_CHECK();
+  return XDFM_OK;
+}
+
 extern "C" int xdfm_eval_workspace_bytes(int64_t n, size_t* bytes) {
   XDFM_REQUIRE(bytes && n > 0 && n < ((int64_t)1 << 31), "xdfm_eval_workspace_bytes: bad argument");
   EvalLayout L;

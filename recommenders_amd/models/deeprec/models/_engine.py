@@ -301,6 +301,8 @@ class XDeepFMEngine(object):
         # with the channel count and the pair kernels sit at 24/38 us) -- opt-in until they do
         self.pool_split = os.environ.get("XDFM_POOL_SPLIT", "0") != "0"
         self.pooled_layer = os.environ.get("XDFM_POOLED_LAYER", "1") != "0"
+        self.head_in_layer = os.environ.get("XDFM_HEAD_IN_LAYER", "1") != "0"
+        self._loss_partials = 0
         self._split = {}
         self._fused_pool = set()
         self.split_dw = os.environ.get("XDFM_SPLIT_DW", "1") != "0"
@@ -850,6 +852,37 @@ class XDeepFMEngine(object):
                     xk = xnext
                     continue
                 if k in self._fused_pool:
+                    if (fused_head and self.head_in_layer and k == len(shapes) - 1 and final_len <= 64
+                            and B <= 16384 and hp.loss in ("log_loss", "cross_entropy_loss")):
+                        # the rest of the forward pass rides in the last layer's launch (one operation
+                        # fewer on the step's chain): it needs the DNN tower's output first
+                        if dnn_done is not None:
+                            torch.cuda.current_stream(self.device).wait_event(dnn_done)
+                            dnn_done = None
+                        elif hp.use_DNN_part and not self.overlap_dnn:
+                            self._dnn_forward(B)
+                        n_part = ctypes.c_int32()
+                        _lib.check(
+                            lib.xdfm_cin_pooled_fwd_head(
+                                _ptr(x0), _ptr(xk), _ptr(self.views["cin_f_%d" % k]), B, F, H, D, L, 0,
+                                _ptr(ws["pooled"]), off,
+                                _ptr(ws["lin_out"]) if use_lin else None, _ptr(ws["fm_out"]) if use_fm else None,
+                                _ptr(ws["dnn_out"]) if hp.use_DNN_part else None,
+                                _ptr(self.views["lin_b"]) if use_lin else None,
+                                _ptr(self.views["cin_w_out"]), _ptr(self.views["cin_b_out"]), final_len,
+                                _ptr(batch.labels), int(self.mean_count or 0),
+                                1 if hp.method == "classification" else 0, _LOSS[hp.loss], _ptr(ws["logit"]),
+                                _ptr(ws["pred"]), _ptr(ws["cin_out"]), _ptr(ws["g_logit"]), _ptr(ws["d_pooled"]),
+                                _ptr(self.loss_scratch), ctypes.byref(n_part), st,
+                            )
+                        )
+                        self._loss_partials = int(n_part.value)
+                        if self.overlap_dnn:
+                            self._loss_deferred = True  # finished on the side stream (backward())
+                        else:
+                            self._finish_loss(B, st)
+                        self._done(ev)
+                        return ws["pred"][:B]
                     _lib.check(lib.xdfm_cin_pooled_fwd(_ptr(x0), _ptr(xk), _ptr(self.views["cin_f_%d" % k]), B, F, H,
                                                        D, L, 0, _ptr(ws["pooled"]), final_len, off, st))
                     off += L
@@ -931,6 +964,7 @@ class XDeepFMEngine(object):
             # with a side stream the mean of the loss is finished there (backward()): no kernel
             # of the step waits for that value
             self._loss_deferred = self.overlap_dnn
+            self._loss_partials = 0
             self._done(ev)
             return ws["pred"][:B]
         _lib.check(
@@ -1170,8 +1204,7 @@ class XDeepFMEngine(object):
             with torch.cuda.stream(side):
                 st = self._stream()
                 if getattr(self, "_loss_deferred", False):
-                    _lib.check(lib.xdfm_loss_finish(_ptr(self.loss_scratch), B, int(self.mean_count or 0),
-                                                    _LOSS[hp.loss], _ptr(self.data_loss), st))
+                    self._finish_loss(B, st)
                     self._loss_deferred = False
                 if fused_head:
                     small_grads(ws["part_dnn"])
@@ -1351,6 +1384,15 @@ class XDeepFMEngine(object):
             torch.cuda.current_stream(self.device).wait_event(dnn_done)  # join
             return bool(advance)
         return False
+
+    def _finish_loss(self, B, st):
+        """The mean of the data loss from the per-block sums the forward pass left in loss_scratch."""
+        if self._loss_partials:
+            _lib.check(self.lib.xdfm_loss_finish_partials(_ptr(self.loss_scratch), self._loss_partials,
+                                                          int(self.mean_count or B), _ptr(self.data_loss), st))
+        else:
+            _lib.check(self.lib.xdfm_loss_finish(_ptr(self.loss_scratch), B, int(self.mean_count or 0),
+                                                 _LOSS[self.hp.loss], _ptr(self.data_loss), st))
 
     def join_late(self):
         """Make the current stream wait for the filter gradient that backward() left running on

@@ -503,7 +503,6 @@ class ShardedXDeepFMEngine(XDeepFMEngine):
                     g.graph = None
             if g.graph is not None:
                 g.graph.replay()
-                self.prefetch_route(next_batch)
                 self._advance_step()
                 self._owner_update(batch, g.send_c)
             else:
@@ -513,7 +512,6 @@ class ShardedXDeepFMEngine(XDeepFMEngine):
                 self.forward(batch, with_loss=True, with_grad=True)
                 rmse = self._square_loss_global(batch)
                 self.backward(batch)
-                self.prefetch_route(next_batch)
                 self._advance_step()
                 self._update_embedding(batch)
         else:
@@ -521,7 +519,6 @@ class ShardedXDeepFMEngine(XDeepFMEngine):
             self.forward(batch, with_loss=True, with_grad=True)
             rmse = self._square_loss_global(batch)
             self.backward(batch)
-            self.prefetch_route(next_batch)
             self._advance_step()
             self._update_embedding(batch)
         self.join_late()
@@ -530,6 +527,11 @@ class ShardedXDeepFMEngine(XDeepFMEngine):
             self.exchange.all_reduce(self.dense_grad)
             self._done(ev)
         self._update_dense(True)
+        # The next batch's routing ends in the step's one host synchronisation (the exchange sizes).  It is
+        # started here, with everything of THIS step enqueued: while the host waits for those few kernels the
+        # device still has this step's update to run (started right behind the local graph, the wait left
+        # the device idle between the graph and the owner-side update: the step was host-bound).
+        self.prefetch_route(next_batch)
         done = torch.cuda.Event()
         done.record(torch.cuda.current_stream(self.device))
         self._gen_free[batch.route.gen] = done
