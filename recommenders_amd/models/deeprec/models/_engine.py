@@ -122,6 +122,7 @@ class XDeepFMEngine(object):
         self.device = torch.device(device) if device is not None else torch.device(
             "cuda", torch.cuda.current_device()
         )
+        self._dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
         self.lib = _lib.lib
         # table_rows: rows held by this process (the sharded engine keeps FEATURE_COUNT / world)
         self.N = int(hp.FEATURE_COUNT) if table_rows is None else int(table_rows)
@@ -458,7 +459,9 @@ class XDeepFMEngine(object):
             ev[1].record(torch.cuda.current_stream(self.device))
 
     def _stream(self):
-        return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        # (the raw handle: torch.cuda.current_stream() builds a Stream object per call, 5 us each and a
+        # dozen calls per step on the eager paths)
+        return ctypes.c_void_p(torch._C._cuda_getCurrentRawStream(self._dev_index))
 
     def _ensure_ws(self, B, nnz):
         if B <= self._cap_B and nnz <= self._cap_nnz:
