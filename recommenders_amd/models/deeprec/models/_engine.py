@@ -1661,15 +1661,19 @@ class GraphedStep(object):
     run_packed(pb, next_pb) / run(..., next_ids=)): every replay still does one sort, one step ahead.
     A batch that was not announced that way is sorted eagerly in front of the replay."""
 
-    def __init__(self, engine, labels, dnn_idx, ids, weights):
+    def __init__(self, engine, labels, dnn_idx, ids, weights, csr=None):
+        """csr = (row_ptr, tok_row): the lookup's offsets / token rows when they exist already (a
+        DeviceBatch); dnn_idx may then be None.  The constructor TRAINS one step on the batch it is
+        given (the warm-up a capture needs); its losses are left in warmup_loss."""
         self.engine = engine
+        self._csr_only = dnn_idx is None
         if engine.kernel_events is not None:
             raise RuntimeError("kernel event hooks cannot be captured")
         self.lookahead = bool(engine.catchup_on)
         dev = engine.device
         B, nnz = int(labels.numel()), int(ids.numel())
         self._B, self._nnz = B, nnz
-        self._idx_shape, self._idx_dtype = tuple(dnn_idx.shape), dnn_idx.dtype
+        self._idx_shape, self._idx_dtype = (None, None) if dnn_idx is None else (tuple(dnn_idx.shape), dnn_idx.dtype)
         fields = [("labels", labels.dtype, tuple(labels.shape)),
                   ("row_ptr", torch.int32, (B * engine.F + 1,)),
                   ("tok_row", torch.int32, (max(nnz, 1),)),
@@ -1688,7 +1692,7 @@ class GraphedStep(object):
             off += (nbytes + 255) // 256 * 256
         self.flat = torch.empty((max(off, 256),), dtype=torch.uint8, device=dev)
         self.views = self._views(self.flat)
-        self._fill(self.views, labels, dnn_idx, ids, weights, ids)
+        self._fill(self.views, labels, dnn_idx, ids, weights, ids, csr)
         self._planned_for = None  # what the graph's plan_next was sorted from (PackedBatch / ids tensor)
         if self.lookahead:
             self.next_ids = self.views["next_ids"]  # always ids of a real batch: the replay sorts and reads rows by them
@@ -1703,7 +1707,7 @@ class GraphedStep(object):
         s = torch.cuda.Stream(device=dev)
         s.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(s):
-            engine.train_step(self._batch_of_views())
+            self.warmup_loss = engine.train_step(self._batch_of_views())
         torch.cuda.current_stream(dev).wait_stream(s)
         torch.cuda.synchronize(dev)
         engine.check_errors()
@@ -1742,19 +1746,25 @@ class GraphedStep(object):
             if tuple(src.shape) != shape or src.dtype != dt:
                 raise ValueError("batch array %s/%s does not match the captured shape %s/%s"
                                  % (tuple(src.shape), src.dtype, shape, dt))
-        if tuple(dnn_idx.shape) != self._idx_shape or dnn_idx.dtype != self._idx_dtype:
+        if dnn_idx is not None and self._idx_shape is not None and (
+                tuple(dnn_idx.shape) != self._idx_shape or dnn_idx.dtype != self._idx_dtype):
             raise ValueError("batch array %s/%s does not match the captured shape %s/%s"
                              % (tuple(dnn_idx.shape), dnn_idx.dtype, self._idx_shape, self._idx_dtype))
 
-    def _fill(self, views, labels, dnn_idx, ids, weights, next_ids):
+    def _fill(self, views, labels, dnn_idx, ids, weights, next_ids, csr=None):
         """The arrays of a batch into the views of a flat buffer; the CSR offsets / token rows are
-        built from the index array here (xdfm_build_row_ptr, which also flags bad indices)."""
+        built from the index array here (xdfm_build_row_ptr, which also flags bad indices) unless
+        they are handed over (csr)."""
         eng = self.engine
-        views["labels"].copy_(labels)
+        views["labels"].copy_(labels.reshape(views["labels"].shape))
         views["ids"].copy_(ids)
         views["weights"].copy_(weights)
-        _lib.check(eng.lib.xdfm_build_row_ptr(_ptr(dnn_idx), self._nnz, self._B * eng.F, _ptr(views["row_ptr"]),
-                                              _ptr(views["tok_row"]), _ptr(eng.err_flag), eng._stream()))
+        if csr is not None:
+            views["row_ptr"].copy_(csr[0])
+            views["tok_row"].copy_(csr[1][:views["tok_row"].numel()])
+        else:
+            _lib.check(eng.lib.xdfm_build_row_ptr(_ptr(dnn_idx), self._nnz, self._B * eng.F, _ptr(views["row_ptr"]),
+                                                  _ptr(views["tok_row"]), _ptr(eng.err_flag), eng._stream()))
         if "next_ids" in views:
             views["next_ids"].copy_(next_ids if next_ids is not None else ids)
 
@@ -1766,6 +1776,29 @@ class GraphedStep(object):
         buf = torch.empty_like(self.flat)
         self._fill(self._views(buf), labels, dnn_idx, ids, weights, next_ids)
         return PackedBatch(buf, ids, next_ids)
+
+    def pack_batch(self, batch, next_ids=None):
+        """pack() for a DeviceBatch (its CSR offsets exist already)."""
+        if batch.B != self._B or batch.nnz != self._nnz:
+            raise ValueError("batch of %d samples / %d tokens does not match the captured %d / %d"
+                             % (batch.B, batch.nnz, self._B, self._nnz))
+        buf = torch.empty_like(self.flat)
+        self._fill(self._views(buf), batch.labels, None, batch.ids, batch.weights, next_ids,
+                   csr=(batch.row_ptr, batch.tok_row))
+        return PackedBatch(buf, batch.ids, next_ids)
+
+    def run_batch(self, pb, key, next_key=None, next_ids=None):
+        """run_packed() with caller-chosen identities: `key` names this batch, `next_key` the announced
+        successor (the object the next call will pass as its key); next_ids: the successor's ids unless pb
+        was packed with them."""
+        self.flat.copy_(pb.buf, non_blocking=True)
+        if not self.lookahead or next_key is None:
+            return self._replay(key, None, None)
+        if next_ids is None:
+            raise ValueError("an announced successor needs its ids")
+        if pb.next_src is next_ids:
+            next_ids = None  # packed with them: the copy above brought them
+        return self._replay(key, next_key, next_ids)
 
     def _replay(self, cur_key, next_key, next_ids):
         """cur_key / next_key: what identifies this batch and its announced successor (the objects

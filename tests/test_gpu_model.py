@@ -148,6 +148,32 @@ def test_fit_with_kept_batches_equals_fit_that_parses_every_epoch(resources, mon
     assert outs[0] == outs[1]
 
 
+@pytest.mark.parametrize("update", ["sparse_rows", "dense_exact"])
+def test_fit_replaying_a_captured_step_equals_eager_fit(resources, monkeypatch, update):
+    """Batches of one shape (every line names every field once: a Criteo-style file) are trained by
+    replaying a captured HIP graph after XDFM_FIT_GRAPH_AFTER of them; the last, shorter batch of an
+    epoch and the first batches run eagerly.  Not a bit of the result may change."""
+    from tests.util import random_features, write_libffm
+
+    yaml_file, _, d = resources
+    hp = prepare_hparams(yaml_file, epochs=3, batch_size=64, embedding_update=update,
+                         embed_l2=0.0 if update == "sparse_rows" else 0.01,
+                         layer_l2=0.0 if update == "sparse_rows" else 0.01)
+    rng = np.random.default_rng(17)
+    labels, feats = random_features(rng, 64 * 9 + 13, hp.FIELD_COUNT, hp.FEATURE_COUNT, multi_p=0.0, missing_p=0.0)
+    data_file = write_libffm(str(d / ("fixed_%s.ffm" % update)), labels, feats)
+    outs = []
+    for after in ("3", "0"):
+        monkeypatch.setenv("XDFM_FIT_GRAPH_AFTER", after)
+        model = XDeepFMModel(hp, FFMTextIterator, seed=5)
+        model.fit(data_file, data_file)
+        assert bool(model._graphed) == (after != "0")
+        out = str(d / ("pred_graph_%s_%s.txt" % (update, after)))
+        model.predict(data_file, out)
+        outs.append(open(out).read())
+    assert outs[0] == outs[1]
+
+
 def test_write_tfevents_writes_the_summary_scalars_without_tensorflow(resources):
     """write_tfevents (base_model.py:448-450, :467-468): the merged summary's scalars, one record per
     training step, in SUMMARIES_DIR/events.jsonl."""
