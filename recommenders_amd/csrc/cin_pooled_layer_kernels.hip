@@ -200,6 +200,25 @@ __global__ __launch_bounds__(256, (T * LN <= 30 ? 2 : 1)) void cin_pooled_fwd_ke
     for (int t = 0; t < T; ++t) xa[s][t] = load4(x0 + b * FD + oa[t]);
     xb[s] = load4(xk + b * HD + ob);
   }
+  // HEAD: what the head of every sample needs from memory, requested with the operands (a load per
+  // sample inside the loop below would add its latency four times over)
+  float h_other[kSpwFwd], h_lin[kSpwFwd], h_fm[kSpwFwd], h_dnn[kSpwFwd], h_y[kSpwFwd];
+  float h_w = 0.f, h_b0 = 0.f, h_bias = 0.f;
+  if constexpr (HEAD) {
+    const int ch = lane < hd.n_total ? lane : 0;
+    h_w = lane < hd.n_total ? hd.head_w[ch] : 0.f;
+    h_b0 = hd.head_b[0];
+    h_bias = hd.bias ? hd.bias[0] : 0.f;
+#pragma unroll
+    for (int s = 0; s < kSpwFwd; ++s) {
+      const int64_t b = first + s < c.B ? first + s : c.B - 1;
+      h_other[s] = pooled[b * pool_stride + ch];  // (this layer's channels: replaced below)
+      h_lin[s] = hd.lin ? hd.lin[b] : 0.f;
+      h_fm[s] = hd.fm ? hd.fm[b] : 0.f;
+      h_dnn[s] = hd.dnn ? hd.dnn[b] : 0.f;
+      h_y[s] = hd.labels[b];
+    }
+  }
   float wr[T][4][LN];
   filter_stage<T, LN>(c, wv, lds, wr);
 #pragma unroll
@@ -228,27 +247,25 @@ __global__ __launch_bounds__(256, (T * LN <= 30 ? 2 : 1)) void cin_pooled_fwd_ke
       const int src = lane - pool_off;
       const float own = __shfl(mine, src < 0 ? 0 : (src > 63 ? 63 : src));
       if (b < c.B) {  // (wave-uniform)
-        float r = 0.f, wj = 0.f;
-        if (lane < hd.n_total) {
-          wj = hd.head_w[lane];
-          r = (src >= 0 && src < c.L) ? own : pooled[b * pool_stride + lane];
-        }
+        const float wj = h_w;
+        float r = 0.f;
+        if (lane < hd.n_total) r = (src >= 0 && src < c.L) ? own : h_other[s];
         const float base = wave_sum(r), dot = wave_sum(r * wj);
-        const float cin = base + (dot + hd.head_b[0]);
+        const float cin = base + (dot + h_b0);
         float z = 0.f;
-        bool first = true;
+        bool first_part = true;
         if (hd.lin) {
-          z = hd.lin[b] + (hd.bias ? hd.bias[0] : 0.f);
-          first = false;
+          z = h_lin[s] + h_bias;
+          first_part = false;
         }
         if (hd.fm) {
-          z = first ? hd.fm[b] : z + hd.fm[b];
-          first = false;
+          z = first_part ? h_fm[s] : z + h_fm[s];
+          first_part = false;
         }
-        z = first ? cin : z + cin;
-        if (hd.dnn) z = z + hd.dnn[b];
+        z = first_part ? cin : z + cin;
+        if (hd.dnn) z = z + h_dnn[s];
         const float p = hd.classification ? sigmoidf(z) : z;
-        const float y = hd.labels[b];
+        const float y = h_y[s];
         const float dp_dz = hd.classification ? p * (1.f - p) : 1.f;
         float g;
         if (hd.loss_kind == XDFM_LOSS_LOG) {
