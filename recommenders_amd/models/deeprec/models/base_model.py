@@ -183,8 +183,7 @@ class BaseModel:
         coming -- Criteo-style files where every line names every field -- and as eager launches
         otherwise (the eager step is bound by the host's launch rate: 0.66 against 0.42 ms at batch 8192).
         A shape is captured after XDFM_FIT_GRAPH_AFTER consecutive batches of it (default 4; 0 = never);
-        the capture trains this batch as its warm-up.  The two losses are the graph's static tensors:
-        read them (or combine them into new tensors, as fit() does) before the next step.
+        the capture trains this batch as its warm-up.
         Returns None when this step should run eagerly."""
         eng = self.engine
         after = self._graph_after
@@ -214,7 +213,11 @@ class BaseModel:
                 feed_dict.packed_batch = pb
                 self._device_cache_bytes = held + nbytes
                 weakref.finalize(feed_dict, self._release_device_cache, nbytes)
-        return gs.run_batch(pb[1], feed_dict, next_feed_dict if same else None, nxt.ids if same else None)
+        loss, data_loss = gs.run_batch(pb[1], feed_dict, next_feed_dict if same else None, nxt.ids if same else None)
+        # the graph writes the same two tensors every step: hand out copies, as the eager step hands out
+        # new tensors (a caller may keep them across steps)
+        pair = torch.stack([loss, data_loss])
+        return pair[0], pair[1]
 
     def eval(self, sess, feed_dict):
         """``[pred [B,1], labels [B,1]]`` as numpy arrays (reference :390-402)."""
