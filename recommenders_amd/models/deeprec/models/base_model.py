@@ -193,6 +193,10 @@ class BaseModel:
         self._shape_run = self._shape_run + 1 if key == self._shape_last else 1
         self._shape_last = key
         gs = self._graphed.get(key)
+        if gs is not None and gs._ws_token != eng._ws_token:
+            # a larger batch made the engine re-allocate its workspace: the capture holds stale addresses
+            del self._graphed[key]
+            gs = None
         if gs is None:
             if self._shape_run < after or len(self._graphed) >= 2 or batch.nnz == 0:
                 return None

@@ -161,6 +161,10 @@ def test_fit_replaying_a_captured_step_equals_eager_fit(resources, monkeypatch, 
                          layer_l2=0.0 if update == "sparse_rows" else 0.01)
     rng = np.random.default_rng(17)
     labels, feats = random_features(rng, 64 * 9 + 13, hp.FIELD_COUNT, hp.FEATURE_COUNT, multi_p=0.0, missing_p=0.0)
+    # one batch in the middle with more tokens than any before it (a field named three times): the engine
+    # re-allocates its workspace there and the capture made before it must not be replayed again
+    for toks in feats[64 * 6:64 * 7]:
+        toks.extend([[0, int(rng.integers(0, hp.FEATURE_COUNT)), 1.0], [0, int(rng.integers(0, hp.FEATURE_COUNT)), 1.0]])
     data_file = write_libffm(str(d / ("fixed_%s.ffm" % update)), labels, feats)
     outs = []
     for after in ("3", "0"):
