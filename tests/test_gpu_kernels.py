@@ -294,6 +294,45 @@ def test_graphed_sparse_rows_step_sorts_one_batch_ahead_and_equals_eager():
             assert torch.equal(sa[k], sb[k]), k
 
 
+def test_graphed_step_through_run_and_run_batch_equals_eager():
+    """The other two ways into a captured step: run() with four arrays (the successor announced by its
+    ids tensor) and pack_batch() / run_batch() from DeviceBatches with caller-chosen identities (what
+    fit() uses).  Same bits as eager steps, with and without an announced successor."""
+    hp = make_hp(optimizer="adam", learning_rate=0.02, FEATURE_COUNT=2000, batch_size=48)
+    rng = np.random.default_rng(13)
+    p32 = X.init_params(hp, seed=8)
+    batches = [random_batch(rng, hp, 48, multi_p=0.0, missing_p=0.0) for _ in range(9)]
+
+    def dev(b):
+        return [torch.from_numpy(np.ascontiguousarray(a)).cuda() for a in (
+            b["labels"].reshape(-1), b["dnn_feat_indices"], b["dnn_feat_values"], b["dnn_feat_weights"])]
+
+    eager, graph = load_engine(hp, p32, "sparse_rows"), load_engine(hp, p32, "sparse_rows")
+    eager.train_step(upload(eager, batches[0]))
+    devs = [dev(b) for b in batches]
+    dbs = [upload(graph, b) for b in batches]
+    from recommenders_amd.models.deeprec.models._engine import GraphedStep
+
+    gs = GraphedStep(graph, dbs[0].labels, None, dbs[0].ids, dbs[0].weights, csr=(dbs[0].row_ptr, dbs[0].tok_row))
+    keys = [object() for _ in batches]
+    for k in range(1, 9):
+        le = float(eager.train_step(upload(eager, batches[k]))[0])
+        announce = k + 1 < 9 and k != 3
+        if k < 5:  # four arrays
+            # (step 4 announces a tensor, step 5 arrives under another identity: sorted again in front of it)
+            lg = float(gs.run(*devs[k], next_ids=devs[k + 1][2] if announce else None)[0])
+        else:      # device batches, identities chosen by the caller
+            pb = gs.pack_batch(dbs[k], next_ids=dbs[k + 1].ids if (announce and k % 2) else None)
+            lg = float(gs.run_batch(pb, keys[k], keys[k + 1] if announce else None,
+                                    dbs[k + 1].ids if announce else None)[0])
+        assert le == lg, (k, le, lg)
+    sa, sb = eager.state_dict(), graph.state_dict()
+    assert sa["step"] == sb["step"] == 9
+    for k in sa:
+        if torch.is_tensor(sa[k]):
+            assert torch.equal(sa[k], sb[k]), k
+
+
 @pytest.mark.parametrize("name", ["all_parts", "criteo_shape", "wide_shape"])
 def test_pooled_channels_summed_over_d_first_equal_the_layer_kernels(name):
     """The pooled channels of a CIN layer through xdfm_cin_pair_sum + a plain product (the sum over the
