@@ -572,6 +572,27 @@ int xdfm_bn_bwd(const float* x, const float* y, const float* dy, int64_t B, int3
                 const float* gamma, const float* stats, int32_t act, float* dx, float* dgamma,
                 float* dbeta, void* stream);
 
+/* The same normalisation when the batch is split between ranks (one process per GPU; the reference
+ * is one process, its statistics are those of the whole batch: xDeepFM.py:234-240, :497-503).
+ *   xdfm_bn_local_moments: moments[c] = mean of this rank's B*I values of channel c,
+ *     moments[C + c] = their sum of squared deviations from that mean.  The ranks combine these
+ *     (count-weighted mean; M2 = sum_r M2_r + n_r (mean_r - mean)^2) into
+ *   mean_var[2C] = (mean, biased variance) of the whole batch, and
+ *   xdfm_bn_fwd_moments normalises with it: stats, moving statistics and y as xdfm_bn_fwd(training).
+ *   xdfm_bn_bwd_sums: dgamma[C], dbeta[C] over THIS rank's samples (its share of the parameter
+ *     gradients); the ranks add them into sum_gamma / sum_beta, and
+ *   xdfm_bn_bwd_apply: dx = gamma*inv*(g - sum_beta/n_total - xhat*sum_gamma/n_total), n_total =
+ *     the whole batch's count per channel (sum of the ranks' B*I).  dx may alias dy. */
+int xdfm_bn_local_moments(const float* x, int64_t B, int32_t C, int32_t I, float* moments, void* stream);
+int xdfm_bn_fwd_moments(const float* x, int64_t B, int32_t C, int32_t I, const float* gamma, const float* beta,
+                        float* moving_mean, float* moving_var, float momentum, float eps,
+                        const float* mean_var, int32_t act, float* stats, float* y, void* stream);
+int xdfm_bn_bwd_sums(const float* x, const float* y, const float* dy, int64_t B, int32_t C, int32_t I,
+                     const float* stats, int32_t act, float* dgamma, float* dbeta, void* stream);
+int xdfm_bn_bwd_apply(const float* x, const float* y, const float* dy, int64_t B, int32_t C, int32_t I,
+                      int64_t n_total, const float* gamma, const float* stats, int32_t act,
+                      const float* sum_gamma, const float* sum_beta, float* dx, void* stream);
+
 /* softmax activation (`_activate`, base_model.py:343-344: tf.nn.softmax over the last axis), the
  * one activation the fused forms above do not carry: run the layer with the identity and then
  *   y[b,:,i] = softmax(x[b,:,i])            x, y: [B, C, I] as for xdfm_bn_fwd; y may alias x

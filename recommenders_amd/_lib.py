@@ -144,6 +144,10 @@ SIGNATURES = {
     "xdfm_softmax_fwd": [_P, _I64, _I32, _I32, _P, _P],
     "xdfm_softmax_bwd": [_P, _P, _I64, _I32, _I32, _P, _P],
     "xdfm_bn_bwd": [_P, _P, _P, _I64, _I32, _I32, _P, _P, _I32, _P, _P, _P, _P],
+    "xdfm_bn_local_moments": [_P, _I64, _I32, _I32, _P, _P],
+    "xdfm_bn_fwd_moments": [_P, _I64, _I32, _I32, _P, _P, _P, _P, ctypes.c_float, ctypes.c_float, _P, _I32, _P, _P, _P],
+    "xdfm_bn_bwd_sums": [_P, _P, _P, _I64, _I32, _I32, _P, _I32, _P, _P, _P],
+    "xdfm_bn_bwd_apply": [_P, _P, _P, _I64, _I32, _I32, _I64, _P, _P, _I32, _P, _P, _P, _P],
     "xdfm_dense_fwd": [_P, _P, _P, _I64, _I32, _I32, _I32, _P, _P],
     "xdfm_dense_bf16_workspace_floats": [_I64, _I32, _I32, _PSZ],
     "xdfm_dense_bf16_fwd": [_P, _P, _P, _I64, _I32, _I32, _I32, _P, _P, _P],

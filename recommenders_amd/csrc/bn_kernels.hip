@@ -169,6 +169,104 @@ extern "C" int xdfm_bn_bwd(const float* x, const float* y, const float* dy, int6
   return XDFM_OK;
 }
 
+// ------------------------------------------------------- batch split between ranks
+// The batch statistics of the reference are those of the WHOLE batch (one process there).  When
+// the batch is split between ranks, each rank forms its own moments (xdfm_bn_local_moments), the
+// ranks combine them (count-weighted means, M2 = sum M2_r + n_r (mean_r - mean)^2: the host side
+// does that on 2C numbers per rank) and xdfm_bn_fwd_moments normalises with the result.  Backward
+// likewise: xdfm_bn_bwd_sums gives this rank's sums (= its share of the gamma / beta gradients),
+// the ranks add them, xdfm_bn_bwd_apply takes the totals and the total count.
+namespace {
+
+// moments[c] = mean of this rank's part, moments[C + c] = sum of squared deviations from it
+__global__ __launch_bounds__(256) void bn_local_moments_kernel(const float* __restrict__ x, int64_t B, int C, int I,
+                                                               float* __restrict__ moments) {
+  __shared__ float sh[256];
+  const int c = blockIdx.x;
+  const int64_t n = B * I;
+  float s = 0.f;
+  for (int64_t j = threadIdx.x; j < n; j += 256) s += x[elem(j, c, C, I)];
+  const float mean = block_sum<256>(s, sh) / (float)n;
+  float q = 0.f;
+  for (int64_t j = threadIdx.x; j < n; j += 256) {
+    const float d = x[elem(j, c, C, I)] - mean;
+    q += d * d;
+  }
+  q = block_sum<256>(q, sh);
+  if (threadIdx.x == 0) {
+    moments[c] = mean;
+    moments[C + c] = q;
+  }
+}
+
+// mean_var[c] = mean, mean_var[C + c] = biased variance of the whole batch
+__global__ void bn_given_stats_kernel(const float* __restrict__ mean_var, float* __restrict__ moving_mean,
+                                      float* __restrict__ moving_var, int C, float momentum, float eps,
+                                      float* __restrict__ stats) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float mean = mean_var[c], var = mean_var[C + c];
+  stats[c] = mean;
+  stats[C + c] = 1.f / sqrtf(var + eps);
+  const float decay = 1.f - momentum;
+  moving_mean[c] -= (moving_mean[c] - mean) * decay;
+  moving_var[c] -= (moving_var[c] - var) * decay;
+}
+
+}  // namespace
+
+extern "C" int xdfm_bn_local_moments(const float* x, int64_t B, int32_t C, int32_t I, float* moments,
+                                     void* stream) {
+  XDFM_REQUIRE(x && moments, "xdfm_bn_local_moments: null argument");
+  XDFM_REQUIRE(B > 0 && C > 0 && I > 0, "xdfm_bn_local_moments: bad sizes");
+  XDFM_LAUNCH("bn_local_moments_kernel", (hipStream_t)stream, bn_local_moments_kernel, dim3((unsigned)C), dim3(256),
+              0, x, B, C, I, moments);
+  XDFM_LAUNCH_CHECK();
+  return XDFM_OK;
+}
+
+extern "C" int xdfm_bn_fwd_moments(const float* x, int64_t B, int32_t C, int32_t I, const float* gamma,
+                                   const float* beta, float* moving_mean, float* moving_var, float momentum,
+                                   float eps, const float* mean_var, int32_t act, float* stats, float* y,
+                                   void* stream) {
+  XDFM_REQUIRE(x && gamma && beta && moving_mean && moving_var && mean_var && stats && y,
+               "xdfm_bn_fwd_moments: null argument");
+  XDFM_REQUIRE(B > 0 && C > 0 && I > 0, "xdfm_bn_fwd_moments: bad sizes");
+  XDFM_REQUIRE(act_ok(act), "xdfm_bn_fwd_moments: unknown activation %d", act);
+  hipStream_t st = (hipStream_t)stream;
+  XDFM_LAUNCH("bn_given_stats_kernel", st, bn_given_stats_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0,
+              mean_var, moving_mean, moving_var, C, momentum, eps, stats);
+  const int64_t total = B * C * I;
+  XDFM_LAUNCH("bn_apply_kernel", st, bn_apply_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, x, total, C,
+              I, gamma, beta, stats, act, y);
+  XDFM_LAUNCH_CHECK();
+  return XDFM_OK;
+}
+
+extern "C" int xdfm_bn_bwd_sums(const float* x, const float* y, const float* dy, int64_t B, int32_t C, int32_t I,
+                                const float* stats, int32_t act, float* dgamma, float* dbeta, void* stream) {
+  XDFM_REQUIRE(x && y && dy && stats && dgamma && dbeta, "xdfm_bn_bwd_sums: null argument");
+  XDFM_REQUIRE(B > 0 && C > 0 && I > 0, "xdfm_bn_bwd_sums: bad sizes");
+  XDFM_REQUIRE(act_ok(act), "xdfm_bn_bwd_sums: unknown activation %d", act);
+  XDFM_LAUNCH("bn_bwd_reduce_kernel", (hipStream_t)stream, bn_bwd_reduce_kernel, dim3((unsigned)C), dim3(256), 0, x, y,
+              dy, B, C, I, stats, act, dgamma, dbeta);
+  XDFM_LAUNCH_CHECK();
+  return XDFM_OK;
+}
+
+extern "C" int xdfm_bn_bwd_apply(const float* x, const float* y, const float* dy, int64_t B, int32_t C, int32_t I,
+                                 int64_t n_total, const float* gamma, const float* stats, int32_t act,
+                                 const float* sum_gamma, const float* sum_beta, float* dx, void* stream) {
+  XDFM_REQUIRE(x && y && dy && gamma && stats && sum_gamma && sum_beta && dx, "xdfm_bn_bwd_apply: null argument");
+  XDFM_REQUIRE(B > 0 && C > 0 && I > 0 && n_total >= B * I, "xdfm_bn_bwd_apply: bad sizes");
+  XDFM_REQUIRE(act_ok(act), "xdfm_bn_bwd_apply: unknown activation %d", act);
+  const int64_t total = B * C * I;
+  XDFM_LAUNCH("bn_bwd_apply_kernel", (hipStream_t)stream, bn_bwd_apply_kernel, dim3((unsigned)((total + 255) / 256)),
+              dim3(256), 0, x, y, dy, total, n_total, C, I, gamma, stats, act, sum_gamma, sum_beta, dx);
+  XDFM_LAUNCH_CHECK();
+  return XDFM_OK;
+}
+
 // ------------------------------------------------------------------------ softmax
 // `_activate(..., "softmax")` (base_model.py:343-344): tf.nn.softmax over the last axis -- the
 // units of a DNN layer ([B, n]: C = n, I = 1) or the channels of a CIN layer's curr ([B, D, L]

@@ -111,8 +111,14 @@ def _two_rank_worker(rank, world, port, optimizer, loss, out):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        hp = make_hp(optimizer=optimizer, learning_rate=0.01, FEATURE_COUNT=301, cross_l2=0.01, cross_l1=0.001,
-                     loss=loss)
+        bn = loss == "batch_norm"
+        if bn:
+            # cross_entropy_loss: see test_batch_norm_training_matches_oracle (logits of +-10 under log_loss)
+            hp = make_hp(optimizer=optimizer, learning_rate=0.01, FEATURE_COUNT=301, cross_l2=0.01,
+                         loss="cross_entropy_loss", enable_BN=True)
+        else:
+            hp = make_hp(optimizer=optimizer, learning_rate=0.01, FEATURE_COUNT=301, cross_l2=0.01, cross_l1=0.001,
+                         loss=loss)
         F, N = hp.FIELD_COUNT, hp.FEATURE_COUNT
         p32 = X.init_params(hp, seed=9)
         eng = ShardedXDeepFMEngine(hp, seed=7)
@@ -148,9 +154,18 @@ def _two_rank_worker(rank, world, port, optimizer, loss, out):
             err = np.abs(got.cpu().numpy() - exp).max()
             assert err <= tol * np.abs(exp).max(), (name, err)
         for k in eng.dense_shapes:
+            if bn and k.startswith("dnn_b_") and k != "dnn_b_out":
+                continue  # zero gradient in front of a batch norm: Adam walks on rounding noise
             exp = p64[k].numpy().reshape(eng.dense_shapes[k])
             err = np.abs(eng.views[k].cpu().numpy() - exp).max()
-            assert err <= tol * max(np.abs(exp).max(), 1e-30), (k, err)
+            assert err <= (5e-4 if bn else tol) * max(np.abs(exp).max(), 1e-30), (k, err)
+        assert bool(eng.bn_state) == bn
+        for k, t in eng.bn_state.items():  # moving statistics of the GLOBAL batch, the same on every rank
+            if k.startswith("bnstat_dnn_mm_"):
+                continue  # follows the noise-walked bias
+            exp = p64[k].numpy().reshape(t.shape)
+            err = np.abs(t.cpu().numpy() - exp).max()
+            assert err <= 5e-4 * max(np.abs(exp).max(), 1e-30), (k, err)
         out.put((rank, "ok"))
     except Exception:  # noqa: BLE001
         import traceback
@@ -160,12 +175,14 @@ def _two_rank_worker(rank, world, port, optimizer, loss, out):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("optimizer,loss", [("adam", "log_loss"), ("adagrad", "log_loss"), ("adam", "square_loss")])
+@pytest.mark.parametrize("optimizer,loss", [("adam", "log_loss"), ("adagrad", "log_loss"), ("adam", "square_loss"),
+                                            ("adam", "batch_norm")])
 def test_two_ranks_sharing_the_gpu_match_the_oracle_on_the_global_batch(optimizer, loss):
     """world_size 2, one process per rank: ids to their owners, rows back, gradient rows to the
     owners, owner-side update, dense all-reduce -- against the oracle stepping on the
     concatenated batch.  square_loss (a root of a mean over the GLOBAL batch) adds one scalar all-reduce
-    between the forward and the backward pass.  (RCCL needs one GPU per rank; the driver's scaling bench is that run.)"""
+    between the forward and the backward pass; "batch_norm" = enable_BN, whose statistics are those of the global
+    batch: one all-reduce per normalisation and pass.  (RCCL needs one GPU per rank; the driver's scaling bench is that run.)"""
     import torch.multiprocessing as mp
 
     world = 2
@@ -181,7 +198,7 @@ def test_two_ranks_sharing_the_gpu_match_the_oracle_on_the_global_batch(optimize
     assert sorted(res) == [(r, "ok") for r in range(world)], res
 
 
-def _rccl_worker(port, out):
+def _rccl_worker(port, bn, out):
     """One rank over the nccl (= RCCL) backend with every collective of the N-GPU step issued for
     real (an exchange with oneself): the calls, dtypes and split lists of the multi-GPU path."""
     import os
@@ -193,9 +210,11 @@ def _rccl_worker(port, out):
     torch.cuda.set_device(0)
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     try:
-        hp = make_hp(optimizer="adam", learning_rate=0.01, FEATURE_COUNT=300)
+        extra = dict(enable_BN=True, loss="cross_entropy_loss") if bn else {}
+        hp = make_hp(optimizer="adam", learning_rate=0.01, FEATURE_COUNT=300, **extra)
         p32 = X.init_params(hp, seed=9)
         eng = ShardedXDeepFMEngine(hp, seed=7, force_collectives=True)
+        assert eng.graph_local == (not bn)
         assert eng.exchange.collective and not eng.exchange.host_staged
         eng.load_global_state({k: v.clone() for k, v in p32.items()})
         p64 = {k: v.double() for k, v in p32.items()}
@@ -206,12 +225,12 @@ def _rccl_worker(port, out):
         for k, b in enumerate(batches):
             loss, dloss = eng.train_step(dev[k], next_batch=dev[k + 1] if k + 1 < len(dev) else None)
             o_loss, o_dl, _, _ = X.train_step(p64, st, b, hp, mode="dense_exact")
-            assert abs(float(dloss) - o_dl) <= 1e-5 * abs(o_dl), (k, float(dloss), o_dl)
+            assert abs(float(dloss) - o_dl) <= 2e-5 * abs(o_dl), (k, float(dloss), o_dl)
         torch.cuda.synchronize()
         eng.check_errors()
         table, _ = eng.gather_global_table()
         err = np.abs(table.cpu().numpy() - p64["embedding"].numpy()).max()
-        assert err <= 2e-4 * np.abs(p64["embedding"].numpy()).max(), err
+        assert err <= (5e-4 if bn else 2e-4) * np.abs(p64["embedding"].numpy()).max(), err
         out.put("ok")
     except Exception:  # noqa: BLE001
         import traceback
@@ -221,12 +240,14 @@ def _rccl_worker(port, out):
         dist.destroy_process_group()
 
 
-def test_collectives_of_the_sharded_step_run_over_rccl():
+@pytest.mark.parametrize("bn", [False, True])
+def test_collectives_of_the_sharded_step_run_over_rccl(bn):
+    """bn: enable_BN, whose moments / sums all-reduces then run over RCCL too."""
     import torch.multiprocessing as mp
 
     ctx = mp.get_context("spawn")
     out = ctx.Queue()
-    p = ctx.Process(target=_rccl_worker, args=(_free_port(), out))
+    p = ctx.Process(target=_rccl_worker, args=(_free_port(), bn, out))
     p.start()
     res = out.get(timeout=110)
     p.join(timeout=30)
