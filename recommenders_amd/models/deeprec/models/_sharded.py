@@ -687,13 +687,19 @@ class _LocalGraph(object):
         self.graph = None
 
     def capture(self):
-        """A warm-up pass off the capture, then the capture (the inputs hold a real batch)."""
+        """A warm-up pass off the capture, then the capture (the inputs hold a real batch).  The replay
+        that follows does this batch's work once more: everything the pass writes is overwritten by it,
+        except the moving statistics of enable_BN, which move with every forward pass -- they are put
+        back after the warm-up."""
         dev = self.eng.device
+        moving = {k: t.clone() for k, t in self.eng.bn_state.items()}
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):
             self._run()
         torch.cuda.current_stream(dev).wait_stream(side)
+        for k, t in moving.items():
+            self.eng.bn_state[k].copy_(t)
         torch.cuda.synchronize(dev)
         graph = torch.cuda.CUDAGraph()
         # thread_local: the process group's watchdog thread may touch the runtime meanwhile

@@ -62,6 +62,28 @@ def test_sharded_step_equals_plain_engine_and_oracle(optimizer, virtual_world):
     assert np.abs(plain.state_dict()["embedding"].cpu().numpy() - table.cpu().numpy()).max() <= 1e-6
 
 
+def test_sharded_batch_norm_without_peers_equals_plain_engine():
+    """enable_BN with nothing split: the plain normalisation kernels, inside the captured local graph."""
+    hp = make_hp(optimizer="adam", learning_rate=0.01, FEATURE_COUNT=300, enable_BN=True, loss="cross_entropy_loss")
+    rng = np.random.default_rng(8)
+    p32 = X.init_params(hp, seed=9)
+    plain = XDeepFMEngine(hp, embedding_update="sparse_rows")
+    shard = ShardedXDeepFMEngine(hp)
+    assert shard.graph_local
+    plain.load_state({k: v.clone() for k, v in p32.items()})
+    shard.load_global_state({k: v.clone() for k, v in p32.items()})
+    for step in range(4):
+        b = random_batch(rng, hp, 64)
+        _, d0 = plain.train_step(_upload(plain, b))
+        _, d1 = shard.train_step(_upload(shard, b))
+        assert float(d0) == float(d1), step
+    assert shard._local_graphs and all(g.graph is not None for g in shard._local_graphs.values())
+    a, b_ = plain.state_dict(), shard.state_dict()
+    for k in a:
+        if k.startswith("bnstat_"):
+            assert torch.equal(a[k], b_[k]), k
+
+
 def test_device_partition_equals_its_torch_restatement():
     """xdfm_route_keys + the radix sort + xdfm_route_uniq against RowShardExchange._partition_host (the
     torch form the gloo rehearsal on CPU tensors runs): bit-exact, incl. hot ids, an owner without
