@@ -231,6 +231,13 @@ def main():
     if args.dtype is None:
         args.dtype = "bf16" if args.workload == "wide" else "fp32"
 
+    # stdout carries the one JSON line and nothing else: libraries write to file descriptor 1 too (RCCL
+    # prints a version banner there when its first communicator comes up), so descriptor 1 is pointed
+    # at stderr for the run and the line goes to the kept copy
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -426,7 +433,8 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline and args.workload == "criteo":
             line["cpu_baseline"] = run_cpu_baseline(hp, host_batches)
-        print(json.dumps(line))
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(line) + "\n").encode())
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
