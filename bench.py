@@ -302,6 +302,11 @@ def main():
         return eng.train_step(batch, next_batch=pending.get(i + 1))
 
     graphed = None
+    from recommenders_amd.models.deeprec.models._engine import graph_replay_refusal
+
+    if graph_replay_refusal() and not args.no_graph:
+        print("bench: %s -- every step launched eagerly" % graph_replay_refusal(), file=sys.stderr)
+        args.no_graph = True
     if world == 1 and not args.no_graph and not args.sharded:
         # one GPU: the whole step (copy of the batch arrays into the graph's inputs aside) is one
         # HIP graph launch; N > 1 stays eager (split sizes of the all-to-all are host values)

@@ -1647,6 +1647,16 @@ class PackedBatch(object):
         self.buf, self.ids_src, self.next_src = buf, ids_src, next_src
 
 
+def graph_replay_refusal():
+    """None, or why a captured step must not be replayed in this process: the step's graph has four
+    parallel branches, and with GPU_MAX_HW_QUEUES below HIP's default of 4 this ROCm's hipGraphLaunch
+    dies with a segmentation fault inside the runtime (seen with 2 on ROCm 7.0 / MI355X)."""
+    q = os.environ.get("GPU_MAX_HW_QUEUES", "").strip()
+    if q.isdigit() and int(q) < 4:
+        return "GPU_MAX_HW_QUEUES=%s: replaying the captured step needs at least 4 hardware queues (HIP's default)" % q
+    return None
+
+
 class GraphedStep(object):
     """A captured train step.  The graph reads its batch from one flat device buffer -- labels, the CSR
     offsets and token rows of the lookup (what the text reader hands over as `row_ptr`; built once
@@ -1669,6 +1679,8 @@ class GraphedStep(object):
         self._csr_only = dnn_idx is None
         if engine.kernel_events is not None:
             raise RuntimeError("kernel event hooks cannot be captured")
+        if graph_replay_refusal():
+            raise RuntimeError(graph_replay_refusal())
         self.lookahead = bool(engine.catchup_on)
         dev = engine.device
         B, nnz = int(labels.numel()), int(ids.numel())
