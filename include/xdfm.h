@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define XDFM_ABI_VERSION 2
+#define XDFM_ABI_VERSION 3
 
 #define XDFM_OK 0
 #define XDFM_E_INVALID (-1)   /* bad argument (null pointer, size, enum) */
@@ -127,6 +127,67 @@ int xdfm_ffm_close(xdfm_ffm_reader* r);
 int xdfm_build_row_ptr(const int64_t* dnn_feat_indices, int64_t nnz, int64_t n_rows,
                        int32_t* row_ptr, int32_t* tok_row, int32_t* err_flag, void* stream);
 
+typedef struct xdfm_opt_args {
+  int32_t kind;       /* XDFM_OPT_* */
+  float lr;           /* learning_rate */
+  float beta1, beta2; /* Adam */
+  float eps;          /* Adam epsilon (outside the sqrt, TF1 placement) */
+  float beta1_power;  /* beta1^t, t = 1-based step being applied */
+  float beta2_power;  /* beta2^t */
+  float l2;           /* coefficient of sum(p^2)/2, gradient l2*p */
+  float l1;           /* coefficient of sum|p|, gradient l1*sign(p) */
+  float clip_norm;    /* >0: per-tensor tf.clip_by_norm(g, clip_norm); 0: off */
+  int32_t reserved;   /* keeps the pointer below 8-byte aligned; set to 0 */
+  /* Optional device scalars (NULL: use beta1_power / beta2_power above).  opt_state[2] is the
+   * Adam step size lr*sqrt(1-beta2^t)/(1-beta1^t) kept up to date by xdfm_opt_advance; with it
+   * no host value changes from step to step, so a step can be captured in a HIP graph. */
+  const float* opt_state;
+} xdfm_opt_args;
+
+/* opt_state[4] = {beta1^t, beta2^t, step size, t}: advance t by one (one small kernel).
+ * Initialise the buffer to {1, 1, 0, 0} before the first step.  Build extra.
+ * drift_tab (NULL ok): the table row ageing reads under Adam (below); the call rebuilds its entries for
+ * the new step count t in slot t & 1, so that kernels still ageing rows to t - 1 keep reading theirs. */
+int xdfm_opt_advance(float* opt_state, float lr, float beta1, float beta2, float eps, float* drift_tab,
+                     void* stream);
+
+/* ------------------------------------------------------------------------
+ * Row ageing: sparse row updates (xdfm_embed_bwd mode 0) that give the reference's numbers.
+ * In the reference the table's gradient is dense (the regulariser ops of base_model.py:121-149 sit on
+ * the table even at coefficient 0; SURVEY.md 8a A2/O1), so apply_gradients (base_model.py:322) moves
+ * every row every step: a row without a token in the batch still takes Adam's m <- b1 m, v <- b2 v,
+ * p <- p - lr_t m / (sqrt(v) + eps).  row_step[id] (int32) records the number of optimizer steps a
+ * row's stored (p, m, v) are current for; a call that is handed an xdfm_row_age applies the
+ * G = opt_state[3] + step_offset - row_step[id] steps the row missed as it reads it:
+ *   xdfm_embed_fwd / xdfm_embed_gather   aged row formed in registers, nothing written
+ *   xdfm_embed_bwd (mode 0)              (p, m, v) aged in the registers of the row update, then the
+ *                                        gradient applied, row_step <- opt_state[3] + step_offset + 1
+ *   xdfm_embed_catchup                   aged rows written back (checkpoints, table exports)
+ * Adam's G steps are summed in closed form (error below 1e-6 of the movement at any learning rate,
+ * tools/drift_sim.py) with coefficients from the drift table: xdfm_drift_tab_floats() floats, filled by
+ * xdfm_drift_tab_init (once, and after opt_state was set from a checkpoint) and kept current by
+ * xdfm_opt_advance.  RMSProp / Adadelta decay their accumulators; FTRL re-derives p = -linear /
+ * quadratic as TF's dense ApplyFtrl does every step (a row that never had a gradient becomes 0);
+ * SGD and Adagrad have no drift.  opt_state[3] is a float: exact up to 2^24 steps.
+ * No counterpart in the reference (its optimizer streams the whole table every step).
+ * ---------------------------------------------------------------------- */
+typedef struct xdfm_row_age {
+  int32_t* row_step;       /* device, one entry per table row */
+  int64_t step_stride;     /* 4-byte words between consecutive entries (0 = dense) */
+  const float* slot_m;     /* the table's optimizer slots, strides as the table (read by the gathers; */
+  const float* slot_v;     /*   xdfm_embed_bwd / xdfm_embed_catchup take them as arguments of their own) */
+  const float* lin_m;      /* lin_w's slots (NULL without a linear part) */
+  const float* lin_v;
+  const float* drift_tab;  /* Adam: the drift table; NULL for the other optimizers */
+  const xdfm_opt_args* opt; /* kind, lr, betas, eps and opt_state (required: the step count is read there) */
+  int32_t step_offset;     /* 0, or -1 once xdfm_opt_advance has counted the step being applied */
+  int32_t reserved;
+} xdfm_row_age;
+
+int xdfm_drift_tab_floats(size_t* floats);
+int xdfm_drift_tab_init(float* drift_tab, const float* opt_state, float lr, float beta1, float beta2, float eps,
+                        void* stream);
+
 /* ------------------------------------------------------------------------
  * Field-embedding lookup + linear part + FM part (forward).
  *   tf.nn.embedding_lookup_sparse(..., combiner="sum")   xDeepFM.py:92-100
@@ -144,11 +205,12 @@ int xdfm_build_row_ptr(const int64_t* dnn_feat_indices, int64_t nnz, int64_t n_r
  *   lin_out[B]  (NULL ok)    sum_j w_j*lin_w[id_j]
  *   fm_out[B]   (NULL ok)    FM second-order term
  *   fm_sum[B,D] (NULL ok)    s[b,d] = sum_j w_j*table[id_j,d]   (kept for the backward)
+ *   age (NULL ok)            rows are aged as they are read (xdfm_row_age above)
  * ---------------------------------------------------------------------- */
 int xdfm_embed_fwd(const float* table, const float* lin_w, int64_t table_stride, int64_t lin_stride,
                    int64_t N, int32_t D, int32_t F, int64_t B, const int32_t* row_ptr, const int64_t* ids, const float* weights,
                    int64_t nnz, float* emb_out, float* lin_out, float* fm_out, float* fm_sum,
-                   int32_t* err_flag, void* stream);
+                   int32_t* err_flag, const xdfm_row_age* age, void* stream);
 
 /* Plain row gather: out[i,:] = table[rows[i],:], lin_out[i] = lin_w[rows[i]] (NULL ok).
  * No counterpart in the reference (one device, one table): it is the owner-side lookup of the
@@ -156,10 +218,12 @@ int xdfm_embed_fwd(const float* table, const float* lin_w, int64_t table_stride,
  * does with one token of weight 1 per row, without spending a wave per row.
  * out_stride: floats between consecutive rows of `out` and between consecutive entries of
  * `lin_out` (0 = dense D / 1): with out and lin_out pointing into one buffer of
- * [row | linear weight | pad] records, rows and weights travel in one all-to-all. */
+ * [row | linear weight | pad] records, rows and weights travel in one all-to-all.
+ * age (NULL ok): rows are aged as they are read (xdfm_row_age above). */
 int xdfm_embed_gather(const float* table, const float* lin_w, int64_t table_stride,
                       int64_t lin_stride, int64_t N, int32_t D, const int64_t* rows, int64_t n, float* out,
-                      float* lin_out, int64_t out_stride, int32_t* err_flag, void* stream);
+                      float* lin_out, int64_t out_stride, int32_t* err_flag, const xdfm_row_age* age,
+                      void* stream);
 
 /* ------------------------------------------------------------------------
  * Routing for the row-sharded table (owner = id mod G, local row = id div G).
@@ -208,37 +272,17 @@ int xdfm_embed_plan_static(const int64_t* ids, int64_t nnz, int64_t N, int32_t* 
 int xdfm_embed_plan_gather(const int32_t* sorted_tok, const int32_t* tok_row, const float* weights,
                            int64_t nnz, int32_t* row_sorted, float* w_sorted, void* stream);
 
-typedef struct xdfm_opt_args {
-  int32_t kind;       /* XDFM_OPT_* */
-  float lr;           /* learning_rate */
-  float beta1, beta2; /* Adam */
-  float eps;          /* Adam epsilon (outside the sqrt, TF1 placement) */
-  float beta1_power;  /* beta1^t, t = 1-based step being applied */
-  float beta2_power;  /* beta2^t */
-  float l2;           /* coefficient of sum(p^2)/2, gradient l2*p */
-  float l1;           /* coefficient of sum|p|, gradient l1*sign(p) */
-  float clip_norm;    /* >0: per-tensor tf.clip_by_norm(g, clip_norm); 0: off */
-  int32_t reserved;   /* keeps the pointer below 8-byte aligned; set to 0 */
-  /* Optional device scalars (NULL: use beta1_power / beta2_power above).  opt_state[2] is the
-   * Adam step size lr*sqrt(1-beta2^t)/(1-beta1^t) kept up to date by xdfm_opt_advance; with it
-   * no host value changes from step to step, so a step can be captured in a HIP graph. */
-  const float* opt_state;
-} xdfm_opt_args;
-
-/* opt_state[4] = {beta1^t, beta2^t, step size, t}: advance t by one (one tiny kernel).
- * Initialise the buffer to {1, 1, 0, 0} before the first step.  Build extra. */
-int xdfm_opt_advance(float* opt_state, float lr, float beta1, float beta2, void* stream);
-
 /* Segment sum of the per-token gradient contributions
  *     c_j = w_j*d_emb[row_j,:] + g[b_j]*w_j*(fm_sum[b_j,:] - w_j*table[id_j,:])   (FM term optional)
  *     l_j = g[b_j]*w_j                                                            (linear, optional)
- * over equal ids in sorted order, then
+ * over equal ids in sorted order (the FM term's common factor table[id,:] is taken out of the sum: the
+ * row is read once per segment, where it is updated), then
  *   mode 0 (sparse_rows): apply `opt` to the touched rows of table (+slots) and lin_w in place;
  *   (table_stride / lin_stride as for xdfm_embed_fwd: they address table, slot_m, slot_v and
  *   lin_w, lin_m, lin_v; grad_table / grad_lin are always dense)
  *   mode 1 (scatter)    : store the sums into grad_table[N,D] / grad_lin[N] (rows of untouched
  *                         ids are left as they are: the caller keeps them zero).
- *   pieces: float scratch of 2*(nnz/64 + 1)*(D + 1) elements (partial sums of the segments that
+ *   pieces: float scratch of 2*(nnz/64 + 1)*(D + 2) elements (partial sums of the segments that
  *   cross a 64-token chunk boundary).
  *   sorted_tok = NULL: tok_row and weights are already in sorted order (xdfm_embed_plan_gather).
  *   d_emb[B,F,D]; d_emb2: NULL, or a second [B,F,D] array added to d_emb as it is read (two
@@ -247,7 +291,9 @@ int xdfm_opt_advance(float* opt_state, float lr, float beta1, float beta2, void*
  *   grad_stride (0 = dense): floats between consecutive gradient records.  Mode 1 then writes
  *   row i at grad_table + i*grad_stride and its linear gradient at grad_lin + i*grad_stride;
  *   mode 0 reads d_emb / d_emb2 rows and g_logit entries at that stride (the owner side of the
- *   row-sharded table gets [gradient row | linear gradient | pad] records from one all-to-all). */
+ *   row-sharded table gets [gradient row | linear gradient | pad] records from one all-to-all).
+ *   age (NULL ok, mode 0): the rows are aged in the registers of their update (xdfm_row_age above;
+ *   step_offset = -1 when xdfm_opt_advance has already counted this step). */
 int xdfm_embed_bwd(int32_t mode, float* table, float* slot_m, float* slot_v, float* lin_w,
                    float* lin_m, float* lin_v, int64_t table_stride, int64_t lin_stride,
                    float* grad_table, float* grad_lin, int64_t N,
@@ -255,25 +301,14 @@ int xdfm_embed_bwd(int32_t mode, float* table, float* slot_m, float* slot_v, flo
                    const int32_t* sorted_tok, const int32_t* tok_row, const float* weights,
                    int64_t nnz, const float* d_emb, const float* g_logit, const float* fm_sum,
                    int32_t use_fm, const xdfm_opt_args* opt, float* pieces, const float* d_emb2,
-                   int64_t grad_stride, void* stream);
-/* Lazy-row catch-up: makes sparse row updates (xdfm_embed_bwd mode 0) give the reference's numbers.
- * In the reference the table's gradient is dense (the regulariser ops of base_model.py:121-149 sit on
- * the table even at coefficient 0; SURVEY.md 8a A2/O1), so apply_gradients (base_model.py:322) moves
- * every row every step: a row without a token in the batch still takes Adam's m <- b1 m, v <- b2 v,
- * p <- p - lr_t m / (sqrt(v) + eps).  row_step[id] (int32, entries step_stride apart, 0 = dense)
- * records the step a row's (p, m, v) are current for; this call brings the rows named by sorted_ids
- * (the first position of each run of equal ids works; NULL: all N rows, n ignored) up to the step
- * count in opt->opt_state[3] and writes that count + advance into row_step (advance = 1 before a
- * training step whose xdfm_embed_bwd will update exactly these rows; 0 for a flush before scoring or
- * a checkpoint; -1 takes a mark back: rows dated later than the step count -- prepared for a step that
- * then went to another batch -- are re-dated to it, nothing else changes).  The first 24 missed steps are applied one by one in TF's expression order, the
- * geometric remainder in closed form (|error| < 1e-5).  RMSProp / Adadelta decay their accumulators;
- * FTRL re-derives p = -linear / quadratic as TF's dense ApplyFtrl does every step (a row that never
- * had a gradient becomes 0); SGD and Adagrad have no drift (a no-op apart from row_step). */
+                   int64_t grad_stride, const xdfm_row_age* age, void* stream);
+/* Writes aged rows back: the rows named by sorted_ids (the first position of each run of equal ids
+ * works; NULL: all N rows, n ignored) are brought up to opt_state[3] + age->step_offset steps and
+ * row_step is set to that count (xdfm_row_age above; age->slot_* are ignored, the slots are arguments).
+ * Needed only where the table is read by something that does not age rows itself: checkpoints, exports. */
 int xdfm_embed_catchup(float* table, float* slot_m, float* slot_v, float* lin_w, float* lin_m,
-                       float* lin_v, int32_t* row_step, int64_t table_stride, int64_t lin_stride,
-                       int64_t step_stride, int64_t N, int32_t D, const int32_t* sorted_ids, int64_t n,
-                       int32_t advance, const xdfm_opt_args* opt, void* stream);
+                       float* lin_v, int64_t table_stride, int64_t lin_stride, int64_t N, int32_t D,
+                       const int32_t* sorted_ids, int64_t n, const xdfm_row_age* age, void* stream);
 /* zero the rows of grad_table / grad_lin named by sorted_ids (restores the all-zero invariant) */
 int xdfm_embed_clear_rows(float* grad_table, float* grad_lin, int32_t D,
                           const int32_t* sorted_ids, int64_t nnz, void* stream);

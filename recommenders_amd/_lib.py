@@ -15,7 +15,7 @@ import os
 # then satisfies libxdfm.so's NEEDED libamdhip64.so.7 by soname from the already loaded one.
 import torch  # noqa: F401  (must precede the CDLL below)
 
-__all__ = ["lib", "check", "XdfmLibraryError", "XdfmError", "OptArgs", "BatchInfo", "LIB_PATH"]
+__all__ = ["lib", "check", "XdfmLibraryError", "XdfmError", "OptArgs", "RowAge", "BatchInfo", "LIB_PATH"]
 
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libxdfm.so")
 
@@ -47,6 +47,23 @@ class OptArgs(ctypes.Structure):
         ("clip_norm", ctypes.c_float),
         ("reserved", ctypes.c_int32),
         ("opt_state", ctypes.c_void_p),
+    ]
+
+
+class RowAge(ctypes.Structure):
+    """struct xdfm_row_age"""
+
+    _fields_ = [
+        ("row_step", ctypes.c_void_p),
+        ("step_stride", ctypes.c_int64),
+        ("slot_m", ctypes.c_void_p),
+        ("slot_v", ctypes.c_void_p),
+        ("lin_m", ctypes.c_void_p),
+        ("lin_v", ctypes.c_void_p),
+        ("drift_tab", ctypes.c_void_p),
+        ("opt", ctypes.POINTER(OptArgs)),
+        ("step_offset", ctypes.c_int32),
+        ("reserved", ctypes.c_int32),
     ]
 
 
@@ -95,8 +112,9 @@ SIGNATURES = {
     "xdfm_ffm_fill": [_P] * 11,
     "xdfm_ffm_close": [_P],
     "xdfm_build_row_ptr": [_P, _I64, _I64, _P, _P, _P, _P],
-    "xdfm_embed_fwd": [_P, _P, _I64, _I64, _I64, _I32, _I32, _I64, _P, _P, _P, _I64, _P, _P, _P, _P, _P, _P],
-    "xdfm_embed_gather": [_P, _P, _I64, _I64, _I64, _I32, _P, _I64, _P, _P, _I64, _P, _P],
+    "xdfm_embed_fwd": [_P, _P, _I64, _I64, _I64, _I32, _I32, _I64, _P, _P, _P, _I64, _P, _P, _P, _P, _P,
+                       ctypes.POINTER(RowAge), _P],
+    "xdfm_embed_gather": [_P, _P, _I64, _I64, _I64, _I32, _P, _I64, _P, _P, _I64, _P, ctypes.POINTER(RowAge), _P],
     "xdfm_route_keys": [_P, _I64, _I64, _I32, _P, _P],
     "xdfm_route_scratch_ints": [_I64, _PSZ],
     "xdfm_route_uniq": [_P, _P, _I64, _I64, _I32, _P, _P, _P, _P, _P, _P],
@@ -105,11 +123,13 @@ SIGNATURES = {
     "xdfm_embed_plan_static": [_P, _I64, _I64, _P, _P, _P],
     "xdfm_embed_plan_gather": [_P, _P, _P, _I64, _P, _P, _P],
     "xdfm_embed_bwd": [_I32, _P, _P, _P, _P, _P, _P, _I64, _I64, _P, _P, _I64, _I32, _I32, _I64, _P, _P, _P,
-                       _P, _I64, _P, _P, _P, _I32, ctypes.POINTER(OptArgs), _P, _P, _I64, _P],
-    "xdfm_embed_catchup": [_P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _I32, _P, _I64, _I32,
-                           ctypes.POINTER(OptArgs), _P],
+                       _P, _I64, _P, _P, _P, _I32, ctypes.POINTER(OptArgs), _P, _P, _I64, ctypes.POINTER(RowAge),
+                       _P],
+    "xdfm_embed_catchup": [_P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I32, _P, _I64, ctypes.POINTER(RowAge), _P],
     "xdfm_embed_clear_rows": [_P, _P, _I32, _P, _I64, _P],
-    "xdfm_opt_advance": [_P, ctypes.c_float, ctypes.c_float, ctypes.c_float, _P],
+    "xdfm_opt_advance": [_P, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, _P, _P],
+    "xdfm_drift_tab_floats": [_PSZ],
+    "xdfm_drift_tab_init": [_P, _P, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, _P],
     "xdfm_dense_update": [_P, _P, _P, _P, _I32, _P, _P, _P, _P, ctypes.POINTER(OptArgs), _P, _P,
                           _I32, _P],
     "xdfm_dense_reg_loss": [_P, _I32, _P, _P, _P, _P, _P, _P, _I32, _P],

@@ -18,6 +18,7 @@
 
 #include <cstring>
 
+#include "drift.h"
 #include "xdfm_common.h"
 
 namespace {
@@ -72,173 +73,7 @@ __global__ void build_row_ptr_kernel(const int64_t* __restrict__ idx, int64_t nn
   if (err) atomicOr(err_flag, err);
 }
 
-// ---------------------------------------------------------------- forward
-// One wave per sample.  LPR = D/VEC lanes cover one output row (VEC floats each), so a
-// wave gathers 64/LPR rows per pass and writes them as one contiguous span of emb_out.
-// The sample's per-dimension sums (FM) and its linear term are reduced through LDS in a
-// fixed order, so the result does not depend on scheduling.
-template <int VEC>
-__global__ __launch_bounds__(256) void embed_fwd_kernel(
-    const float* __restrict__ table, const float* __restrict__ lin_w, int64_t TS, int64_t LS, int64_t N,
-    int D, int F, int64_t B, const int32_t* __restrict__ row_ptr, const int64_t* __restrict__ ids,
-    const float* __restrict__ weights, int64_t nnz, float* __restrict__ emb_out, float* __restrict__ lin_out,
-    float* __restrict__ fm_out, float* __restrict__ fm_sum, int32_t* err_flag) {
-  __shared__ float red_s[4][kWave][VEC];
-  __shared__ float red_q[4][kWave][VEC];
-  __shared__ float red_l[4][kWave];
-  const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
-  const int64_t b = (int64_t)blockIdx.x * 4 + wave;
-  const int LPR = D / VEC;
-  const int RPP = kWave / LPR;  // rows per pass
-  const int g = lane / LPR;
-  const int c = lane - g * LPR;
-  const bool lane_on = (g < RPP) && (b < B);
-  const bool want_fm = (fm_out != nullptr) || (fm_sum != nullptr);
-
-  float s_acc[VEC], q_acc[VEC];
-#pragma unroll
-  for (int v = 0; v < VEC; ++v) s_acc[v] = q_acc[v] = 0.f;
-  float lin_acc = 0.f;
-  int err = 0;
-
-  if (lane_on) {
-    // Up to PU rows per lane group are handled together: their CSR bounds, then their first
-    // tokens, then the table rows of those tokens are each requested in one go, so a sample
-    // costs three memory round trips instead of three per row.  Further tokens of a multi-hot
-    // row follow in column order (the sums stay bit-identical to the sequential form).
-    constexpr int PU = 4;
-    for (int f0 = g; f0 < F; f0 += PU * RPP) {
-      int beg[PU], end[PU];
-      int64_t id0[PU];
-      float w0[PU];
-      bool has[PU];
-      // The CSR bounds and, speculatively, the token a single-hot batch keeps at position r (one
-      // token per row: row_ptr is the identity) are requested together: two memory round trips
-      // instead of three when the guess holds, which it does for every row of Criteo-shaped data.
-#pragma unroll
-      for (int u = 0; u < PU; ++u) {
-        const int f = f0 + u * RPP;
-        const int64_t r = b * F + (f < F ? f : F - 1);
-        beg[u] = row_ptr[r];
-        end[u] = row_ptr[r + 1];
-        const int64_t guess = r < nnz ? r : 0;
-        id0[u] = nnz > 0 ? ids[guess] : 0;  // a batch without tokens has no array to guess in
-        w0[u] = nnz > 0 ? weights[guess] : 0.f;
-        if (f >= F) end[u] = beg[u];  // no such row: behaves as empty, nothing is stored
-      }
-#pragma unroll
-      for (int u = 0; u < PU; ++u) {
-        has[u] = end[u] > beg[u];
-        const int f = f0 + u * RPP;
-        const int64_t r = b * F + (f < F ? f : F - 1);
-        if (has[u] && beg[u] != r) {  // not where the guess looked
-          id0[u] = ids[beg[u]];
-          w0[u] = weights[beg[u]];
-        }
-      }
-      float e0[PU][VEC];
-      float l0[PU];
-      bool ok0[PU];
-#pragma unroll
-      for (int u = 0; u < PU; ++u) {
-        ok0[u] = has[u] && (uint64_t)id0[u] < (uint64_t)N;
-        const int64_t idc = ok0[u] ? id0[u] : 0;
-        load_vec<VEC>(table + idc * TS + c * VEC, e0[u]);
-        l0[u] = (c == 0 && lin_w) ? lin_w[idc * LS] : 0.f;
-      }
-#pragma unroll
-      for (int u = 0; u < PU; ++u) {
-        const int f = f0 + u * RPP;
-        if (f >= F) continue;
-        const int64_t r = b * F + f;
-        float acc[VEC];
-#pragma unroll
-        for (int v = 0; v < VEC; ++v) acc[v] = 0.f;
-        if (has[u]) {
-          if (ok0[u]) {
-#pragma unroll
-            for (int v = 0; v < VEC; ++v) {
-              const float t = w0[u] * e0[u][v];  // one rounding (TF: embeddings *= weights)
-              acc[v] = t;
-              q_acc[v] += t * t;
-            }
-            if (c == 0 && lin_w) lin_acc += w0[u] * l0[u];
-          } else {
-            err |= XDFM_DEVERR_ID_RANGE;
-          }
-        }
-        bool first = !(has[u] && ok0[u]);  // no valid token summed yet
-        for (int k = beg[u] + 1; k < end[u]; ++k) {
-          const int64_t id = ids[k];
-          const float w = weights[k];
-          if ((uint64_t)id >= (uint64_t)N) {
-            err |= XDFM_DEVERR_ID_RANGE;
-            continue;
-          }
-          float e[VEC];
-          load_vec<VEC>(table + id * TS + c * VEC, e);
-#pragma unroll
-          for (int v = 0; v < VEC; ++v) {
-            const float t = w * e[v];
-            acc[v] = first ? t : acc[v] + t;  // segment_sum in column order
-            q_acc[v] += t * t;
-          }
-          first = false;
-          if (c == 0 && lin_w) lin_acc += w * lin_w[id * LS];
-        }
-        store_vec<VEC>(emb_out + r * D + c * VEC, acc);
-#pragma unroll
-        for (int v = 0; v < VEC; ++v) s_acc[v] += acc[v];
-      }
-    }
-  }
-  if (err) atomicOr(err_flag, err);
-  if (!want_fm && !lin_out) return;  // uniform over the block
-
-#pragma unroll
-  for (int v = 0; v < VEC; ++v) {
-    red_s[wave][lane][v] = lane_on ? s_acc[v] : 0.f;
-    red_q[wave][lane][v] = lane_on ? q_acc[v] : 0.f;
-  }
-  red_l[wave][lane] = (lane_on && c == 0) ? lin_acc : 0.f;
-  __syncthreads();
-  const bool valid = b < B;  // no early exit: every wave takes part in the barriers below
-  // lanes 0..LPR-1: sum their column chunk over the row groups, in group order
-  float part = 0.f;
-  if (valid && lane < LPR) {
-    float s[VEC], q[VEC];
-#pragma unroll
-    for (int v = 0; v < VEC; ++v) s[v] = q[v] = 0.f;
-    for (int gg = 0; gg < RPP; ++gg) {
-#pragma unroll
-      for (int v = 0; v < VEC; ++v) {
-        s[v] += red_s[wave][gg * LPR + lane][v];
-        q[v] += red_q[wave][gg * LPR + lane][v];
-      }
-    }
-    if (fm_sum) store_vec<VEC>(fm_sum + b * D + lane * VEC, s);
-#pragma unroll
-    for (int v = 0; v < VEC; ++v) part += s[v] * s[v] - q[v];
-  }
-  __syncthreads();
-  red_s[wave][lane][0] = part;
-  __syncthreads();
-  if (valid && lane == 0) {
-    if (fm_out) {
-      float tot = 0.f;
-      for (int cc = 0; cc < LPR; ++cc) tot += red_s[wave][cc][0];
-      fm_out[b] = 0.5f * tot;
-    }
-    if (lin_out) {
-      float tot = 0.f;
-      for (int gg = 0; gg < RPP; ++gg) tot += red_l[wave][gg * LPR];
-      lin_out[b] = tot;
-    }
-  }
-}
-
-// ---------------------------------------------------------------- backward
+// ---------------------------------------------------------------- optimizer rows
 struct OptDev {
   int kind;
   float lr, alpha, one_minus_b1, one_minus_b2, eps;
@@ -258,11 +93,11 @@ struct RowVals {
 };
 
 template <int VEC>
-__device__ __forceinline__ void row_load(const OptDev& o, const float* p, const float* m, const float* v,
+__device__ __forceinline__ void row_load(int kind, const float* p, const float* m, const float* v,
                                          RowVals<VEC>& r) {
   load_vec<VEC>(p, r.p);
-  if (opt_uses_m(o.kind)) load_vec<VEC>(m, r.m);
-  if (opt_uses_v(o.kind)) load_vec<VEC>(v, r.v);
+  if (opt_uses_m(kind)) load_vec<VEC>(m, r.m);
+  if (opt_uses_v(kind)) load_vec<VEC>(v, r.v);
 }
 
 template <int VEC>
@@ -319,21 +154,326 @@ __device__ __forceinline__ void row_update(const OptDev& o, RowVals<VEC>& r, con
 }
 
 template <int VEC>
-__device__ __forceinline__ void row_store(const OptDev& o, float* p, float* m, float* v, const RowVals<VEC>& r) {
-  if (opt_uses_m(o.kind)) store_vec<VEC>(m, r.m);
-  if (opt_uses_v(o.kind)) store_vec<VEC>(v, r.v);
+__device__ __forceinline__ void row_store(int kind, float* p, float* m, float* v, const RowVals<VEC>& r) {
+  if (opt_uses_m(kind)) store_vec<VEC>(m, r.m);
+  if (opt_uses_v(kind)) store_vec<VEC>(v, r.v);
   store_vec<VEC>(p, r.p);
 }
 
-template <int VEC>
-__device__ __forceinline__ void apply_row(const OptDev& o, float* p, float* m, float* v,
-                                          const float (&g)[VEC]) {
-  RowVals<VEC> r;
-  row_load<VEC>(o, p, m, v, r);
-  row_update<VEC>(o, r, g);
-  row_store<VEC>(o, p, m, v, r);
+// ---------------------------------------------------------------- row ageing
+// The reference's table gradient is dense (base_model.py:121-149 put regulariser ops on the table even
+// at coefficient 0, SURVEY.md 8a A2), so TF's Adam moves EVERY row EVERY step: a row without a token in
+// the batch still takes m <- b1 m, v <- b2 v, p <- p - lr_t m / (sqrt(v) + eps).  The sparse-row update
+// skips those steps; row_step[id] records the step a row's stored (p, m, v) are current for, and whoever
+// reads the row applies the G = done - row_step steps it missed in closed form (drift.h):
+//   * the forward gather and the owner-side row gather form the aged row in registers and write nothing;
+//   * the row update ages (p, m, v) in the registers it loads them into anyway, then applies the
+//     gradient: one read-modify-write per updated row and step, rows absent from the batch are not
+//     touched at all;
+//   * xdfm_embed_catchup writes aged rows back (before checkpoints / table exports).
+// RMSProp / Adadelta only decay their accumulators (no gradient, no movement); FTRL re-derives the row
+// from its slots (TF does so every step: rows that never had a gradient become 0); SGD and Adagrad
+// have nothing to age.
+struct AgeDev {
+  int32_t* row_step;  // null: rows are always current
+  int64_t SS;         // 4-byte words between consecutive entries of row_step
+  const float *slot_m, *slot_v, *lin_m, *lin_v;  // the slots as the gathers read them
+  const float4* tab;   // drift table (Adam), null for the other optimizers
+  const float* state;  // opt_state: [3] = optimizer steps applied so far
+  int step_off;        // rows are aged to (int)state[3] + step_off steps
+  int kind;
+  int packed_tail;  // lin_w, lin_m, lin_v, row_step are the four words of one aligned 16-byte group per row
+  float lr, ebar, lg_b1, lg_b2;
+};
+
+__device__ __forceinline__ bool age_needed(int kind, int last, int G) {
+  // last == 0: never updated; Adam's / Adadelta's slots are still zero: no drift (RMSProp's rms starts
+  // at 1 and decays from the first step on, FTRL rewrites the row at its first step)
+  return G > 0 && (last > 0 || kind == XDFM_OPT_RMSPROP || kind == XDFM_OPT_FTRL);
 }
 
+__device__ __forceinline__ float4 drift_coeffs(const AgeDev& a, const float4* cur_s, int last, int G) {
+  if (a.kind != XDFM_OPT_ADAM) return make_float4(0.f, 0.f, 0.f, 0.f);
+  if (G < xdfm::kDriftG) return cur_s[G];
+  return a.tab[2 * xdfm::kDriftG + (last < xdfm::kDriftS ? last : xdfm::kDriftS)];
+}
+
+template <int VEC>
+__device__ __forceinline__ void age_vals(const AgeDev& a, const float4 cf, RowVals<VEC>& r, int G) {
+  if (a.kind == XDFM_OPT_ADAM) {
+    // the hardware's square root and reciprocal (1 ulp each): the drift is orders of magnitude below the
+    // parameter, the difference to the correctly rounded forms never reaches the parameter's last bits
+    const float pw1 = exp2f((float)G * a.lg_b1), pw2 = exp2f((float)G * a.lg_b2);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      const float y = __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(r.v[i]) + a.ebar);
+      r.p[i] = r.p[i] - r.m[i] * y * (cf.x - y * (cf.y - y * cf.z));
+      r.m[i] = r.m[i] * pw1;
+      r.v[i] = r.v[i] * pw2;
+    }
+  } else if (a.kind == XDFM_OPT_RMSPROP) {
+    const float pw = exp2f((float)G * a.lg_b2);  // ms <- ms + (0 - ms)(1 - decay), G times
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) r.m[i] = r.m[i] * pw;
+  } else if (a.kind == XDFM_OPT_ADADELTA) {
+    const float pw = exp2f((float)G * a.lg_b2);  // accum and accum_update both decay by rho per step
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      r.m[i] = r.m[i] * pw;
+      r.v[i] = r.v[i] * pw;
+    }
+  } else if (a.kind == XDFM_OPT_FTRL) {
+    // TF's dense ApplyFtrl rewrites var = -linear / quadratic every step, gradient or not: a row that
+    // never had a gradient (linear = 0) becomes 0 at the first step; an updated row is a fixed point
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) r.p[i] = -r.v[i] / (sqrtf(r.m[i]) / a.lr);
+  }
+}
+
+// A table row with what ageing it needs, requested in one go and resolved when the values are used.
+template <int VEC>
+struct RowReq {
+  RowVals<VEC> r;
+  RowVals<1> l;  // the row's linear weight and its slots (lanes with want_lin)
+  int last;
+};
+
+template <int VEC, bool AGE>
+__device__ __forceinline__ void row_request(const float* table, const float* lin_w, int64_t TS, int64_t LS,
+                                            const AgeDev& ag, int64_t id, int c, bool want_lin, RowReq<VEC>& q) {
+  const int64_t off = id * TS + c * VEC;
+  load_vec<VEC>(table + off, q.r.p);
+  q.l.p[0] = q.l.m[0] = q.l.v[0] = 0.f;
+  q.last = 0;
+  if (AGE) {
+    if (opt_uses_m(ag.kind)) load_vec<VEC>(ag.slot_m + off, q.r.m);
+    if (opt_uses_v(ag.kind)) load_vec<VEC>(ag.slot_v + off, q.r.v);
+    if (ag.packed_tail) {
+      const float4 t = *reinterpret_cast<const float4*>(lin_w + id * LS);
+      q.l.p[0] = t.x;
+      q.l.m[0] = t.y;
+      q.l.v[0] = t.z;
+      q.last = __float_as_int(t.w);
+    } else {
+      q.last = ag.row_step[id * ag.SS];
+      if (want_lin) {
+        q.l.p[0] = lin_w[id * LS];
+        if (opt_uses_m(ag.kind)) q.l.m[0] = ag.lin_m[id * LS];
+        if (opt_uses_v(ag.kind)) q.l.v[0] = ag.lin_v[id * LS];
+      }
+    }
+  } else if (want_lin) {
+    q.l.p[0] = lin_w[id * LS];
+  }
+}
+
+template <int VEC, bool AGE>
+__device__ __forceinline__ void row_resolve(const AgeDev& ag, const float4* cur_s, int done, bool want_lin,
+                                            RowReq<VEC>& q) {
+  if (!AGE) return;
+  const int G = done - q.last;
+  if (age_needed(ag.kind, q.last, G)) {
+    const float4 cf = drift_coeffs(ag, cur_s, q.last, G);
+    age_vals<VEC>(ag, cf, q.r, G);
+    if (want_lin) age_vals<1>(ag, cf, q.l, G);
+  }
+}
+
+// ---------------------------------------------------------------- forward
+// One wave per sample.  LPR = D/VEC lanes cover one output row (VEC floats each), so a
+// wave gathers 64/LPR rows per pass and writes them as one contiguous span of emb_out.
+// The sample's per-dimension sums (FM) and its linear term are reduced through LDS in a
+// fixed order, so the result does not depend on scheduling.
+// AGE: rows are read together with their slots and row_step and aged in registers (see above).
+struct FwdArgs {
+  const float *table, *lin_w;
+  int64_t TS, LS, N, B, nnz;
+  int D, F;
+  const int32_t* row_ptr;
+  const int64_t* ids;
+  const float* weights;
+  float *emb_out, *lin_out, *fm_out, *fm_sum;
+  int32_t* err_flag;
+  AgeDev age;
+};
+
+template <int VEC, bool AGE>
+__global__ __launch_bounds__(256) void embed_fwd_kernel(FwdArgs a) {
+  __shared__ float red_s[4][kWave][VEC];
+  __shared__ float red_q[4][kWave][VEC];
+  __shared__ float red_l[4][kWave];
+  __shared__ float4 cur_s[AGE ? xdfm::kDriftG : 1];
+  const float* __restrict__ table = a.table;
+  const float* __restrict__ lin_w = a.lin_w;
+  const int64_t TS = a.TS, LS = a.LS, N = a.N, B = a.B, nnz = a.nnz;
+  const int D = a.D, F = a.F;
+  const int32_t* __restrict__ row_ptr = a.row_ptr;
+  const int64_t* __restrict__ ids = a.ids;
+  const float* __restrict__ weights = a.weights;
+  float* __restrict__ emb_out = a.emb_out;
+  float* lin_out = a.lin_out;
+  float* fm_out = a.fm_out;
+  float* fm_sum = a.fm_sum;
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int64_t b = (int64_t)blockIdx.x * 4 + wave;
+  const int LPR = D / VEC;
+  const int RPP = kWave / LPR;  // rows per pass
+  const int g = lane / LPR;
+  const int c = lane - g * LPR;
+  const bool lane_on = (g < RPP) && (b < B);
+  const bool want_fm = (fm_out != nullptr) || (fm_sum != nullptr);
+  // the linear weight rides with lane c == 0 of a row (under ageing also when only its row_step is wanted)
+  const bool want_lin = c == 0 && lin_w != nullptr;
+  int done = 0;
+  if (AGE) {
+    done = (int)a.age.state[3] + a.age.step_off;
+    if (a.age.tab) cur_s[threadIdx.x] = a.age.tab[(done & 1) * xdfm::kDriftG + threadIdx.x];
+    __syncthreads();
+  }
+
+  float s_acc[VEC], q_acc[VEC];
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) s_acc[v] = q_acc[v] = 0.f;
+  float lin_acc = 0.f;
+  int err = 0;
+
+  if (lane_on) {
+    // Up to PU rows per lane group are handled together: their CSR bounds, then their first
+    // tokens, then the table rows of those tokens are each requested in one go, so a sample
+    // costs three memory round trips instead of three per row.  Further tokens of a multi-hot
+    // row follow in column order (the sums stay bit-identical to the sequential form).
+    constexpr int PU = 4;
+    for (int f0 = g; f0 < F; f0 += PU * RPP) {
+      int beg[PU], end[PU];
+      int64_t id0[PU];
+      float w0[PU];
+      bool has[PU];
+      // The CSR bounds and, speculatively, the token a single-hot batch keeps at position r (one
+      // token per row: row_ptr is the identity) are requested together: two memory round trips
+      // instead of three when the guess holds, which it does for every row of Criteo-shaped data.
+#pragma unroll
+      for (int u = 0; u < PU; ++u) {
+        const int f = f0 + u * RPP;
+        const int64_t r = b * F + (f < F ? f : F - 1);
+        beg[u] = row_ptr[r];
+        end[u] = row_ptr[r + 1];
+        const int64_t guess = r < nnz ? r : 0;
+        id0[u] = nnz > 0 ? ids[guess] : 0;  // a batch without tokens has no array to guess in
+        w0[u] = nnz > 0 ? weights[guess] : 0.f;
+        if (f >= F) end[u] = beg[u];  // no such row: behaves as empty, nothing is stored
+      }
+#pragma unroll
+      for (int u = 0; u < PU; ++u) {
+        has[u] = end[u] > beg[u];
+        const int f = f0 + u * RPP;
+        const int64_t r = b * F + (f < F ? f : F - 1);
+        if (has[u] && beg[u] != r) {  // not where the guess looked
+          id0[u] = ids[beg[u]];
+          w0[u] = weights[beg[u]];
+        }
+      }
+      RowReq<VEC> rq[PU];
+      bool ok0[PU];
+#pragma unroll
+      for (int u = 0; u < PU; ++u) {
+        ok0[u] = has[u] && (uint64_t)id0[u] < (uint64_t)N;
+        row_request<VEC, AGE>(table, lin_w, TS, LS, a.age, ok0[u] ? id0[u] : 0, c, want_lin, rq[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < PU; ++u) {
+        const int f = f0 + u * RPP;
+        if (f >= F) continue;
+        const int64_t r = b * F + f;
+        float acc[VEC];
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) acc[v] = 0.f;
+        if (has[u]) {
+          if (ok0[u]) {
+            row_resolve<VEC, AGE>(a.age, cur_s, done, want_lin, rq[u]);
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) {
+              const float t = w0[u] * rq[u].r.p[v];  // one rounding (TF: embeddings *= weights)
+              acc[v] = t;
+              q_acc[v] += t * t;
+            }
+            if (want_lin) lin_acc += w0[u] * rq[u].l.p[0];
+          } else {
+            err |= XDFM_DEVERR_ID_RANGE;
+          }
+        }
+        bool first = !(has[u] && ok0[u]);  // no valid token summed yet
+        for (int k = beg[u] + 1; k < end[u]; ++k) {
+          const int64_t id = ids[k];
+          const float w = weights[k];
+          if ((uint64_t)id >= (uint64_t)N) {
+            err |= XDFM_DEVERR_ID_RANGE;
+            continue;
+          }
+          RowReq<VEC> q;
+          row_request<VEC, AGE>(table, lin_w, TS, LS, a.age, id, c, want_lin, q);
+          row_resolve<VEC, AGE>(a.age, cur_s, done, want_lin, q);
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) {
+            const float t = w * q.r.p[v];
+            acc[v] = first ? t : acc[v] + t;  // segment_sum in column order
+            q_acc[v] += t * t;
+          }
+          first = false;
+          if (want_lin) lin_acc += w * q.l.p[0];
+        }
+        store_vec<VEC>(emb_out + r * D + c * VEC, acc);
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) s_acc[v] += acc[v];
+      }
+    }
+  }
+  if (err) atomicOr(a.err_flag, err);
+  if (!want_fm && !lin_out) return;  // uniform over the block
+
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) {
+    red_s[wave][lane][v] = lane_on ? s_acc[v] : 0.f;
+    red_q[wave][lane][v] = lane_on ? q_acc[v] : 0.f;
+  }
+  red_l[wave][lane] = (lane_on && c == 0) ? lin_acc : 0.f;
+  __syncthreads();
+  const bool valid = b < B;  // no early exit: every wave takes part in the barriers below
+  // lanes 0..LPR-1: sum their column chunk over the row groups, in group order
+  float part = 0.f;
+  if (valid && lane < LPR) {
+    float s[VEC], q[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) s[v] = q[v] = 0.f;
+    for (int gg = 0; gg < RPP; ++gg) {
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) {
+        s[v] += red_s[wave][gg * LPR + lane][v];
+        q[v] += red_q[wave][gg * LPR + lane][v];
+      }
+    }
+    if (fm_sum) store_vec<VEC>(fm_sum + b * D + lane * VEC, s);
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) part += s[v] * s[v] - q[v];
+  }
+  __syncthreads();
+  red_s[wave][lane][0] = part;
+  __syncthreads();
+  if (valid && lane == 0) {
+    if (fm_out) {
+      float tot = 0.f;
+      for (int cc = 0; cc < LPR; ++cc) tot += red_s[wave][cc][0];
+      fm_out[b] = 0.5f * tot;
+    }
+    if (lin_out) {
+      float tot = 0.f;
+      for (int gg = 0; gg < RPP; ++gg) tot += red_l[wave][gg * LPR];
+      lin_out[b] = tot;
+    }
+  }
+}
+
+// ---------------------------------------------------------------- backward
 struct BwdArgs {
   float *table, *slot_m, *slot_v, *lin_w, *lin_m, *lin_v, *grad_table, *grad_lin;
   int64_t N, B, nnz;
@@ -344,30 +484,92 @@ struct BwdArgs {
   const float *weights, *d_emb, *d_emb2, *g_logit, *fm_sum;
   int use_fm;
   OptDev opt;
-  float* pieces;      // head[nchunks][D], tail[nchunks][D], head_lin[nchunks], tail_lin[nchunks]
+  AgeDev age;
+  float* pieces;  // head[nchunks][D], tail[nchunks][D], then head / tail [nchunks] of the linear and of the FM scalar
 };
 
-template <int VEC, int MODE>
-__device__ __forceinline__ void finish_row(const BwdArgs& a, int id, int c, const float (&acc)[VEC],
-                                           float lacc) {
+// A row about to be finished: requested early (with the gather of its gradient), completed when the
+// segment's sum is known.  The gradient of a segment (one id) is
+//     sum_j (w_j d_emb[row_j] + gw_j fm_sum[b_j])  -  E[id] * sum_j gw_j w_j,       gw_j = g[b_j] w_j
+// (the FM term of every token of a segment has the same table row E[id] as its factor: it is taken
+// out of the sum, so no token reads the table -- the row is read once, where it is updated, and under
+// ageing it is the aged row, the one the forward pass used).
+template <int VEC>
+struct RowState {
+  RowVals<VEC> rv;
+  RowVals<1> rl;
+  int last;
+};
+
+template <int VEC, int MODE, bool AGE>
+__device__ __forceinline__ void finish_request(const BwdArgs& a, int key, int c, RowState<VEC>& s) {
+  s.last = 0;
   if (MODE == 0) {
-    const int64_t off = (int64_t)id * a.TS + c * VEC;
-    apply_row<VEC>(a.opt, a.table + off, a.slot_m + off, a.slot_v + off, acc);
-    if (a.lin_w && c == 0) {
-      float g1[1] = {lacc};
-      const int64_t lo = (int64_t)id * a.LS;
-      apply_row<1>(a.opt, a.lin_w + lo, a.lin_m + lo, a.lin_v + lo, g1);
+    const int64_t off = (int64_t)key * a.TS + c * VEC;
+    const int64_t lo = (int64_t)key * a.LS;
+    row_load<VEC>(a.opt.kind, a.table + off, a.slot_m + off, a.slot_v + off, s.rv);
+    if (AGE && a.age.packed_tail) {
+      const float4 t = *reinterpret_cast<const float4*>(a.lin_w + lo);
+      s.rl.p[0] = t.x;
+      s.rl.m[0] = t.y;
+      s.rl.v[0] = t.z;
+      s.last = __float_as_int(t.w);
+    } else {
+      if (a.lin_w && c == 0) row_load<1>(a.opt.kind, a.lin_w + lo, a.lin_m + lo, a.lin_v + lo, s.rl);
+      if (AGE) s.last = a.age.row_step[(int64_t)key * a.age.SS];
+    }
+  } else if (a.use_fm) {
+    load_vec<VEC>(a.table + (int64_t)key * a.TS + c * VEC, s.rv.p);
+  }
+}
+
+template <int VEC, int MODE, bool AGE>
+__device__ __forceinline__ void finish_complete(const BwdArgs& a, const float4* cur_s, int done, int key, int c,
+                                                RowState<VEC>& s, float (&g)[VEC], float lsum, float fsum) {
+  if (MODE == 0) {
+    const bool lin = a.lin_w != nullptr && c == 0;
+    if (AGE) {
+      const int G = done - s.last;
+      if (age_needed(a.age.kind, s.last, G)) {
+        const float4 cf = drift_coeffs(a.age, cur_s, s.last, G);
+        age_vals<VEC>(a.age, cf, s.rv, G);
+        if (lin) age_vals<1>(a.age, cf, s.rl, G);
+      }
+    }
+    if (a.use_fm) {
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) g[k] = g[k] - s.rv.p[k] * fsum;
+    }
+    const int64_t off = (int64_t)key * a.TS + c * VEC;
+    const int64_t lo = (int64_t)key * a.LS;
+    row_update<VEC>(a.opt, s.rv, g);
+    row_store<VEC>(a.opt.kind, a.table + off, a.slot_m + off, a.slot_v + off, s.rv);
+    if (lin) {
+      const float g1[1] = {lsum};
+      row_update<1>(a.opt, s.rl, g1);
+    }
+    if (AGE && a.age.packed_tail) {
+      if (c == 0)
+        *reinterpret_cast<float4*>(a.lin_w + lo) =
+            make_float4(s.rl.p[0], s.rl.m[0], s.rl.v[0], __int_as_float(done + 1));
+    } else {
+      if (lin) row_store<1>(a.opt.kind, a.lin_w + lo, a.lin_m + lo, a.lin_v + lo, s.rl);
+      if (AGE && c == 0) a.age.row_step[(int64_t)key * a.age.SS] = done + 1;
     }
   } else {
-    const int64_t off = (int64_t)id * a.GS + c * VEC;
-    store_vec<VEC>(a.grad_table + off, acc);
-    if (a.grad_lin && c == 0) a.grad_lin[(int64_t)id * a.GLS] = lacc;
+    if (a.use_fm) {
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) g[k] = g[k] - s.rv.p[k] * fsum;
+    }
+    const int64_t off = (int64_t)key * a.GS + c * VEC;
+    store_vec<VEC>(a.grad_table + off, g);
+    if (a.grad_lin && c == 0) a.grad_lin[(int64_t)key * a.GLS] = lsum;
   }
 }
 
 // Segment sum over the id-sorted token list, one wave per chunk of 64 sorted positions.
 //  * lane = position: loads key / token / row / weight once, and runs a 6-step segmented
-//    scan of the linear-part scalar g*w.
+//    scan of the linear-part scalar g*w and of the FM scalar g*w*w.
 //  * the D-wide contributions are handled R = 64/LPR positions per pass (LPR = D/VEC lanes
 //    own one row, VEC floats each): gather, then a log2(R)-step segmented inclusive scan
 //    across the lane groups with cross-lane shuffles; a carry links the passes.
@@ -384,18 +586,40 @@ __device__ __forceinline__ void shfl_vec(const float (&v)[VEC], int src, float (
   for (int k = 0; k < VEC; ++k) o[k] = __shfl(v[k], src);
 }
 
-template <int VEC, int MODE>
+struct Pieces {
+  float *head_vec, *tail_vec, *head_lin, *tail_lin, *head_fm, *tail_fm;
+};
+__device__ __forceinline__ Pieces pieces_of(const BwdArgs& a, int64_t nchunks) {
+  Pieces p;
+  p.head_vec = a.pieces;
+  p.tail_vec = p.head_vec + nchunks * a.D;
+  p.head_lin = p.tail_vec + nchunks * a.D;
+  p.tail_lin = p.head_lin + nchunks;
+  p.head_fm = p.tail_lin + nchunks;
+  p.tail_fm = p.head_fm + nchunks;
+  return p;
+}
+
+template <int VEC, int MODE, bool AGE>
 __global__ __launch_bounds__(256) void embed_bwd_kernel(BwdArgs a) {
+  __shared__ float4 cur_s[AGE ? xdfm::kDriftG : 1];
+  int done = 0;
+  if (AGE) {
+    done = (int)a.age.state[3] + a.age.step_off;
+    if (a.age.tab) cur_s[threadIdx.x] = a.age.tab[(done & 1) * xdfm::kDriftG + threadIdx.x];
+    __syncthreads();
+  }
   const int lane = threadIdx.x & 63;
   const int64_t chunk = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int64_t p0 = chunk * kChunk;
-  if (p0 >= a.nnz) return;  // wave-uniform; the kernel has no barrier
+  if (p0 >= a.nnz) return;  // wave-uniform; no barrier below
   const int LPR = a.D / VEC;
   const int R = 64 / LPR;
   const int g = lane / LPR;
   const int c = lane - g * LPR;
   const int nvalid = (int)((a.nnz - p0 < kChunk) ? (a.nnz - p0) : kChunk);
-  const bool need_g = a.use_fm || a.lin_w != nullptr;
+  const bool use_lin = a.lin_w != nullptr;
+  const bool need_g = a.use_fm || use_lin;
 
   // ---- per-position metadata
   const bool pv = lane < nvalid;
@@ -414,22 +638,23 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(BwdArgs a) {
   const bool cont_next = next_key == last_key;
   const int key_after = __shfl_down(key, 1);  // key of position lane+1 (garbage for lane 63)
 
-  // ---- linear part: segmented inclusive scan of g*w over the 64 positions
-  float lsum = gw;
-  if (a.lin_w != nullptr) {
+  // ---- scalars: segmented inclusive scans of g*w (linear part) and g*w*w (FM) over the 64 positions
+  float lsum = gw, fsum = gw * w;
+  if (need_g) {
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
       const float o = __shfl_up(lsum, d);
+      const float of = __shfl_up(fsum, d);
       const int ko = __shfl_up(key, d);
-      if (lane >= d && ko == key) lsum += o;
+      if (lane >= d && ko == key) {
+        lsum += o;
+        fsum += of;
+      }
     }
   }
 
-  float* head_vec = a.pieces;
   const int64_t nchunks = (a.nnz + kChunk - 1) / kChunk;
-  float* tail_vec = head_vec + nchunks * a.D;
-  float* head_lin = tail_vec + nchunks * a.D;
-  float* tail_lin = head_lin + nchunks;
+  const Pieces pc = pieces_of(a, nchunks);
 
   float carry[VEC];
 #pragma unroll
@@ -447,6 +672,7 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(BwdArgs a) {
     const float gw_q = __shfl(gw, qs);
     const int keyn_q = __shfl(key_after, qs);
     const float lsum_q = __shfl(lsum, qs);
+    const float fsum_q = __shfl(fsum, qs);
     // what becomes of this position's running sum is known from the keys alone: a row that will
     // be finished in this pass is requested now, together with the gather of its gradient
     const bool chunk_end = q == nvalid - 1;
@@ -454,14 +680,8 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(BwdArgs a) {
     const bool to_head = cont_prev && key_q == first_key;
     const bool to_tail = chunk_end && cont_next;
     const bool finish = seg_end && !to_head && !to_tail;
-    RowVals<VEC> rv;
-    RowVals<1> rl;
-    if (MODE == 0 && finish) {
-      const int64_t off = (int64_t)key_q * a.TS + c * VEC;
-      const int64_t lo = (int64_t)key_q * a.LS;
-      row_load<VEC>(a.opt, a.table + off, a.slot_m + off, a.slot_v + off, rv);
-      if (a.lin_w && c == 0) row_load<1>(a.opt, a.lin_w + lo, a.lin_m + lo, a.lin_v + lo, rl);
-    }
+    RowState<VEC> rs;
+    if (finish) finish_request<VEC, MODE, AGE>(a, key_q, c, rs);
     float v[VEC];
 #pragma unroll
     for (int k = 0; k < VEC; ++k) v[k] = 0.f;
@@ -478,11 +698,10 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(BwdArgs a) {
 #pragma unroll
       for (int k = 0; k < VEC; ++k) v[k] = w_q * de[k];
       if (a.use_fm) {
-        float e[VEC], sfm[VEC];
-        load_vec<VEC>(a.table + (int64_t)key_q * a.TS + c * VEC, e);
+        float sfm[VEC];
         load_vec<VEC>(a.fm_sum + (int64_t)(row_q / a.F) * a.D + c * VEC, sfm);
 #pragma unroll
-        for (int k = 0; k < VEC; ++k) v[k] = fmaf(gw_q, sfm[k] - w_q * e[k], v[k]);
+        for (int k = 0; k < VEC; ++k) v[k] = fmaf(gw_q, sfm[k], v[k]);
       }
       if (g == 0 && carry_key == key_q) {
 #pragma unroll
@@ -508,23 +727,19 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(BwdArgs a) {
     }
     if (seg_end) {
       if (to_head) {
-        store_vec<VEC>(head_vec + chunk * a.D + c * VEC, v);
-        if (c == 0) head_lin[chunk] = lsum_q;
+        store_vec<VEC>(pc.head_vec + chunk * a.D + c * VEC, v);
+        if (c == 0) {
+          pc.head_lin[chunk] = lsum_q;
+          pc.head_fm[chunk] = fsum_q;
+        }
       } else if (to_tail) {
-        store_vec<VEC>(tail_vec + chunk * a.D + c * VEC, v);
-        if (c == 0) tail_lin[chunk] = lsum_q;
-      } else if (MODE == 0) {
-        const int64_t off = (int64_t)key_q * a.TS + c * VEC;
-        row_update<VEC>(a.opt, rv, v);
-        row_store<VEC>(a.opt, a.table + off, a.slot_m + off, a.slot_v + off, rv);
-        if (a.lin_w && c == 0) {
-          const float g1[1] = {lsum_q};
-          const int64_t lo = (int64_t)key_q * a.LS;
-          row_update<1>(a.opt, rl, g1);
-          row_store<1>(a.opt, a.lin_w + lo, a.lin_m + lo, a.lin_v + lo, rl);
+        store_vec<VEC>(pc.tail_vec + chunk * a.D + c * VEC, v);
+        if (c == 0) {
+          pc.tail_lin[chunk] = lsum_q;
+          pc.tail_fm[chunk] = fsum_q;
         }
       } else {
-        finish_row<VEC, MODE>(a, key_q, c, v, lsum_q);
+        finish_complete<VEC, MODE, AGE>(a, cur_s, done, key_q, c, rs, v, lsum_q, fsum_q);
       }
     }
   }
@@ -532,8 +747,15 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(BwdArgs a) {
 
 // One wave per chunk boundary.  The wave whose boundary is the first one a segment crosses
 // adds the segment's pieces in chunk order and finishes the row.
-template <int VEC, int MODE>
+template <int VEC, int MODE, bool AGE>
 __global__ __launch_bounds__(256) void embed_bwd_long_kernel(BwdArgs a) {
+  __shared__ float4 cur_s[AGE ? xdfm::kDriftG : 1];
+  int done = 0;
+  if (AGE) {
+    done = (int)a.age.state[3] + a.age.step_off;
+    if (a.age.tab) cur_s[threadIdx.x] = a.age.tab[(done & 1) * xdfm::kDriftG + threadIdx.x];
+    __syncthreads();
+  }
   const int lane = threadIdx.x & 63;
   const int64_t c1 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6) + 1;  // boundary between c1-1 and c1
   const int64_t nchunks = (a.nnz + kChunk - 1) / kChunk;
@@ -541,6 +763,12 @@ __global__ __launch_bounds__(256) void embed_bwd_long_kernel(BwdArgs a) {
   const int key = a.sorted_ids[c1 * kChunk];
   if (a.sorted_ids[c1 * kChunk - 1] != key) return;                           // no segment crosses here
   if (c1 >= 2 && a.sorted_ids[(c1 - 1) * kChunk - 1] == key) return;          // an earlier boundary owns it
+  const int LPR = a.D / VEC;
+  const int R = 64 / LPR;
+  const int g = lane / LPR;
+  const int c = lane - g * LPR;
+  RowState<VEC> rs;
+  if (g == 0) finish_request<VEC, MODE, AGE>(a, key, c, rs);
   // last chunk of the segment: first chunk ce >= c1 whose successor does not start with key
   int64_t ce = c1;
   for (;;) {
@@ -553,14 +781,7 @@ __global__ __launch_bounds__(256) void embed_bwd_long_kernel(BwdArgs a) {
     }
     ce += 64;
   }
-  const float* head_vec = a.pieces;
-  const float* tail_vec = head_vec + nchunks * a.D;
-  const float* head_lin = tail_vec + nchunks * a.D;
-  const float* tail_lin = head_lin + nchunks;
-  const int LPR = a.D / VEC;
-  const int R = 64 / LPR;
-  const int g = lane / LPR;
-  const int c = lane - g * LPR;
+  const Pieces pc = pieces_of(a, nchunks);
   // group g adds pieces g, g+R, ... (piece 0 = tail[c1-1], piece k = head[c1+k-1]) in order
   const int64_t npieces = ce - c1 + 2;
   float v[VEC];
@@ -569,7 +790,7 @@ __global__ __launch_bounds__(256) void embed_bwd_long_kernel(BwdArgs a) {
   if (g < R) {
     for (int64_t k = g; k < npieces; k += R) {
       float pv[VEC];
-      const float* src = (k == 0) ? tail_vec + (c1 - 1) * a.D : head_vec + (c1 + k - 1) * a.D;
+      const float* src = (k == 0) ? pc.tail_vec + (c1 - 1) * a.D : pc.head_vec + (c1 + k - 1) * a.D;
       load_vec<VEC>(src + c * VEC, pv);
 #pragma unroll
       for (int kx = 0; kx < VEC; ++kx) v[kx] += pv[kx];
@@ -585,14 +806,21 @@ __global__ __launch_bounds__(256) void embed_bwd_long_kernel(BwdArgs a) {
       for (int kx = 0; kx < VEC; ++kx) v[kx] += o[kx];
     }
   }
-  float lsum = 0.f;
-  if (a.lin_w != nullptr) {
-    for (int64_t k = lane; k < npieces; k += 64) lsum += (k == 0) ? tail_lin[c1 - 1] : head_lin[c1 + k - 1];
+  float lsum = 0.f, fsum = 0.f;
+  if (a.lin_w != nullptr || a.use_fm) {
+    for (int64_t k = lane; k < npieces; k += 64) {
+      lsum += (k == 0) ? pc.tail_lin[c1 - 1] : pc.head_lin[c1 + k - 1];
+      fsum += (k == 0) ? pc.tail_fm[c1 - 1] : pc.head_fm[c1 + k - 1];
+    }
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) lsum += __shfl_down(lsum, d);
+    for (int d = 32; d >= 1; d >>= 1) {
+      lsum += __shfl_down(lsum, d);
+      fsum += __shfl_down(fsum, d);
+    }
     lsum = __shfl(lsum, 0);
+    fsum = __shfl(fsum, 0);
   }
-  if (g == 0) finish_row<VEC, MODE>(a, key, c, v, lsum);
+  if (g == 0) finish_complete<VEC, MODE, AGE>(a, cur_s, done, key, c, rs, v, lsum, fsum);
 }
 
 __global__ void plan_gather_kernel(const int32_t* __restrict__ sorted_tok, const int32_t* __restrict__ tok_row,
@@ -636,6 +864,47 @@ int make_opt(const xdfm_opt_args* opt, OptDev* o) {
   return XDFM_OK;
 }
 
+// Device view of xdfm_row_age.  lin_w / LS: the linear weights the call itself addresses (null: none);
+// need_slots: the call reads the slots through the struct (the gathers; the row update has them as
+// arguments of its own).
+int make_age(const xdfm_row_age* age, const float* lin_w, int64_t LS, bool need_slots, AgeDev* a) {
+  memset(a, 0, sizeof(*a));
+  if (!age) return XDFM_OK;
+  XDFM_REQUIRE(age->row_step && age->opt && age->opt->opt_state,
+               "row ageing needs row_step and the optimizer arguments with opt_state");
+  const xdfm_opt_args* opt = age->opt;
+  XDFM_REQUIRE(opt->kind >= XDFM_OPT_SGD && opt->kind <= XDFM_OPT_FTRL, "unknown optimizer kind %d", opt->kind);
+  XDFM_REQUIRE(opt->kind != XDFM_OPT_ADAM || age->drift_tab, "row ageing under Adam needs the drift table");
+  XDFM_REQUIRE(age->step_offset >= -1 && age->step_offset <= 0, "row ageing: step_offset must be 0 or -1");
+  const bool um = opt->kind != XDFM_OPT_SGD, uv = xdfm::opt_needs_v(opt->kind);
+  if (need_slots) {
+    XDFM_REQUIRE((!um || age->slot_m) && (!uv || age->slot_v), "row ageing: table slot missing");
+    XDFM_REQUIRE(!lin_w || ((!um || age->lin_m) && (!uv || age->lin_v)), "row ageing: lin slot missing");
+  }
+  a->row_step = age->row_step;
+  a->SS = age->step_stride ? age->step_stride : 1;
+  a->slot_m = age->slot_m;
+  a->slot_v = age->slot_v;
+  a->lin_m = age->lin_m;
+  a->lin_v = age->lin_v;
+  a->tab = opt->kind == XDFM_OPT_ADAM ? reinterpret_cast<const float4*>(age->drift_tab) : nullptr;
+  a->state = opt->opt_state;
+  a->step_off = age->step_offset;
+  a->kind = opt->kind;
+  a->lr = opt->lr;
+  a->ebar = opt->eps * exp2f(-(float)xdfm::kDriftC * 0.5f * log2f(opt->beta2));
+  a->lg_b1 = opt->beta1 > 0.f ? log2f(opt->beta1) : 0.f;
+  a->lg_b2 = opt->beta2 > 0.f ? log2f(opt->beta2) : 0.f;
+  return XDFM_OK;
+}
+
+// one aligned 16-byte group [lin w | lin m | lin v | row_step] per row (the record layout of the engine)
+bool tail_is_packed(const AgeDev& a, const float* lin_w, const float* lin_m, const float* lin_v, int64_t LS) {
+  return a.row_step && lin_w && a.kind != XDFM_OPT_SGD && xdfm::opt_needs_v(a.kind) && lin_m == lin_w + 1 &&
+         lin_v == lin_w + 2 && reinterpret_cast<const float*>(a.row_step) == lin_w + 3 && a.SS == LS &&
+         (LS % 4) == 0 && (reinterpret_cast<uintptr_t>(lin_w) % 16) == 0;
+}
+
 }  // namespace
 
 extern "C" int xdfm_build_row_ptr(const int64_t* dnn_feat_indices, int64_t nnz, int64_t n_rows,
@@ -665,7 +934,8 @@ extern "C" int xdfm_embed_fwd(const float* table, const float* lin_w, int64_t ta
                               int64_t lin_stride, int64_t N, int32_t D,
                               int32_t F, int64_t B, const int32_t* row_ptr, const int64_t* ids,
                               const float* weights, int64_t nnz, float* emb_out, float* lin_out,
-                              float* fm_out, float* fm_sum, int32_t* err_flag, void* stream) {
+                              float* fm_out, float* fm_sum, int32_t* err_flag, const xdfm_row_age* age,
+                              void* stream) {
   XDFM_REQUIRE(table && row_ptr && emb_out && err_flag, "xdfm_embed_fwd: null argument");
   XDFM_REQUIRE(nnz == 0 || (ids && weights), "xdfm_embed_fwd: null token arrays");
   XDFM_REQUIRE(N > 0 && D > 0 && F > 0 && B >= 0, "xdfm_embed_fwd: bad sizes");
@@ -674,73 +944,121 @@ extern "C" int xdfm_embed_fwd(const float* table, const float* lin_w, int64_t ta
   XDFM_REQUIRE(D / vec <= kWave, "xdfm_embed_fwd: dim %d not supported (needs D/%d <= 64)", D, vec);
   XDFM_REQUIRE(strides_ok(&table_stride, &lin_stride, D, vec), "xdfm_embed_fwd: bad row strides");
   if (B == 0) return XDFM_OK;
+  FwdArgs a;
+  memset(&a, 0, sizeof(a));
+  a.table = table;
+  a.lin_w = lin_out ? lin_w : nullptr;
+  a.TS = table_stride;
+  a.LS = lin_stride;
+  a.N = N;
+  a.B = B;
+  a.nnz = nnz;
+  a.D = D;
+  a.F = F;
+  a.row_ptr = row_ptr;
+  a.ids = ids;
+  a.weights = weights;
+  a.emb_out = emb_out;
+  a.lin_out = lin_out;
+  a.fm_out = fm_out;
+  a.fm_sum = fm_sum;
+  a.err_flag = err_flag;
+  int rc = make_age(age, a.lin_w, lin_stride, true, &a.age);
+  if (rc) return rc;
+  a.age.packed_tail = tail_is_packed(a.age, a.lin_w, a.age.lin_m, a.age.lin_v, lin_stride) ? 1 : 0;
   const unsigned blocks = (unsigned)((B + 3) / 4);
-#define LAUNCH(V)                                                                               \
-  XDFM_LAUNCH("embed_fwd_kernel<" #V ">", stream, embed_fwd_kernel<V>, dim3(blocks), dim3(256), 0, table, \
-                     lin_out ? lin_w : nullptr, table_stride, lin_stride, N, D, F, B, row_ptr, ids,    \
-                     weights, nnz, emb_out, lin_out, fm_out, fm_sum, err_flag)
-  if (vec == 4)
-    LAUNCH(4);
-  else if (vec == 2)
-    LAUNCH(2);
-  else
-    LAUNCH(1);
+#define LAUNCH(V, A) \
+  XDFM_LAUNCH("embed_fwd_kernel<" #V ", " #A ">", stream, (embed_fwd_kernel<V, A>), dim3(blocks), dim3(256), 0, a)
+  if (a.age.row_step) {
+    if (vec == 4) LAUNCH(4, true); else if (vec == 2) LAUNCH(2, true); else LAUNCH(1, true);
+  } else {
+    if (vec == 4) LAUNCH(4, false); else if (vec == 2) LAUNCH(2, false); else LAUNCH(1, false);
+  }
 #undef LAUNCH
   XDFM_LAUNCH_CHECK();
   return XDFM_OK;
 }
 
 // plain row gather (owner side of the row-sharded table): D/VEC lanes per row
-template <int VEC>
-__global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ table,
-                                                          const float* __restrict__ lin_w, int64_t TS,
-                                                          int64_t LS, int64_t N, int D,
-                                                          const int64_t* __restrict__ rows,
-                                                          int64_t n, float* __restrict__ out,
-                                                          float* __restrict__ lin_out, int64_t OS, int64_t OLS,
-                                                          int32_t* err_flag) {
-  const int LPR = D / VEC;
+struct GatherArgs {
+  const float *table, *lin_w;
+  int64_t TS, LS, N, n, OS, OLS;
+  int D;
+  const int64_t* rows;
+  float *out, *lin_out;
+  int32_t* err_flag;
+  AgeDev age;
+};
+
+template <int VEC, bool AGE>
+__global__ __launch_bounds__(256) void gather_rows_kernel(GatherArgs a) {
+  __shared__ float4 cur_s[AGE ? xdfm::kDriftG : 1];
+  int done = 0;
+  if (AGE) {
+    done = (int)a.age.state[3] + a.age.step_off;
+    if (a.age.tab) cur_s[threadIdx.x] = a.age.tab[(done & 1) * xdfm::kDriftG + threadIdx.x];
+    __syncthreads();
+  }
+  const int LPR = a.D / VEC;
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t r = t / LPR;
   const int c = (int)(t - r * LPR);
-  if (r >= n) return;
-  int64_t id = rows[r];
-  if ((uint64_t)id >= (uint64_t)N) {
-    atomicOr(err_flag, XDFM_DEVERR_ID_RANGE);
+  if (r >= a.n) return;
+  int64_t id = a.rows[r];
+  if ((uint64_t)id >= (uint64_t)a.N) {
+    atomicOr(a.err_flag, XDFM_DEVERR_ID_RANGE);
     id = 0;
   }
-  float e[VEC];
-  load_vec<VEC>(table + id * TS + c * VEC, e);
-  store_vec<VEC>(out + r * OS + c * VEC, e);
-  if (lin_out && c == 0) lin_out[r * OLS] = lin_w[id * LS];
+  const bool want_lin = c == 0 && a.lin_out != nullptr;
+  RowReq<VEC> q;
+  row_request<VEC, AGE>(a.table, a.lin_w, a.TS, a.LS, a.age, id, c, want_lin, q);
+  row_resolve<VEC, AGE>(a.age, cur_s, done, want_lin, q);
+  store_vec<VEC>(a.out + r * a.OS + c * VEC, q.r.p);
+  if (want_lin) a.lin_out[r * a.OLS] = q.l.p[0];
 }
 
 extern "C" int xdfm_embed_gather(const float* table, const float* lin_w, int64_t table_stride,
                                  int64_t lin_stride, int64_t N, int32_t D,
                                  const int64_t* rows, int64_t n, float* out, float* lin_out,
-                                 int64_t out_stride, int32_t* err_flag, void* stream) {
+                                 int64_t out_stride, int32_t* err_flag, const xdfm_row_age* age, void* stream) {
   XDFM_REQUIRE(table && out && err_flag, "xdfm_embed_gather: null argument");
   XDFM_REQUIRE(N > 0 && D > 0 && n >= 0, "xdfm_embed_gather: bad sizes");
   XDFM_REQUIRE(!lin_out || lin_w, "xdfm_embed_gather: lin_out needs lin_w");
   if (n == 0) return XDFM_OK;
   XDFM_REQUIRE(rows, "xdfm_embed_gather: null rows");
   const int vec = pick_vec(D);
+  XDFM_REQUIRE(D / vec <= kWave, "xdfm_embed_gather: dim %d not supported", D);
   XDFM_REQUIRE(strides_ok(&table_stride, &lin_stride, D, vec), "xdfm_embed_gather: bad row strides");
   // out_stride: floats between consecutive output rows AND between consecutive lin_out entries
   // (one buffer of [row | linear weight | pad] records goes through one all-to-all); 0 = dense
   XDFM_REQUIRE(out_stride == 0 || (out_stride >= D && out_stride % vec == 0), "xdfm_embed_gather: bad out_stride");
-  const int64_t os = out_stride ? out_stride : D, ols = out_stride ? out_stride : 1;
+  GatherArgs a;
+  memset(&a, 0, sizeof(a));
+  a.table = table;
+  a.lin_w = lin_out ? lin_w : nullptr;
+  a.TS = table_stride;
+  a.LS = lin_stride;
+  a.N = N;
+  a.n = n;
+  a.OS = out_stride ? out_stride : D;
+  a.OLS = out_stride ? out_stride : 1;
+  a.D = D;
+  a.rows = rows;
+  a.out = out;
+  a.lin_out = lin_out;
+  a.err_flag = err_flag;
+  int rc = make_age(age, a.lin_w, lin_stride, true, &a.age);
+  if (rc) return rc;
+  a.age.packed_tail = tail_is_packed(a.age, a.lin_w, a.age.lin_m, a.age.lin_v, lin_stride) ? 1 : 0;
   const int64_t threads = n * (D / vec);
   const unsigned blocks = (unsigned)((threads + 255) / 256);
-#define LAUNCH(V)                                                                                          \
-  XDFM_LAUNCH("gather_rows_kernel<" #V ">", stream, gather_rows_kernel<V>, dim3(blocks), dim3(256), 0, table, \
-              lin_out ? lin_w : nullptr, table_stride, lin_stride, N, D, rows, n, out, lin_out, os, ols, err_flag)
-  if (vec == 4)
-    LAUNCH(4);
-  else if (vec == 2)
-    LAUNCH(2);
-  else
-    LAUNCH(1);
+#define LAUNCH(V, A) \
+  XDFM_LAUNCH("gather_rows_kernel<" #V ", " #A ">", stream, (gather_rows_kernel<V, A>), dim3(blocks), dim3(256), 0, a)
+  if (a.age.row_step) {
+    if (vec == 4) LAUNCH(4, true); else if (vec == 2) LAUNCH(2, true); else LAUNCH(1, true);
+  } else {
+    if (vec == 4) LAUNCH(4, false); else if (vec == 2) LAUNCH(2, false); else LAUNCH(1, false);
+  }
 #undef LAUNCH
   XDFM_LAUNCH_CHECK();
   return XDFM_OK;
@@ -754,13 +1072,15 @@ extern "C" int xdfm_embed_bwd(int32_t mode, float* table, float* slot_m, float* 
                               const int32_t* tok_row, const float* weights, int64_t nnz,
                               const float* d_emb, const float* g_logit, const float* fm_sum,
                               int32_t use_fm, const xdfm_opt_args* opt, float* pieces,
-                              const float* d_emb2, int64_t grad_stride, void* stream) {
+                              const float* d_emb2, int64_t grad_stride, const xdfm_row_age* age,
+                              void* stream) {
   XDFM_REQUIRE(mode == 0 || mode == 1, "xdfm_embed_bwd: mode must be 0 or 1");
   XDFM_REQUIRE(N > 0 && D > 0 && F > 0 && B >= 0 && nnz >= 0, "xdfm_embed_bwd: bad sizes");
   if (nnz == 0) return XDFM_OK;
   XDFM_REQUIRE(sorted_ids && tok_row && weights && d_emb && pieces,
                "xdfm_embed_bwd: null argument");
   XDFM_REQUIRE(!use_fm || (g_logit && fm_sum && table), "xdfm_embed_bwd: FM needs g_logit, fm_sum, table");
+  XDFM_REQUIRE(!age || mode == 0, "xdfm_embed_bwd: rows are aged where they are updated (mode 0)");
   BwdArgs a;
   memset(&a, 0, sizeof(a));
   if (mode == 0) {
@@ -777,6 +1097,7 @@ extern "C" int xdfm_embed_bwd(int32_t mode, float* table, float* slot_m, float* 
       XDFM_REQUIRE(opt->kind == XDFM_OPT_SGD || lin_m, "xdfm_embed_bwd: lin slot missing");
       XDFM_REQUIRE(!xdfm::opt_needs_v(opt->kind) || lin_v, "xdfm_embed_bwd: lin slot_v missing");
     }
+    XDFM_REQUIRE(!age || (age->opt && age->opt->kind == opt->kind), "xdfm_embed_bwd: age->opt must name the same optimizer");
   } else {
     XDFM_REQUIRE(grad_table, "xdfm_embed_bwd: scatter mode needs grad_table");
     XDFM_REQUIRE(!grad_lin || g_logit, "xdfm_embed_bwd: linear part needs g_logit");
@@ -793,8 +1114,6 @@ extern "C" int xdfm_embed_bwd(int32_t mode, float* table, float* slot_m, float* 
   a.B = B;
   a.nnz = nnz;
   a.D = D;
-  a.TS = table_stride;
-  a.LS = lin_stride;
   a.F = F;
   a.sorted_ids = sorted_ids;
   a.sorted_tok = sorted_tok;
@@ -816,128 +1135,49 @@ extern "C" int xdfm_embed_bwd(int32_t mode, float* table, float* slot_m, float* 
   XDFM_REQUIRE(grad_stride == 0 || (grad_stride >= D && grad_stride % vec == 0), "xdfm_embed_bwd: bad grad_stride");
   a.GS = grad_stride ? grad_stride : D;
   a.GLS = grad_stride ? grad_stride : 1;
+  int rc = make_age(mode == 0 ? age : nullptr, lin_w, lin_stride, false, &a.age);
+  if (rc) return rc;
+  a.age.packed_tail = (mode == 0 && tail_is_packed(a.age, lin_w, lin_m, lin_v, lin_stride)) ? 1 : 0;
   hipStream_t st = (hipStream_t)stream;
   const int64_t nchunks = (nnz + kChunk - 1) / kChunk;
   const unsigned blocks = (unsigned)((nchunks + 3) / 4);
   const unsigned blocks_long = (unsigned)((nchunks + 3) / 4);  // boundaries 1 .. nchunks-1
-#define LAUNCH(V, M)                                                                          \
-  do {                                                                                        \
-    XDFM_LAUNCH("embed_bwd_kernel<" #V ", " #M ">", st, (embed_bwd_kernel<V, M>), dim3(blocks), dim3(256), 0, a);          \
-    XDFM_LAUNCH("embed_bwd_long_kernel<" #V ", " #M ">", st, (embed_bwd_long_kernel<V, M>), dim3(blocks_long), dim3(256), 0, a); \
+#define LAUNCH(V, M, A)                                                                                          \
+  do {                                                                                                           \
+    XDFM_LAUNCH("embed_bwd_kernel<" #V ", " #M ", " #A ">", st, (embed_bwd_kernel<V, M, A>), dim3(blocks),      \
+                dim3(256), 0, a);                                                                                \
+    XDFM_LAUNCH("embed_bwd_long_kernel<" #V ", " #M ", " #A ">", st, (embed_bwd_long_kernel<V, M, A>),          \
+                dim3(blocks_long), dim3(256), 0, a);                                                             \
   } while (0)
-  if (mode == 0) {
-    if (vec == 4) LAUNCH(4, 0); else if (vec == 2) LAUNCH(2, 0); else LAUNCH(1, 0);
+  if (mode == 0 && a.age.row_step) {
+    if (vec == 4) LAUNCH(4, 0, true); else if (vec == 2) LAUNCH(2, 0, true); else LAUNCH(1, 0, true);
+  } else if (mode == 0) {
+    if (vec == 4) LAUNCH(4, 0, false); else if (vec == 2) LAUNCH(2, 0, false); else LAUNCH(1, 0, false);
   } else {
-    if (vec == 4) LAUNCH(4, 1); else if (vec == 2) LAUNCH(2, 1); else LAUNCH(1, 1);
+    if (vec == 4) LAUNCH(4, 1, false); else if (vec == 2) LAUNCH(2, 1, false); else LAUNCH(1, 1, false);
   }
 #undef LAUNCH
   XDFM_LAUNCH_CHECK();
   return XDFM_OK;
 }
 
-// ---------------------------------------------------------------- lazy-row catch-up
-// The reference's table gradient is dense (base_model.py:121-149 put regulariser ops on the table even
-// at coefficient 0, SURVEY.md 8a A2), so TF's Adam moves EVERY row EVERY step: a row without a token in
-// the batch still takes m <- b1 m, v <- b2 v, p <- p - lr_t m / (sqrt(v) + eps).  The sparse-row update
-// skips those steps; this kernel applies them when the row is next needed, so that sparse rows give the
-// reference's numbers.  row_step[id] = the step the row's (p, m, v) are current for.  A row G steps
-// behind takes its first kCatchExact missed steps one by one in TF's own expression order; the rest of
-// the geometric tail (its weight is b1^kCatchExact of the whole drift) through a log-linear fit of
-// lr_t / (sqrt(v b2^i) + eps) over the next steps, worst case 4e-6 absolute at lr 0.002
-// (tools/catchup_sim.py).
-// RMSProp / Adadelta only decay their accumulators (no gradient, no movement); FTRL re-derives the row
-// from its slots (TF does so every step: rows that never had a gradient become 0); SGD and Adagrad
-// have nothing to catch up with.
-constexpr int kCatchExact = 24;
-
+// ---------------------------------------------------------------- aged rows written back
+// One lane group (LPR = D/VEC lanes) per sorted position, groups never straddle a wave; only the
+// first position of an id's run works.
 struct CatchArgs {
   float *table, *slot_m, *slot_v, *lin_w, *lin_m, *lin_v;
-  int32_t* row_step;
-  int64_t TS, LS, SS, N, n;
-  int D, advance;
+  int64_t TS, LS, N, n;
+  int D;
   const int32_t* sorted_ids;  // null: every row 0..N-1
-  OptDev opt;
-  float b1, b2;
+  AgeDev age;
 };
 
 template <int VEC>
-__device__ __forceinline__ void catchup_vals(const CatchArgs& a, RowVals<VEC>& r, int last, int G) {
-  const OptDev& o = a.opt;
-  const float lb1 = log2f(a.b1), lb2 = log2f(a.b2);
-  if (o.kind == XDFM_OPT_ADAM) {
-    // while lr_t still bends (the first steps of training) more steps are taken one by one
-    const int k0 = kCatchExact + (last < 64 ? 64 - last : 0);
-    const int kx = G < k0 ? G : k0;
-    float b1j = exp2f((float)(last + 1) * lb1), b2j = exp2f((float)(last + 1) * lb2);
-    // The hardware's square root and reciprocal (1 ulp each) instead of the correctly rounded library
-    // forms: a step's increment is orders of magnitude below the parameter, so the difference never
-    // reaches the parameter's last bit, and the loop is a third as long (it shares the SIMDs with the
-    // backward pass's matrix kernels: 109 -> 59 us, and the step 0.571 -> 0.523 ms).  Tried and dropped:
-    // handing only the runs' first positions out to the lane groups (a ballot per 64 positions) -- a
-    // quarter of the waves, each with two dependent rounds: 112 us, the kernel is latency-bound after this.
-    // ... and the loop itself is kept to one reciprocal per element and step (the transcendental unit
-    // runs at a quarter of the rate): sqrt(v b2^k) is carried as sqrt(v) g^k, g = sqrt(b2), and m, v
-    // decay by one multiplication each (TF writes m + (0 - m)(1 - b1): the same number to an ulp).
-    const float g = sqrtf(a.b2);
-    float sv[VEC];
-#pragma unroll
-    for (int i = 0; i < VEC; ++i) sv[i] = __builtin_amdgcn_sqrtf(r.v[i]);
-    for (int k = 0; k < kx; ++k) {
-      const float alpha = o.lr * __builtin_amdgcn_sqrtf(1.f - b2j) * __builtin_amdgcn_rcpf(1.f - b1j);
-#pragma unroll
-      for (int i = 0; i < VEC; ++i) {
-        r.m[i] *= a.b1;
-        r.v[i] *= a.b2;
-        sv[i] *= g;
-        r.p[i] = fmaf(-(r.m[i] * alpha), __builtin_amdgcn_rcpf(sv[i] + o.eps), r.p[i]);
-      }
-      b1j *= a.b1;
-      b2j *= a.b2;
-    }
-    const int gp = G - kx;
-    if (gp > 0) {
-      // steps j1 = last + kx + 1 ... : sum_i alpha(j1 + i - 1) m b1^i / (sqrt(v) g^i + eps);
-      // f(i) = alpha / (sqrt(v) g^i + eps) is fitted as f(1) rho^(i-1) through i = 1 and i = 9
-      // (hardware log2 / exp2 / rcp / sqrt: 1 ulp each, far inside the fit's own 4e-6)
-      const float a1 = o.lr * __builtin_amdgcn_sqrtf(1.f - b2j) * __builtin_amdgcn_rcpf(1.f - b1j);
-      const float b1j9 = b1j * exp2f(8.f * lb1), b2j9 = b2j * exp2f(8.f * lb2);
-      const float a9 = o.lr * __builtin_amdgcn_sqrtf(1.f - b2j9) * __builtin_amdgcn_rcpf(1.f - b1j9);
-      const float g1 = g, g9 = exp2f(4.5f * lb2);
-      const float pw1 = exp2f((float)gp * lb1), pw2 = exp2f((float)gp * lb2);
-#pragma unroll
-      for (int i = 0; i < VEC; ++i) {
-        const float f1 = a1 * __builtin_amdgcn_rcpf(sv[i] * g1 + o.eps);
-        const float f9 = a9 * __builtin_amdgcn_rcpf(sv[i] * g9 + o.eps);
-        const float q = a.b1 * __builtin_amdgcn_exp2f(__builtin_amdgcn_logf(f9 * __builtin_amdgcn_rcpf(f1)) * 0.125f);
-        const float qg = __builtin_amdgcn_exp2f((float)gp * __builtin_amdgcn_logf(q));
-        r.p[i] = r.p[i] - r.m[i] * f1 * a.b1 * (1.f - qg) * __builtin_amdgcn_rcpf(1.f - q);
-        r.m[i] = r.m[i] * pw1;
-        r.v[i] = r.v[i] * pw2;
-      }
-    }
-  } else if (o.kind == XDFM_OPT_RMSPROP) {
-    const float pw = exp2f((float)G * lb2);  // ms <- ms + (0 - ms)(1 - decay), G times
-#pragma unroll
-    for (int i = 0; i < VEC; ++i) r.m[i] = r.m[i] * pw;
-  } else if (o.kind == XDFM_OPT_ADADELTA) {
-    const float pw = exp2f((float)G * lb2);  // accum and accum_update both decay by rho per step
-#pragma unroll
-    for (int i = 0; i < VEC; ++i) {
-      r.m[i] = r.m[i] * pw;
-      r.v[i] = r.v[i] * pw;
-    }
-  } else if (o.kind == XDFM_OPT_FTRL) {
-    // TF's dense ApplyFtrl rewrites var = -linear / quadratic every step, gradient or not: a row that
-    // never had a gradient (linear = 0) becomes 0 at the first step; an updated row is a fixed point
-#pragma unroll
-    for (int i = 0; i < VEC; ++i) r.p[i] = -r.v[i] / (sqrtf(r.m[i]) / o.lr);
-  }
-}
-
-// One lane group (LPR = D/VEC lanes) per sorted position, groups never straddle a wave; only the
-// first position of an id's run works.
-template <int VEC>
 __global__ __launch_bounds__(256) void embed_catchup_kernel(CatchArgs a) {
+  __shared__ float4 cur_s[xdfm::kDriftG];
+  const int done = (int)a.age.state[3] + a.age.step_off;
+  if (a.age.tab) cur_s[threadIdx.x] = a.age.tab[(done & 1) * xdfm::kDriftG + threadIdx.x];
+  __syncthreads();
   const int lane = threadIdx.x & 63;
   const int LPR = a.D / VEC;
   const int R = 64 / LPR;
@@ -951,33 +1191,25 @@ __global__ __launch_bounds__(256) void embed_catchup_kernel(CatchArgs a) {
     id = a.sorted_ids[q];
     if (q > 0 && a.sorted_ids[q - 1] == id) return;
   }
-  const int done = (int)a.opt.state[3];  // optimizer steps applied so far
-  const int last = a.row_step[id * a.SS];
-  if (a.advance < 0) {
-    // un-mark: rows that were prepared for a step that did not come (a batch announced as the next
-    // one and then not trained) are current for the steps applied so far, nothing more
-    if (c == 0 && last > done) a.row_step[id * a.SS] = done;
-    return;
-  }
+  const int last = a.age.row_step[id * a.age.SS];
   const int G = done - last;
-  // last == 0: never updated; Adam's / Adadelta's slots are still zero: no drift (RMSProp's rms starts
-  // at 1 and decays from the first step on)
-  if (G > 0 && (last > 0 || a.opt.kind == XDFM_OPT_RMSPROP || a.opt.kind == XDFM_OPT_FTRL)) {
+  if (age_needed(a.age.kind, last, G)) {
+    const float4 cf = drift_coeffs(a.age, cur_s, last, G);
     const int64_t off = id * a.TS + c * VEC;
     RowVals<VEC> rv;
-    row_load<VEC>(a.opt, a.table + off, a.slot_m + off, a.slot_v + off, rv);
-    catchup_vals<VEC>(a, rv, last, G);
-    row_store<VEC>(a.opt, a.table + off, a.slot_m + off, a.slot_v + off, rv);
+    row_load<VEC>(a.age.kind, a.table + off, a.slot_m + off, a.slot_v + off, rv);
+    age_vals<VEC>(a.age, cf, rv, G);
+    row_store<VEC>(a.age.kind, a.table + off, a.slot_m + off, a.slot_v + off, rv);
     if (a.lin_w && c == 0) {
       const int64_t lo = id * a.LS;
       RowVals<1> rl;
-      row_load<1>(a.opt, a.lin_w + lo, a.lin_m + lo, a.lin_v + lo, rl);
-      catchup_vals<1>(a, rl, last, G);
-      row_store<1>(a.opt, a.lin_w + lo, a.lin_m + lo, a.lin_v + lo, rl);
+      row_load<1>(a.age.kind, a.lin_w + lo, a.lin_m + lo, a.lin_v + lo, rl);
+      age_vals<1>(a.age, cf, rl, G);
+      row_store<1>(a.age.kind, a.lin_w + lo, a.lin_m + lo, a.lin_v + lo, rl);
     }
   }
   // written last, by a lane whose own read of it has been consumed above
-  if (c == 0 && (G > 0 || a.advance)) a.row_step[id * a.SS] = done + a.advance;
+  if (c == 0 && G > 0) a.age.row_step[id * a.age.SS] = done;
 }
 
 extern "C" int xdfm_embed_clear_rows(float* grad_table, float* grad_lin, int32_t D,
@@ -992,19 +1224,18 @@ extern "C" int xdfm_embed_clear_rows(float* grad_table, float* grad_lin, int32_t
 }
 
 extern "C" int xdfm_embed_catchup(float* table, float* slot_m, float* slot_v, float* lin_w, float* lin_m,
-                                  float* lin_v, int32_t* row_step, int64_t table_stride, int64_t lin_stride,
-                                  int64_t step_stride, int64_t N, int32_t D, const int32_t* sorted_ids,
-                                  int64_t n, int32_t advance, const xdfm_opt_args* opt, void* stream) {
-  XDFM_REQUIRE(table && row_step && opt, "xdfm_embed_catchup: null argument");
-  XDFM_REQUIRE(N > 0 && D > 0 && n >= 0 && advance >= -1 && advance <= 1, "xdfm_embed_catchup: bad sizes");
-  XDFM_REQUIRE(opt->opt_state, "xdfm_embed_catchup: needs the device step count (opt_state)");
+                                  float* lin_v, int64_t table_stride, int64_t lin_stride, int64_t N, int32_t D,
+                                  const int32_t* sorted_ids, int64_t n, const xdfm_row_age* age, void* stream) {
+  XDFM_REQUIRE(table && age, "xdfm_embed_catchup: null argument");
+  XDFM_REQUIRE(N > 0 && D > 0 && n >= 0, "xdfm_embed_catchup: bad sizes");
   CatchArgs a;
   memset(&a, 0, sizeof(a));
-  int rc = make_opt(opt, &a.opt);
+  int rc = make_age(age, lin_w, lin_stride, false, &a.age);
   if (rc) return rc;
-  XDFM_REQUIRE(opt->kind == XDFM_OPT_SGD || slot_m, "xdfm_embed_catchup: optimizer slot missing");
-  XDFM_REQUIRE(!xdfm::opt_needs_v(opt->kind) || slot_v, "xdfm_embed_catchup: this optimizer needs slot_v");
-  XDFM_REQUIRE(!lin_w || ((opt->kind == XDFM_OPT_SGD || lin_m) && (!xdfm::opt_needs_v(opt->kind) || lin_v)),
+  const int kind = a.age.kind;
+  XDFM_REQUIRE(kind == XDFM_OPT_SGD || slot_m, "xdfm_embed_catchup: optimizer slot missing");
+  XDFM_REQUIRE(!xdfm::opt_needs_v(kind) || slot_v, "xdfm_embed_catchup: this optimizer needs slot_v");
+  XDFM_REQUIRE(!lin_w || ((kind == XDFM_OPT_SGD || lin_m) && (!xdfm::opt_needs_v(kind) || lin_v)),
                "xdfm_embed_catchup: lin slot missing");
   if (!sorted_ids) n = N;
   if (n == 0) return XDFM_OK;
@@ -1017,17 +1248,12 @@ extern "C" int xdfm_embed_catchup(float* table, float* slot_m, float* slot_v, fl
   a.lin_w = lin_w;
   a.lin_m = lin_m;
   a.lin_v = lin_v;
-  a.row_step = row_step;
   a.TS = table_stride;
   a.LS = lin_stride;
-  a.SS = step_stride ? step_stride : 1;
   a.N = N;
   a.n = n;
   a.D = D;
-  a.advance = advance;
   a.sorted_ids = sorted_ids;
-  a.b1 = opt->beta1;
-  a.b2 = opt->beta2;
   const int R = kWave / (D / vec);
   const int64_t waves = (n + R - 1) / R;
   const unsigned blocks = (unsigned)((waves + 3) / 4);

@@ -14,6 +14,7 @@
 #include <cstring>
 #include <rocprim/rocprim.hpp>
 
+#include "drift.h"
 #include "xdfm_common.h"
 
 namespace {
@@ -191,15 +192,77 @@ __global__ __launch_bounds__(256) void dense_update_kernel(SegTable tab, OptDev 
   }
 }
 
-// TF keeps beta1_power / beta2_power as fp32 variables multiplied up every step; same here
-__global__ void opt_advance_kernel(float* st, float lr, float beta1, float beta2) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) {
-    const float b1p = st[0] * beta1, b2p = st[1] * beta2;
+// ------------------------------------------------------------------ drift table (drift.h)
+// Partial sums (C0, C1, C2) over the steps i = k0 + 1, k0 + 1 + stride, ... <= n of a row whose stored
+// values are current for step s:  c_i = alpha_{s+i} (b1/g)^i,  d_i = eps (g^-i - g^-kDriftC),  C_k = sum c_i d_i^k.
+// alpha_j = lr sqrt(1 - b2^j) / (1 - b1^j) from fp32 powers (TF multiplies its beta powers up step by step:
+// the same numbers to a few ulp); s >= 2^24 stands for "alpha = lr".
+__device__ __forceinline__ float4 drift_partial(float lr, float b1, float b2, float eps, int s, int n, int k0,
+                                                int stride) {
+  const float lb1 = log2f(b1), lb2 = log2f(b2);
+  const float lq = lb1 - 0.5f * lb2;                              // log2(b1 / g)
+  const float gc = exp2f(-(float)xdfm::kDriftC * 0.5f * lb2);     // g^-kDriftC
+  float c0 = 0.f, c1 = 0.f, c2 = 0.f;
+  for (int i = k0 + 1; i <= n; i += stride) {
+    const float j = (float)s + (float)i;
+    const float alpha = lr * sqrtf(1.f - exp2f(j * lb2)) / (1.f - exp2f(j * lb1));
+    const float c = alpha * exp2f((float)i * lq);
+    const float d = eps * (exp2f(-(float)i * 0.5f * lb2) - gc);
+    c0 += c;
+    c1 += c * d;
+    c2 += c * d * d;
+  }
+  return make_float4(c0, c1, c2, 0.f);
+}
+
+// the four lanes of a quad hold the partial sums of one entry: added in a fixed tree
+__device__ __forceinline__ float4 quad_sum(float4 c) {
+  c.x += __shfl_xor(c.x, 1);
+  c.y += __shfl_xor(c.y, 1);
+  c.z += __shfl_xor(c.z, 1);
+  c.x += __shfl_xor(c.x, 2);
+  c.y += __shfl_xor(c.y, 2);
+  c.z += __shfl_xor(c.z, 2);
+  return c;
+}
+
+// entries of slot t & 1 for G = 0 .. kDriftG-1 steps missed as of step t (s = t - G; no row has s < 0)
+__device__ __forceinline__ void drift_fill_cur(float4* tab, int t, float lr, float b1, float b2, float eps) {
+  const int G = threadIdx.x >> 2, k = threadIdx.x & 3;
+  float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (t - G >= 0) c = drift_partial(lr, b1, b2, eps, t - G, G, k, 4);
+  c = quad_sum(c);
+  if (k == 0) tab[(t & 1) * xdfm::kDriftG + G] = c;
+}
+
+// TF keeps beta1_power / beta2_power as fp32 variables multiplied up every step; same here.
+// 4 * kDriftG threads: the state moves on in thread 0, every quad rebuilds one drift entry for the new step.
+__global__ __launch_bounds__(4 * xdfm::kDriftG) void opt_advance_kernel(float* st, float lr, float beta1,
+                                                                        float beta2, float eps, float4* tab) {
+  const float b1p = st[0] * beta1, b2p = st[1] * beta2, t = st[3] + 1.f;
+  __syncthreads();  // every thread has read the old state
+  if (threadIdx.x == 0) {
     st[0] = b1p;
     st[1] = b2p;
     st[2] = lr * sqrtf(1.f - b2p) / (1.f - b1p);
-    st[3] = st[3] + 1.f;
+    st[3] = t;
   }
+  if (tab) drift_fill_cur(tab, (int)t, lr, beta1, beta2, eps);
+}
+
+__global__ __launch_bounds__(4 * xdfm::kDriftG) void drift_init_kernel(const float* st, float lr, float beta1,
+                                                                       float beta2, float eps, float4* tab) {
+  if (blockIdx.x == 0) {
+    drift_fill_cur(tab, (int)st[3], lr, beta1, beta2, eps);
+    return;
+  }
+  // hist[s]: the first kDriftG - 1 missed steps after step s (the rest weighs (b1/g)^255)
+  const int s = (int)(blockIdx.x - 1) * xdfm::kDriftG + (threadIdx.x >> 2);
+  const int k = threadIdx.x & 3;
+  if (s > xdfm::kDriftS) return;  // whole quads leave together
+  float4 c = drift_partial(lr, beta1, beta2, eps, s < xdfm::kDriftS ? s : (1 << 24), xdfm::kDriftG - 1, k, 4);
+  c = quad_sum(c);
+  if (k == 0) tab[2 * xdfm::kDriftG + s] = c;
 }
 
 // ------------------------------------------------------------------ loss
@@ -638,10 +701,33 @@ extern "C" int xdfm_dense_reg_loss(const float* param, int32_t n_seg, const int6
   return XDFM_OK;
 }
 
-extern "C" int xdfm_opt_advance(float* opt_state, float lr, float beta1, float beta2, void* stream) {
+extern "C" int xdfm_opt_advance(float* opt_state, float lr, float beta1, float beta2, float eps, float* drift_tab,
+                                void* stream) {
   XDFM_REQUIRE(opt_state, "xdfm_opt_advance: null state");
-  XDFM_LAUNCH("opt_advance_kernel", stream, opt_advance_kernel, dim3(1), dim3(64), 0, opt_state, lr, beta1,
-              beta2);
+  XDFM_REQUIRE(!drift_tab || (beta1 > 0.f && beta1 < 1.f && beta2 > 0.f && beta2 < 1.f),
+               "xdfm_opt_advance: the drift table is Adam's (betas in (0, 1))");
+  XDFM_LAUNCH("opt_advance_kernel", stream, opt_advance_kernel, dim3(1), dim3(4 * xdfm::kDriftG), 0, opt_state, lr,
+              beta1, beta2, eps, reinterpret_cast<float4*>(drift_tab));
+  XDFM_LAUNCH_CHECK();
+  return XDFM_OK;
+}
+
+extern "C" int xdfm_drift_tab_floats(size_t* floats) {
+  XDFM_REQUIRE(floats, "xdfm_drift_tab_floats: null argument");
+  *floats = (size_t)xdfm::kDriftFloat4 * 4;
+  return XDFM_OK;
+}
+
+extern "C" int xdfm_drift_tab_init(float* drift_tab, const float* opt_state, float lr, float beta1, float beta2,
+                                   float eps, void* stream) {
+  XDFM_REQUIRE(drift_tab && opt_state, "xdfm_drift_tab_init: null argument");
+  XDFM_REQUIRE((reinterpret_cast<uintptr_t>(drift_tab) % 16) == 0, "xdfm_drift_tab_init: the table must be 16-byte aligned");
+  XDFM_REQUIRE(beta1 > 0.f && beta1 < 1.f && beta2 > 0.f && beta2 < 1.f, "xdfm_drift_tab_init: betas in (0, 1)");
+  hipStream_t st = (hipStream_t)stream;
+  XDFM_HIP(hipMemsetAsync(drift_tab, 0, (size_t)2 * xdfm::kDriftG * sizeof(float4), st));
+  const unsigned blocks = 1 + (xdfm::kDriftS + 1 + xdfm::kDriftG - 1) / xdfm::kDriftG;
+  XDFM_LAUNCH("drift_init_kernel", st, drift_init_kernel, dim3(blocks), dim3(4 * xdfm::kDriftG), 0, opt_state, lr,
+              beta1, beta2, eps, reinterpret_cast<float4*>(drift_tab));
   XDFM_LAUNCH_CHECK();
   return XDFM_OK;
 }

@@ -186,12 +186,13 @@ class XDeepFMEngine(object):
             self.opt_kind = 0  # unknown names fall back to SGD (base_model.py:301-302)
         # sparse_rows = the reference's numbers from row updates: TF moves every row every step (Adam's
         # m keeps decaying into p without a gradient; RMSProp / Adadelta decay their accumulators), so
-        # the steps a row missed are applied when it is next needed (xdfm_embed_catchup) and before
-        # scoring / checkpoints.  sparse_lazy skips them (a different algorithm for absent rows).
+        # every record carries the step it is current for and whoever reads a row applies the steps it
+        # missed (xdfm_row_age: the gathers in registers, the row update in its one read-modify-write;
+        # xdfm_embed_catchup writes aged rows back before checkpoints).  sparse_lazy skips them (a
+        # different algorithm for absent rows).
         self.catchup_on = embedding_update == "sparse_rows" and self.opt_kind in (1, 3, 4, 5)
         self._rows_stale = False
-        self._announced = None  # the batch whose rows have been caught up for the step to come
-        self._adv_event = None
+        self._age_args = {}
         if self.sparse:
             if hp.embed_l1 != 0.0 or hp.embed_l2 != 0.0:
                 raise ValueError("sparse_rows needs embed_l1 = embed_l2 = 0 (their gradient is dense)")
@@ -268,6 +269,13 @@ class XDeepFMEngine(object):
         # device copy {b1^t, b2^t, Adam step size, t}: what the kernels read, so that no host
         # scalar changes between steps (a step can be replayed from a HIP graph)
         self.opt_state = torch.tensor([1.0, 1.0, 0.0, 0.0], dtype=f32, device=dev)
+        # Adam's missed steps in closed form: coefficients by (steps missed, step) -- csrc/drift.h
+        self.drift_tab = None
+        if self.catchup_on and self.opt_kind == 1:
+            sz = ctypes.c_size_t()
+            _lib.check(self.lib.xdfm_drift_tab_floats(ctypes.byref(sz)))
+            self.drift_tab = torch.zeros((sz.value,), dtype=f32, device=dev)
+            self._init_drift_tab()
         # dense_exact keeps a dense gradient image of the table, all zero between steps
         if embedding_update == "dense_exact":
             self.grad_table = torch.zeros_like(self.table)
@@ -410,6 +418,31 @@ class XDeepFMEngine(object):
         if self.row_step is not None:  # a state dict holds flushed rows: all current for `step`
             self.row_step.fill_(self.step)
             self._rows_stale = False
+        if self.drift_tab is not None:
+            self._init_drift_tab()
+
+    def _init_drift_tab(self):
+        b1, b2, eps = _OPT_CONST[self.opt_kind]
+        _lib.check(self.lib.xdfm_drift_tab_init(_ptr(self.drift_tab), _ptr(self.opt_state),
+                                                float(self.hp.learning_rate), b1, b2, eps, self._stream()))
+
+    def _age(self, step_offset=0):
+        """xdfm_row_age for this engine's table (None when rows never age): step_offset = -1 once
+        xdfm_opt_advance has counted the step being applied."""
+        if not self.catchup_on:
+            return None
+        hit = self._age_args.get(step_offset)
+        if hit is None:
+            opt = self._opt_args()  # the kernels read the step scalars from opt_state, not from here
+            age = _lib.RowAge(self.row_step.data_ptr(), self.step_stride,
+                              self.table_m.data_ptr() if self.table_m is not None else None,
+                              self.table_v.data_ptr() if self.table_v is not None else None,
+                              self.lin_m.data_ptr() if self.lin_m is not None else None,
+                              self.lin_v.data_ptr() if self.lin_v is not None else None,
+                              self.drift_tab.data_ptr() if self.drift_tab is not None else None,
+                              ctypes.pointer(opt), int(step_offset), 0)
+            hit = self._age_args[step_offset] = (age, opt)
+        return ctypes.byref(hit[0])
 
     @staticmethod
     def overlap_dnn_wanted(hp):
@@ -628,7 +661,7 @@ class XDeepFMEngine(object):
             _lib.check(self.lib.xdfm_dense_bwd_workspace_floats(B, ws["pooled"].shape[1], 1, ctypes.byref(sz)))
             dnn_part_floats = max(dnn_part_floats, sz.value)
         buf("part_dnn", dnn_part_floats)
-        buf("pieces", 2 * (nnz // 64 + 1) * (D + 1))
+        buf("pieces", 2 * (nnz // 64 + 1) * (D + 2))
         if self.overlap_dnn:
             # the DNN tower's gradient w.r.t. emb_out, written beside the CIN backward and added to
             # d_emb where the table gradient reads it
@@ -780,8 +813,7 @@ class XDeepFMEngine(object):
         # layer_keeps = keep_prob_train only under train() (base_model.py:377); eval / infer feed ones
         self._dropout_live = self.use_dropout and with_grad
         self._training = bool(with_grad)  # is_train_stage (base_model.py:378, :401, :415)
-        if not with_grad:
-            self.flush_rows()  # scoring reads the table as the reference's dense optimizer left it
+        # (scoring needs no flush: the gather ages the rows it reads, like the training forward pass)
         self._ensure_ws(batch.B, batch.nnz)
         ws = self.ws
         B, F, D = batch.B, self.F, self.D
@@ -800,7 +832,7 @@ class XDeepFMEngine(object):
                 _ptr(batch.weights), batch.nnz,
                 _ptr(ws["emb_out"]), _ptr(ws["lin_out"]) if use_lin else None,
                 _ptr(ws["fm_out"]) if use_fm else None, _ptr(ws["fm_sum"]) if use_fm else None,
-                _ptr(self.err_flag), st,
+                _ptr(self.err_flag), None if batch.src_table is not None else self._age(0), st,
             )
         )
         self._done(ev)
@@ -1422,7 +1454,7 @@ class XDeepFMEngine(object):
             self.b1p = np.float32(self.b1p * np.float32(0.9))  # host mirror (checkpoints)
             self.b2p = np.float32(self.b2p * np.float32(0.999))
             _lib.check(self.lib.xdfm_opt_advance(_ptr(self.opt_state), float(self.hp.learning_rate), 0.9, 0.999,
-                                                 self._stream()))
+                                                 1e-8, _ptr(self.drift_tab), self._stream()))
 
     def update(self, batch, advanced=False):
         """apply_gradients (base_model.py:305-322) for every variable + regular_loss
@@ -1459,10 +1491,13 @@ class XDeepFMEngine(object):
                 _ptr(batch.sorted_w if pre else batch.weights), batch.nnz, _ptr(ws["d_emb"]),
                 _ptr(ws["g_logit"]) if (use_lin or use_fm) else None,
                 _ptr(ws["fm_sum"]) if use_fm else None, 1 if use_fm else 0,
-                ctypes.byref(opt_sparse), _ptr(ws["pieces"]), _ptr(self.d_emb2()), 0, st,
+                ctypes.byref(opt_sparse), _ptr(ws["pieces"]), _ptr(self.d_emb2()), 0,
+                self._age(-1) if sparse else None, st,
             )
         )
         self._done(ev)
+        if sparse and self.catchup_on:
+            self._rows_stale = True
         first = True  # the first dense_update writes reg_loss, the others accumulate
         if not sparse:
             one = np.asarray([0, self.N * self.D], dtype=np.int64)
@@ -1527,91 +1562,39 @@ class XDeepFMEngine(object):
             self.reg_loss.zero_()
         self._done(ev_upd)
 
-    def catchup(self, sorted_ids, n, advance):
-        """xdfm_embed_catchup over the rows named by sorted_ids (None: the whole table)."""
+    def catchup(self, sorted_ids, n):
+        """xdfm_embed_catchup: aged rows written back, for the rows named by sorted_ids (None: the whole
+        table)."""
         use_lin = self.lin_w is not None
-        opt = self._opt_args()
         _lib.check(
             self.lib.xdfm_embed_catchup(
                 _ptr(self.table), _ptr(self.table_m), _ptr(self.table_v), _ptr(self.lin_w) if use_lin else None,
-                _ptr(self.lin_m) if use_lin else None, _ptr(self.lin_v) if use_lin else None, _ptr(self.row_step),
-                self.table_stride, self.lin_stride, self.step_stride, self.N, self.D, _ptr(sorted_ids), int(n),
-                int(advance), ctypes.byref(opt), self._stream(),
+                _ptr(self.lin_m) if use_lin else None, _ptr(self.lin_v) if use_lin else None,
+                self.table_stride, self.lin_stride, self.N, self.D, _ptr(sorted_ids), int(n), self._age(0),
+                self._stream(),
             )
         )
 
     def flush_rows(self):
-        """Bring every row up to the current step (before scoring, checkpoints, table exports)."""
+        """Write every row as of the current step (before checkpoints and table exports: whatever reads
+        the table without ageing rows itself)."""
         if self.catchup_on and self._rows_stale:
-            self.catchup(None, self.N, 0)
+            self.catchup(None, self.N)
             self._rows_stale = False
 
     def train_step(self, batch, next_batch=None):
         """One optimisation step; returns (total_loss, data_loss) as 0-dim device tensors.
-        next_batch (optional): the batch of the following step.  Its id sort runs beside this step's
-        compute, and with embedding_update="sparse_rows" so does the catch-up of its rows (they are
-        rows this step does not update, or rows it marks as current): the following step then starts
-        with its forward pass.  A step whose batch was not announced sorts and catches up first."""
-        if self.catchup_on:
-            if self._announced is not batch:
-                if self._announced is not None:
-                    # rows dated for a step that went to another batch: take the mark back
-                    self.catchup(self._announced.sorted_ids, self._announced.nnz, -1)
-                self.plan(batch, sort_only=True)
-                if batch.plan_event is not None:
-                    torch.cuda.current_stream(self.device).wait_event(batch.plan_event)
-                    batch.plan_event = None
-                ev = self._mark("embed_catchup")
-                self.catchup(batch.sorted_ids, batch.nnz, 1)
-                self._done(ev)
-            elif batch.plan_event is not None:
-                torch.cuda.current_stream(self.device).wait_event(batch.plan_event)
-                batch.plan_event = None
-            self._announced = None
-            self._rows_stale = True
-        self.plan_async(batch)  # whatever of the plan is still missing runs beside the forward pass
-        if next_batch is batch:
-            next_batch = None
-        if next_batch is not None:
-            self.plan_async(next_batch)
+        The id sort of the batch runs on a side stream beside its forward pass (it depends on the ids
+        only); next_batch is accepted for callers of earlier versions and not needed any more (rows are
+        aged where they are read, nothing has to be prepared a step ahead)."""
+        self.plan_async(batch)
         self.forward(batch, with_loss=True, with_grad=True)
         advanced = self.backward(batch, advance=True)
         if not advanced:
             self._advance_step()
-        ahead = None
-        if next_batch is not None and self.catchup_on:
-            ahead = self._catchup_ahead(next_batch)
         self.update(batch, True)
         tot = torch.cumsum(self._loss2, 0)  # one launch: [data, data + reg]
-        if ahead is not None:
-            # joined at the end of the step: the next step's forward pass reads caught-up rows
-            torch.cuda.current_stream(self.device).wait_event(ahead)
-        if next_batch is not None and next_batch.plan_event is not None and not self.catchup_on:
-            # join (the sort finished long ago): the sort workspace is free again, and a capture ends
-            # with every forked stream joined
-            torch.cuda.current_stream(self.device).wait_event(next_batch.plan_event)
-            next_batch.plan_event = None
         return tot[1], tot[0]
-
-    def _catchup_ahead(self, nxt):
-        """The catch-up of the announced batch's rows on the sort stream, behind its sort and behind
-        this step's opt_advance: rows this step updates are already dated for it (untouched here, only
-        re-dated), every other row takes its missed steps INCLUDING this one -- which this step's
-        row update does not touch.  The table gradient of this step may run at the same time: the
-        two write disjoint rows."""
-        side = self._side_stream
-        # behind everything this step has enqueued so far (its opt_advance included: backward() has
-        # joined the stream that ran it)
-        ready = torch.cuda.Event()
-        ready.record(torch.cuda.current_stream(self.device))
-        side.wait_event(ready)
-        with torch.cuda.stream(side):
-            self.catchup(nxt.sorted_ids, nxt.nnz, 1)
-            done = torch.cuda.Event()
-            done.record(side)
-        nxt.plan_event = None
-        self._announced = nxt
-        return done
 
     def capture_step(self, labels, dnn_idx, ids, weights):
         """Capture CSR build + train_step for batches of exactly this shape into a HIP graph
@@ -1638,13 +1621,13 @@ class XDeepFMEngine(object):
 
 
 class PackedBatch(object):
-    """A batch in a GraphedStep's input layout: one flat device buffer (`buf`).  `ids_src` /
-    `next_src` name the tensors its ids and its announced successor's ids were copied from."""
+    """A batch in a GraphedStep's input layout: one flat device buffer (`buf`).  `ids_src` names the
+    tensor its ids were copied from."""
 
-    __slots__ = ("buf", "ids_src", "next_src")
+    __slots__ = ("buf", "ids_src")
 
-    def __init__(self, buf, ids_src, next_src):
-        self.buf, self.ids_src, self.next_src = buf, ids_src, next_src
+    def __init__(self, buf, ids_src):
+        self.buf, self.ids_src = buf, ids_src
 
 
 def graph_replay_refusal():
@@ -1660,16 +1643,15 @@ def graph_replay_refusal():
 class GraphedStep(object):
     """A captured train step.  The graph reads its batch from one flat device buffer -- labels, the CSR
     offsets and token rows of the lookup (what the text reader hands over as `row_ptr`; built once
-    from the index array by pack() / run(), which also validates it), ids, weights and, with the
-    look-ahead below, the NEXT batch's ids, at 256-byte aligned offsets -- so handing it a batch is ONE
-    copy and nothing but the step's own kernels sits on the replay's chain (every small operation in
-    front of the forward pass costs the step about 8 us): run_packed(pack(...)) for a batch laid out
-    ahead of time, run(...) for four arrays.
+    from the index array by pack() / run(), which also validates it), ids and weights, at 256-byte
+    aligned offsets -- so handing it a batch is ONE copy and nothing but the step's own kernels sits
+    on the replay's chain (every small operation in front of the forward pass costs the step about
+    8 us): run_packed(pack(...)) for a batch laid out ahead of time, run(...) for four arrays.
 
-    With the catch-up of sparse_rows the id sort is needed before the forward pass; the graph
-    therefore sorts the NEXT batch's ids beside this batch's compute (pack(..., next_ids=) +
-    run_packed(pb, next_pb) / run(..., next_ids=)): every replay still does one sort, one step ahead.
-    A batch that was not announced that way is sorted eagerly in front of the replay."""
+    The id sort of the batch runs inside the graph, on a side stream beside the forward pass (rows are
+    aged where they are read, so nothing of a batch has to be prepared before its step).  The
+    `next_*` arguments of earlier versions, which announced the following batch, are accepted and
+    ignored."""
 
     def __init__(self, engine, labels, dnn_idx, ids, weights, csr=None):
         """csr = (row_ptr, tok_row): the lookup's offsets / token rows when they exist already (a
@@ -1681,7 +1663,6 @@ class GraphedStep(object):
             raise RuntimeError("kernel event hooks cannot be captured")
         if graph_replay_refusal():
             raise RuntimeError(graph_replay_refusal())
-        self.lookahead = bool(engine.catchup_on)
         dev = engine.device
         B, nnz = int(labels.numel()), int(ids.numel())
         self._B, self._nnz = B, nnz
@@ -1691,8 +1672,6 @@ class GraphedStep(object):
                   ("tok_row", torch.int32, (max(nnz, 1),)),
                   ("ids", ids.dtype, tuple(ids.shape)),
                   ("weights", weights.dtype, tuple(weights.shape))]
-        if self.lookahead:
-            fields.append(("next_ids", ids.dtype, tuple(ids.shape)))
         self._layout = {}
         off = 0
         for name, dt, shape in fields:
@@ -1704,17 +1683,7 @@ class GraphedStep(object):
             off += (nbytes + 255) // 256 * 256
         self.flat = torch.empty((max(off, 256),), dtype=torch.uint8, device=dev)
         self.views = self._views(self.flat)
-        self._fill(self.views, labels, dnn_idx, ids, weights, ids, csr)
-        self._planned_for = None  # what the graph's plan_next was sorted from (PackedBatch / ids tensor)
-        if self.lookahead:
-            self.next_ids = self.views["next_ids"]  # always ids of a real batch: the replay sorts and reads rows by them
-            n1 = max(nnz, 1)
-            # (sorted ids, sorted token positions) as the two rows of one array: one copy hands the
-            # look-ahead sort's result to the step that uses it
-            self._plan_cur2 = torch.empty((2, n1), dtype=torch.int32, device=dev)
-            self._plan_next2 = torch.empty((2, n1), dtype=torch.int32, device=dev)
-            self.plan_cur = [self._plan_cur2[0], self._plan_cur2[1]]
-            self.plan_next = [self._plan_next2[0], self._plan_next2[1]]
+        self._fill(self.views, labels, dnn_idx, ids, weights, csr)
         # warm up on a side stream (allocations, lazy module loads), as torch asks before a capture
         s = torch.cuda.Stream(device=dev)
         s.wait_stream(torch.cuda.current_stream(dev))
@@ -1728,22 +1697,9 @@ class GraphedStep(object):
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.batch = self._batch_of_views()
-            if self.lookahead:
-                self._plan_cur2.copy_(self._plan_next2)
-                self.batch.sorted_ids, self.batch.sorted_tok = self.plan_cur
-                self.batch.planned = True
-                engine._announced = self.batch  # its rows were caught up by the replay before (or eagerly)
-                nb = self._nb = DeviceBatch()
-                nb.B, nb.nnz, nb.ids = self.batch.B, self.batch.nnz, self.next_ids
-                nb.sorted_ids, nb.sorted_tok = self.plan_next
-                nb.sorted_row = nb.sorted_w = nb.tok_row = nb.weights = None  # known by its ids only
-                nb.planned, nb.planned_gather, nb.plan_event = False, False, None
-                self.loss, self.data_loss = engine.train_step(self.batch, next_batch=nb)
-            else:
-                self.loss, self.data_loss = engine.train_step(self.batch)
+            self.loss, self.data_loss = engine.train_step(self.batch)
         # the capture pass ran the host bookkeeping of a step without device work
         engine.step, engine.b1p, engine.b2p = mirrors
-        engine._announced = None
 
     def _views(self, flat):
         return {name: flat[o:o + n].view(dt).view(shape) for name, (o, n, dt, shape) in self._layout.items()}
@@ -1763,7 +1719,7 @@ class GraphedStep(object):
             raise ValueError("batch array %s/%s does not match the captured shape %s/%s"
                              % (tuple(dnn_idx.shape), dnn_idx.dtype, self._idx_shape, self._idx_dtype))
 
-    def _fill(self, views, labels, dnn_idx, ids, weights, next_ids, csr=None):
+    def _fill(self, views, labels, dnn_idx, ids, weights, csr=None):
         """The arrays of a batch into the views of a flat buffer; the CSR offsets / token rows are
         built from the index array here (xdfm_build_row_ptr, which also flags bad indices) unless
         they are handed over (csr)."""
@@ -1777,17 +1733,13 @@ class GraphedStep(object):
         else:
             _lib.check(eng.lib.xdfm_build_row_ptr(_ptr(dnn_idx), self._nnz, self._B * eng.F, _ptr(views["row_ptr"]),
                                                   _ptr(views["tok_row"]), _ptr(eng.err_flag), eng._stream()))
-        if "next_ids" in views:
-            views["next_ids"].copy_(next_ids if next_ids is not None else ids)
 
     def pack(self, labels, dnn_idx, ids, weights, next_ids=None):
-        """A batch in the graph's input layout (a new device buffer).  next_ids: the ids of the batch
-        that will be announced as this one's successor (run_packed(pb, next_pb)); without them the
-        successor's ids are copied at run time."""
+        """A batch in the graph's input layout (a new device buffer)."""
         self._check(labels, dnn_idx, ids, weights)
         buf = torch.empty_like(self.flat)
-        self._fill(self._views(buf), labels, dnn_idx, ids, weights, next_ids)
-        return PackedBatch(buf, ids, next_ids)
+        self._fill(self._views(buf), labels, dnn_idx, ids, weights)
+        return PackedBatch(buf, ids)
 
     def pack_batch(self, batch, next_ids=None):
         """pack() for a DeviceBatch (its CSR offsets exist already)."""
@@ -1795,65 +1747,28 @@ class GraphedStep(object):
             raise ValueError("batch of %d samples / %d tokens does not match the captured %d / %d"
                              % (batch.B, batch.nnz, self._B, self._nnz))
         buf = torch.empty_like(self.flat)
-        self._fill(self._views(buf), batch.labels, None, batch.ids, batch.weights, next_ids,
+        self._fill(self._views(buf), batch.labels, None, batch.ids, batch.weights,
                    csr=(batch.row_ptr, batch.tok_row))
-        return PackedBatch(buf, batch.ids, next_ids)
+        return PackedBatch(buf, batch.ids)
 
-    def run_batch(self, pb, key, next_key=None, next_ids=None):
-        """run_packed() with caller-chosen identities: `key` names this batch, `next_key` the announced
-        successor (the object the next call will pass as its key); next_ids: the successor's ids unless pb
-        was packed with them."""
-        self.flat.copy_(pb.buf, non_blocking=True)
-        if not self.lookahead or next_key is None:
-            return self._replay(key, None, None)
-        if next_ids is None:
-            raise ValueError("an announced successor needs its ids")
-        if pb.next_src is next_ids:
-            next_ids = None  # packed with them: the copy above brought them
-        return self._replay(key, next_key, next_ids)
-
-    def _replay(self, cur_key, next_key, next_ids):
-        """cur_key / next_key: what identifies this batch and its announced successor (the objects
-        the caller passed); next_ids: the successor's ids when the graph's buffer does not hold them
-        yet (None: it does, or nothing is announced)."""
+    def _replay(self):
         eng = self.engine
         if eng._ws_token != self._ws_token:
             raise RuntimeError("the engine's workspace was re-allocated after this step was captured "
                                "(a larger batch went through the engine): capture it again")
-        if self.lookahead:
-            if eng._announced is not self._nb or self._planned_for is not cur_key:
-                # not announced by the replay before: take back whatever was, then sort and catch up now,
-                # into the buffer the graph copies from
-                if eng._announced is not None:
-                    eng.catchup(eng._announced.sorted_ids, eng._announced.nnz, -1)
-                ws = eng.ws["plan_ws"]
-                n = int(self.views["ids"].numel())
-                _lib.check(eng.lib.xdfm_embed_plan(_ptr(self.views["ids"]), n, eng.N, _ptr(self.plan_next[0]),
-                                                   _ptr(self.plan_next[1]), _ptr(ws), ws.numel(), eng._stream()))
-                eng.catchup(self.plan_next[0], n, 1)
-            if next_key is not None:
-                if next_ids is not None:
-                    self.next_ids.copy_(next_ids, non_blocking=True)
-                self._planned_for = next_key
-            else:
-                # nothing announced: the replay's look-ahead prepares this batch's own rows again
-                # (valid ids, nothing to bring forward; the marks are taken back by the next call)
-                self.next_ids.copy_(self.views["ids"], non_blocking=True)
-                self._planned_for = None
-            eng._announced = self._nb
         self.graph.replay()
         eng.step += 1
         eng._rows_stale = eng.catchup_on
         return self.loss, self.data_loss
 
+    def run_batch(self, pb, key=None, next_key=None, next_ids=None):
+        return self.run_packed(pb)
+
     def run_packed(self, pb, next_pb=None):
         self.flat.copy_(pb.buf, non_blocking=True)
-        next_ids = None
-        if self.lookahead and next_pb is not None and (pb.next_src is None or pb.next_src is not next_pb.ids_src):
-            next_ids = self._views(next_pb.buf)["ids"]  # not packed with this successor's ids
-        return self._replay(pb, next_pb, next_ids)
+        return self._replay()
 
     def run(self, labels, dnn_idx, ids, weights, next_ids=None):
         self._check(labels, dnn_idx, ids, weights)
-        self._fill(self.views, labels, dnn_idx, ids, weights, next_ids)
-        return self._replay(ids, next_ids, None)
+        self._fill(self.views, labels, dnn_idx, ids, weights)
+        return self._replay()

@@ -330,8 +330,8 @@ class ShardedXDeepFMEngine(XDeepFMEngine):
         return plan
 
     def fetch_rows(self, batch, static=None, train=True):
-        """Route the batch's ids (unless that was prefetched), catch the requested rows up, gather them at
-        the owners, bring them back.  Afterwards the batch reads its embeddings from the fetched rows
+        """Route the batch's ids (unless that was prefetched), gather the requested rows at their owners (aged
+        to the current step as they are read), bring them back.  Afterwards the batch reads its embeddings from the fetched rows
         (token j -> fetched row inverse[j]).  static: a _LocalGraph whose buffers receive the rows."""
         hp, lib, st = self.hp, self.lib, self._stream()
         D = self.D
@@ -340,12 +340,6 @@ class ShardedXDeepFMEngine(XDeepFMEngine):
         if plan is None:
             plan = self._prepare(batch)
         n_recv = plan.n_recv
-        if train and self.catchup_on and n_recv:
-            # the rows about to be read take the steps they missed; their update follows in this step
-            ev = self._mark("embed_catchup")
-            self.catchup(plan.owner_sorted_ids, n_recv, 1)
-            self._done(ev)
-            self._rows_stale = True
         # [row | linear weight | pad] records: rows and weights come back in one all-to-all
         DP = D + 4 if use_lin else D
         comb = self._owner_buf("comb", n_recv * DP).view(n_recv, DP) if n_recv else torch.empty(
@@ -356,7 +350,7 @@ class ShardedXDeepFMEngine(XDeepFMEngine):
                 lib.xdfm_embed_gather(
                     _ptr(self.table), _ptr(self.lin_w) if use_lin else None, self.table_stride, self.lin_stride,
                     self.N, D, _ptr(plan.recv_rows), n_recv, _ptr(comb), _ptr(comb[:, D]) if use_lin else None,
-                    DP if use_lin else 0, _ptr(self.err_flag), st,
+                    DP if use_lin else 0, _ptr(self.err_flag), self._age(0), st,
                 )
             )
             self._done(ev)
@@ -426,7 +420,7 @@ class ShardedXDeepFMEngine(XDeepFMEngine):
                 _ptr(seg_ids), _ptr(order32), _ptr(batch.tok_row), _ptr(batch.weights), nnz,
                 _ptr(ws["d_emb"]), _ptr(ws["g_logit"]) if (use_lin or use_fm) else None,
                 _ptr(ws["fm_sum"]) if use_fm else None, 1 if use_fm else 0, ctypes.byref(opt),
-                _ptr(ws["pieces"]), _ptr(self.d_emb2()), send_c.stride(0) if use_lin else 0, st,
+                _ptr(ws["pieces"]), _ptr(self.d_emb2()), send_c.stride(0) if use_lin else 0, None, st,
             )
         )
         self._done(ev)
@@ -444,7 +438,7 @@ class ShardedXDeepFMEngine(XDeepFMEngine):
         recv_c = self.exchange.to_owner(plan, send_c[:plan.n_send],
                                         out=self._owner_buf("recv_c", n * DP).view(n, DP) if n else None)
         if n:
-            pieces = self._owner_buf("pieces", 2 * (n // 64 + 1) * (D + 1))
+            pieces = self._owner_buf("pieces", 2 * (n // 64 + 1) * (D + 2))
             ev = self._mark("owner_update")
             _lib.check(
                 lib.xdfm_embed_bwd(
@@ -454,10 +448,12 @@ class ShardedXDeepFMEngine(XDeepFMEngine):
                     self.N, D, 1, n,
                     _ptr(plan.owner_sorted_ids), _ptr(plan.owner_sorted_tok), _ptr(self._arange32(n)),
                     _ptr(self._ones(n)), n, _ptr(recv_c), _ptr(recv_c[:, D]) if use_lin else None, None, 0,
-                    ctypes.byref(opt), _ptr(pieces), None, recv_c.stride(0) if use_lin else 0, st,
+                    ctypes.byref(opt), _ptr(pieces), None, recv_c.stride(0) if use_lin else 0, self._age(-1), st,
                 )
             )
             self._done(ev)
+            if self.catchup_on:
+                self._rows_stale = True
 
     def _update_embedding(self, batch):
         nnz = batch.nnz
@@ -618,7 +614,6 @@ class ShardedXDeepFMEngine(XDeepFMEngine):
         return rmse_g
 
     def predict_batch(self, batch):
-        self.flush_rows()
         self.fetch_rows(batch, train=False)
         return self.forward(batch, with_loss=False)
 

@@ -160,25 +160,16 @@ class BaseModel:
         Returns ``[update, extra_update_ops, loss, data_loss, summary]`` like the reference
         (:379-388); the two losses are device scalars.
         """
-        return self._train(sess, feed_dict, None)
-
-    def _train(self, sess, feed_dict, next_feed_dict):
-        """train() with the following batch announced: it is uploaded now and its id sort runs
-        beside this step (the catch-up of embedding_update="sparse_rows" needs a batch's sort
-        before its forward pass)."""
         feed_dict[self.layer_keeps] = self.keep_prob_train
         feed_dict[self.is_train_stage] = True
         batch = self._batch_from_feed(feed_dict)
-        nxt = None
-        if next_feed_dict is not None and getattr(self.engine, "catchup_on", False):
-            nxt = self._batch_from_feed(next_feed_dict)
-        out = self._train_graphed(feed_dict, batch, next_feed_dict, nxt)
+        out = self._train_graphed(feed_dict, batch)
         if out is None:
-            out = self.engine.train_step(batch, next_batch=nxt)
+            out = self.engine.train_step(batch)
         loss, data_loss = out
         return [None, [], loss, data_loss, None]
 
-    def _train_graphed(self, feed_dict, batch, next_feed_dict, nxt):
+    def _train_graphed(self, feed_dict, batch):
         """The step as a replay of a captured HIP graph when batches of one shape (samples, tokens) keep
         coming -- Criteo-style files where every line names every field -- and as eager launches
         otherwise (the eager step is bound by the host's launch rate: 0.66 against 0.42 ms at batch 8192).
@@ -209,10 +200,9 @@ class BaseModel:
             gs = GraphedStep(eng, batch.labels, None, batch.ids, batch.weights, csr=(batch.row_ptr, batch.tok_row))
             self._graphed[key] = gs
             return gs.warmup_loss  # the capture's warm-up WAS this batch's training step
-        same = nxt is not None and (nxt.B, nxt.nnz) == key
         pb = getattr(feed_dict, "packed_batch", None)
         if pb is None or pb[0] is not gs:
-            pb = (gs, gs.pack_batch(batch, next_ids=nxt.ids if same else None))
+            pb = (gs, gs.pack_batch(batch))
             nbytes = pb[1].buf.numel()
             budget = int(os.environ.get("XDFM_FFM_CACHE_DEVICE_MB", "8192")) << 20
             held = getattr(self, "_device_cache_bytes", 0)
@@ -221,7 +211,7 @@ class BaseModel:
                 feed_dict.packed_batch = pb
                 self._device_cache_bytes = held + nbytes
                 weakref.finalize(feed_dict, self._release_device_cache, nbytes)
-        loss, data_loss = gs.run_batch(pb[1], feed_dict, next_feed_dict if same else None, nxt.ids if same else None)
+        loss, data_loss = gs.run_packed(pb[1])
         # the graph writes the same two tensors every step: hand out copies, as the eager step hands out
         # new tensors (a caller may keep them across steps)
         pair = torch.stack([loss, data_loss])
@@ -282,12 +272,8 @@ class BaseModel:
             epoch_loss = 0
             logged = []
             train_start = time.time()
-            batches = self.iterator.load_data_from_file(train_file)
-            upcoming = next(batches, None)
-            while upcoming is not None:
-                batch_data_input, impression, data_size = upcoming
-                upcoming = next(batches, None)
-                step_result = self._train(train_sess, batch_data_input, upcoming[0] if upcoming is not None else None)
+            for batch_data_input, impression, data_size in self.iterator.load_data_from_file(train_file):
+                step_result = self.train(train_sess, batch_data_input)
                 (_, _, step_loss, step_data_loss, summary) = step_result
                 epoch_loss = epoch_loss + step_loss
                 step += 1

@@ -35,20 +35,21 @@ def test_every_declared_symbol_is_exported_and_bound():
 
 
 def test_abi_version_and_error_channel():
-    assert _lib.lib.xdfm_abi_version() == 2
+    assert _lib.lib.xdfm_abi_version() == 3
     # argument validation happens on the host before any device work
     sz = ctypes.c_size_t()
     rc = _lib.lib.xdfm_dense_bwd_workspace_floats(-1, 0, 0, ctypes.byref(sz))
     assert rc == -1
     assert b"bad argument" in _lib.lib.xdfm_last_error()
     rc = _lib.lib.xdfm_embed_fwd(None, None, 0, 0, 10, 4, 2, 1, None, None, None, 0, None, None, None,
-                                 None, None, None)
+                                 None, None, None, None)
     assert rc == -1 and b"null" in _lib.lib.xdfm_last_error()
 
 
 def test_struct_layouts_match_header():
     assert ctypes.sizeof(_lib.OptArgs) == 56 and _lib.OptArgs.opt_state.offset == 48
     assert ctypes.sizeof(_lib.BatchInfo) == 40
+    assert ctypes.sizeof(_lib.RowAge) == 72 and _lib.RowAge.opt.offset == 56 and _lib.RowAge.step_offset.offset == 64
 
 
 def test_product_never_imports_the_oracle():

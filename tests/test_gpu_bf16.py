@@ -59,7 +59,7 @@ def test_bf16_forward_and_gradients_match_the_fp64_oracle(name):
         1, _ptr(eng.table), None, None, None, None, None, eng.table_stride, eng.lin_stride, _ptr(eng.grad_table),
         _ptr(eng.grad_lin), eng.N, eng.D, eng.F, db.B, _ptr(db.sorted_ids), _ptr(db.sorted_tok), _ptr(db.tok_row),
         _ptr(db.weights), db.nnz, _ptr(eng.ws["d_emb"]), _ptr(eng.ws["g_logit"]), _ptr(eng.ws["fm_sum"]), 1,
-        ctypes.byref(opt), _ptr(eng.ws["pieces"]), _ptr(eng.d_emb2()), 0, eng._stream()))
+        ctypes.byref(opt), _ptr(eng.ws["pieces"]), _ptr(eng.d_emb2()), 0, None, eng._stream()))
     torch.cuda.synchronize()
     eng.check_errors()
 

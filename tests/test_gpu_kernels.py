@@ -154,7 +154,7 @@ def test_forward_and_gradients_match_oracle(name, loss):
         _ptr(db.sorted_tok), _ptr(db.tok_row), _ptr(db.weights), db.nnz, _ptr(eng.ws["d_emb"]),
         _ptr(eng.ws["g_logit"]) if (use_lin or use_fm) else None,
         _ptr(eng.ws["fm_sum"]) if use_fm else None, 1 if use_fm else 0, ctypes.byref(opt),
-        _ptr(eng.ws["pieces"]), _ptr(eng.d_emb2()), 0, eng._stream()))
+        _ptr(eng.ws["pieces"]), _ptr(eng.d_emb2()), 0, None, eng._stream()))
     torch.cuda.synchronize()
     eng.check_errors()
 
@@ -264,7 +264,9 @@ def test_sparse_rows_with_long_gaps_equal_reference_dense_updates(optimizer):
     close(pred, X.predict(p64, batches[-1], hp).numpy(), rtol=2e-3, what="pred after training")
 
 
-def test_graphed_sparse_rows_step_sorts_one_batch_ahead_and_equals_eager():
+def test_graphed_sparse_rows_step_equals_eager():
+    """A replayed step graph (its id sort runs inside the graph, beside the forward pass; rows are aged
+    where they are read) gives the same bits as eager steps: through run_packed(pack(...))."""
     hp = make_hp(optimizer="adam", learning_rate=0.02, FEATURE_COUNT=2000, batch_size=48)
     rng = np.random.default_rng(12)
     p32 = X.init_params(hp, seed=6)
@@ -278,14 +280,10 @@ def test_graphed_sparse_rows_step_sorts_one_batch_ahead_and_equals_eager():
     eager.train_step(upload(eager, batches[0]))
     gs = graph.capture_step(*dev(batches[0]))  # runs batch 0 once while warming up
     devs = [dev(b) for b in batches]
-    # odd batches carry their successor's ids in the packed buffer (one copy per step), even ones do not
-    # (the successor's ids are copied at run time)
-    packed = [gs.pack(*devs[k], next_ids=devs[k + 1][2] if (k % 2 == 1 and k + 1 < 9) else None) for k in range(9)]
+    packed = [gs.pack(*devs[k]) for k in range(9)]
     for k in range(1, 9):
         le = float(eager.train_step(upload(eager, batches[k]))[0])
-        # batches 1-4 announce their successor, 5 does not (eager sort in front of the replay), 6-8 do
-        nxt = packed[k + 1] if (k + 1 < 9 and k != 5) else None
-        lg = float(gs.run_packed(packed[k], nxt)[0])
+        lg = float(gs.run_packed(packed[k])[0])
         assert le == lg, (k, le, lg)
     sa, sb = eager.state_dict(), graph.state_dict()
     assert sa["step"] == sb["step"] == 9
@@ -295,9 +293,9 @@ def test_graphed_sparse_rows_step_sorts_one_batch_ahead_and_equals_eager():
 
 
 def test_graphed_step_through_run_and_run_batch_equals_eager():
-    """The other two ways into a captured step: run() with four arrays (the successor announced by its
-    ids tensor) and pack_batch() / run_batch() from DeviceBatches with caller-chosen identities (what
-    fit() uses).  Same bits as eager steps, with and without an announced successor."""
+    """The other two ways into a captured step: run() with four arrays and pack_batch() / run_batch() from
+    DeviceBatches (what fit() uses; the identities and successor arguments of earlier versions are accepted
+    and ignored).  Same bits as eager steps."""
     hp = make_hp(optimizer="adam", learning_rate=0.02, FEATURE_COUNT=2000, batch_size=48)
     rng = np.random.default_rng(13)
     p32 = X.init_params(hp, seed=8)
@@ -317,20 +315,110 @@ def test_graphed_step_through_run_and_run_batch_equals_eager():
     keys = [object() for _ in batches]
     for k in range(1, 9):
         le = float(eager.train_step(upload(eager, batches[k]))[0])
-        announce = k + 1 < 9 and k != 3
         if k < 5:  # four arrays
-            # (step 4 announces a tensor, step 5 arrives under another identity: sorted again in front of it)
-            lg = float(gs.run(*devs[k], next_ids=devs[k + 1][2] if announce else None)[0])
-        else:      # device batches, identities chosen by the caller
-            pb = gs.pack_batch(dbs[k], next_ids=dbs[k + 1].ids if (announce and k % 2) else None)
-            lg = float(gs.run_batch(pb, keys[k], keys[k + 1] if announce else None,
-                                    dbs[k + 1].ids if announce else None)[0])
+            lg = float(gs.run(*devs[k], next_ids=devs[k + 1][2] if k % 2 else None)[0])
+        else:      # device batches
+            pb = gs.pack_batch(dbs[k])
+            lg = float(gs.run_batch(pb, keys[k], keys[k + 1] if k + 1 < 9 else None)[0])
         assert le == lg, (k, le, lg)
     sa, sb = eager.state_dict(), graph.state_dict()
     assert sa["step"] == sb["step"] == 9
     for k in sa:
         if torch.is_tensor(sa[k]):
             assert torch.equal(sa[k], sb[k]), k
+
+
+def _dense_adam_absent(p, m, v, s, G, lr, b1=0.9, b2=0.999, eps=1e-8):
+    """TF1 Adam on a row with a zero gradient for steps s+1 .. s+G (float64, step by step):
+    base_model.py:290 + the dense table gradient of SURVEY.md 8a A2."""
+    p, m, v = (np.asarray(x, dtype=np.float64).copy() for x in (p, m, v))
+    for j in range(s + 1, s + G + 1):
+        m *= b1
+        v *= b2
+        p -= lr * np.sqrt(1 - b2 ** j) / (1 - b1 ** j) * m / (np.sqrt(v) + eps)
+    return p, m, v
+
+
+@pytest.mark.parametrize("lr", [0.002, 0.05])
+def test_row_ageing_equals_dense_adam_step_by_step(lr):
+    """Kernel level: rows that are G steps behind, read through xdfm_embed_gather with an xdfm_row_age
+    (aged in registers, nothing written) and written back by xdfm_embed_catchup, against Adam's dense update
+    applied step by step in float64 -- gaps from 1 to thousands of steps, rows last touched in the first steps
+    of training (where the bias corrections bend) and late, second moments from 1e-4 down to below eps^2, at the
+    notebook's learning rate and at one 25 times larger.  A catch-up split in two (20 steps, then 10) must land
+    where one of 30 steps does."""
+    D, N = 16, 4096
+    hp = make_hp(optimizer="adam", learning_rate=lr, FEATURE_COUNT=N, dim=D, use_CIN_part=False, use_DNN_part=False,
+                 use_FM_part=False)
+    rng = np.random.default_rng(3)
+    cases = [(s, G) for s in (1, 3, 50, 63, 500, 16383, 16384, 40000)
+             for G in (1, 5, 24, 30, 100, 255, 256, 300, 2000)]
+    rows = np.arange(len(cases)) * 7 + 5
+    for t_now_extra in (0,):
+        for s_fixed in sorted({s + G for s, G in cases}):
+            idx = [i for i, (s, G) in enumerate(cases) if s + G == s_fixed]
+            eng = XDeepFMEngine(hp, embedding_update="sparse_rows")
+            eng.load_state({"step": s_fixed}, strict=False)  # all rows current for s_fixed
+            p0 = rng.normal(0, 0.1, (len(idx), D)).astype(np.float32)
+            mag = 10.0 ** rng.uniform(-9, -2, (len(idx), D))
+            m0 = (rng.choice([-1.0, 1.0], (len(idx), D)) * mag * rng.uniform(0.05, 1.0, (len(idx), D))).astype(np.float32)
+            v0 = (mag * mag * rng.uniform(0.001, 1.0, (len(idx), D))).astype(np.float32)
+            lw0 = rng.normal(0, 0.1, len(idx)).astype(np.float32)
+            lm0, lv0 = m0[:, 0].copy(), v0[:, 0].copy()
+            r = torch.as_tensor(rows[idx]).cuda()
+            eng.table[r] = torch.as_tensor(p0).cuda()
+            eng.table_m[r] = torch.as_tensor(m0).cuda()
+            eng.table_v[r] = torch.as_tensor(v0).cuda()
+            eng.lin_w[r] = torch.as_tensor(lw0).cuda()
+            eng.lin_m[r] = torch.as_tensor(lm0).cuda()
+            eng.lin_v[r] = torch.as_tensor(lv0).cuda()
+            eng.row_step[r] = torch.as_tensor([cases[i][0] for i in idx], dtype=torch.int32).cuda()
+            before = eng._records.clone()
+            out = torch.zeros((len(idx), D), device="cuda")
+            lout = torch.zeros((len(idx),), device="cuda")
+            _lib.check(eng.lib.xdfm_embed_gather(_ptr(eng.table), _ptr(eng.lin_w), eng.table_stride, eng.lin_stride,
+                                                 eng.N, D, _ptr(r), len(idx), _ptr(out), _ptr(lout), 0,
+                                                 _ptr(eng.err_flag), eng._age(0), eng._stream()))
+            torch.cuda.synchronize()
+            assert torch.equal(before, eng._records)  # the gather writes nothing
+            eng._rows_stale = True
+            eng.flush_rows()
+            torch.cuda.synchronize()
+            for n, i in enumerate(idx):
+                s, G = cases[i]
+                pe, me, ve = _dense_adam_absent(p0[n], m0[n], v0[n], s, G, lr)
+                le, _, _ = _dense_adam_absent(lw0[n], lm0[n], lv0[n], s, G, lr)
+                drift = np.abs(pe - p0[n]).max()
+                tol = 3e-7 * max(1.0, np.abs(pe).max()) + 2e-5 * drift
+                got = out[n].cpu().numpy()
+                assert np.abs(got - pe).max() <= tol, (lr, s, G, np.abs(got - pe).max(), drift)
+                assert abs(float(lout[n]) - le) <= tol, (lr, s, G, "lin")
+                # written back: the same bits as the gather formed, slots decayed, row dated
+                assert np.array_equal(eng.table[rows[i]].cpu().numpy(), got)
+                np.testing.assert_allclose(eng.table_m[rows[i]].cpu().numpy(), me, rtol=2e-5, atol=1e-37)
+                np.testing.assert_allclose(eng.table_v[rows[i]].cpu().numpy(), ve, rtol=2e-5, atol=1e-37)
+                assert int(eng.row_step[rows[i]]) == s_fixed
+            del eng
+    # split invariance: 30 steps at once against 20 + 10
+    one = XDeepFMEngine(hp, embedding_update="sparse_rows")
+    two = XDeepFMEngine(hp, embedding_update="sparse_rows")
+    s = 700
+    p0 = rng.normal(0, 0.1, (8, D)).astype(np.float32)
+    m0 = (10.0 ** rng.uniform(-7, -3, (8, D))).astype(np.float32)
+    v0 = (m0 * m0 * 0.3).astype(np.float32)
+    r = torch.arange(8).cuda() * 3
+    for eng, stops in ((one, (s + 30,)), (two, (s + 20, s + 30))):
+        eng.load_state({"step": s}, strict=False)
+        eng.table[r], eng.table_m[r], eng.table_v[r] = (torch.as_tensor(x).cuda() for x in (p0, m0, v0))
+        for t in stops:
+            eng.opt_state.copy_(torch.tensor([0.9 ** t, 0.999 ** t, 0.0, float(t)]))
+            eng._init_drift_tab()
+            eng._rows_stale = True
+            eng.flush_rows()
+    torch.cuda.synchronize()
+    d = (one.table[r] - two.table[r]).abs().max().item()
+    moved = (one.table[r].cpu() - torch.as_tensor(p0)).abs().max().item()
+    assert d <= 2e-7 + 2e-6 * moved, (d, moved)
 
 
 @pytest.mark.parametrize("name", ["all_parts", "criteo_shape", "wide_shape"])
