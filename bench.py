@@ -373,8 +373,10 @@ def main():
         if hasattr(eng, "graph_local"):
             eng.graph_local = False
         # per-kernel durations are taken with every kernel alone on the device: the side-stream
-        # placement of the last filter gradient (beside the table update) is switched off here
+        # placements of the last filter gradient (beside the table update) and of the id sort (beside
+        # the forward pass) are switched off here
         eng.split_dw = False
+        eng.serial_plan = True
         for i in range(prof_steps):
             eager_step(args.warmup + args.steps + i)
         fence()

@@ -17,7 +17,8 @@ import torch  # noqa: F401  (must precede the CDLL below)
 
 __all__ = ["lib", "check", "XdfmLibraryError", "XdfmError", "OptArgs", "RowAge", "BatchInfo", "LIB_PATH"]
 
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libxdfm.so")
+# XDFM_LIB_PATH: another build of the same library (kernel tuning builds beside the shipped one)
+LIB_PATH = os.environ.get("XDFM_LIB_PATH") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libxdfm.so")
 
 
 class XdfmLibraryError(ImportError):

@@ -9,8 +9,10 @@
 // second order in d_i = eps (g^-i - g^-kDriftC) around e = eps g^-kDriftC;  with y = 1 / (sqrt(v) + e)
 //     sum = y C0 - y^2 C1 + y^3 C2,      C_k(s, G) = sum_i c_i d_i^k
 // (relative error of the sum below 1e-6: tools/drift_sim.py).  The table holds (C0, C1, C2, 0) as float4:
-//     cur[2][kDriftG]   G < kDriftG steps missed as of optimizer step t (s = t - G), in slot t & 1; rebuilt for
-//                       the new t by every xdfm_opt_advance (readers of step t's slot run while t + 1's is written)
+//     cur[2][kDriftG]   G < kDriftG steps missed as of optimizer step t (s = t - G), in slot t & 1; every
+//                       xdfm_opt_advance forms the new t's slot from the other one (entry G from entry G - 1 plus
+//                       step t's term, with the alpha_t the update itself uses), so readers of step t's slot
+//                       may still run while t + 1's is written
 //     hist[kDriftS + 1] G >= kDriftG (the terms beyond 255 steps weigh 0.9^255): a function of s alone, built
 //                       once; entry kDriftS serves every s >= kDriftS, where alpha_j = lr to the last bit
 #pragma once

@@ -343,7 +343,9 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(FwdArgs a) {
     // tokens, then the table rows of those tokens are each requested in one go, so a sample
     // costs three memory round trips instead of three per row.  Further tokens of a multi-hot
     // row follow in column order (the sums stay bit-identical to the sequential form).
-    constexpr int PU = 4;
+    // (under ageing a row is four loads, not one: 2 rows per group keep the kernel at 110 registers and
+    // 26 us on the bench workload; 4 rows take 161 registers and 32 us, 1 row 88 and 25 us)
+    constexpr int PU = AGE ? 2 : 4;
     for (int f0 = g; f0 < F; f0 += PU * RPP) {
       int beg[PU], end[PU];
       int64_t id0[PU];

@@ -236,18 +236,34 @@ __device__ __forceinline__ void drift_fill_cur(float4* tab, int t, float lr, flo
 }
 
 // TF keeps beta1_power / beta2_power as fp32 variables multiplied up every step; same here.
-// 4 * kDriftG threads: the state moves on in thread 0, every quad rebuilds one drift entry for the new step.
-__global__ __launch_bounds__(4 * xdfm::kDriftG) void opt_advance_kernel(float* st, float lr, float beta1,
-                                                                        float beta2, float eps, float4* tab) {
+// kDriftG threads: the state moves on in thread 0; thread G forms the drift entry of "G steps missed as
+// of the new step t" from the entry of "G - 1 steps missed as of t - 1" (the same row one step earlier, in
+// the other slot) by adding step t's term:  C_k(t - G, G) = C_k(t - G, G - 1) + alpha_t (b1/g)^G d_G^k.
+__global__ __launch_bounds__(xdfm::kDriftG) void opt_advance_kernel(float* st, float lr, float beta1, float beta2,
+                                                                    float eps, float4* tab) {
   const float b1p = st[0] * beta1, b2p = st[1] * beta2, t = st[3] + 1.f;
+  const float alpha = lr * sqrtf(1.f - b2p) / (1.f - b1p);
   __syncthreads();  // every thread has read the old state
   if (threadIdx.x == 0) {
     st[0] = b1p;
     st[1] = b2p;
-    st[2] = lr * sqrtf(1.f - b2p) / (1.f - b1p);
+    st[2] = alpha;
     st[3] = t;
   }
-  if (tab) drift_fill_cur(tab, (int)t, lr, beta1, beta2, eps);
+  if (tab) {
+    const int ti = (int)t, G = threadIdx.x;
+    float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (G >= 1 && G <= ti) {
+      const float lb1 = log2f(beta1), lb2 = log2f(beta2);
+      c = tab[((ti - 1) & 1) * xdfm::kDriftG + G - 1];
+      const float w = alpha * exp2f((float)G * (lb1 - 0.5f * lb2));
+      const float d = eps * (exp2f(-(float)G * 0.5f * lb2) - exp2f(-(float)xdfm::kDriftC * 0.5f * lb2));
+      c.x += w;
+      c.y += w * d;
+      c.z += w * d * d;
+    }
+    tab[(ti & 1) * xdfm::kDriftG + G] = c;
+  }
 }
 
 __global__ __launch_bounds__(4 * xdfm::kDriftG) void drift_init_kernel(const float* st, float lr, float beta1,
@@ -706,7 +722,7 @@ extern "C" int xdfm_opt_advance(float* opt_state, float lr, float beta1, float b
   XDFM_REQUIRE(opt_state, "xdfm_opt_advance: null state");
   XDFM_REQUIRE(!drift_tab || (beta1 > 0.f && beta1 < 1.f && beta2 > 0.f && beta2 < 1.f),
                "xdfm_opt_advance: the drift table is Adam's (betas in (0, 1))");
-  XDFM_LAUNCH("opt_advance_kernel", stream, opt_advance_kernel, dim3(1), dim3(4 * xdfm::kDriftG), 0, opt_state, lr,
+  XDFM_LAUNCH("opt_advance_kernel", stream, opt_advance_kernel, dim3(1), dim3(xdfm::kDriftG), 0, opt_state, lr,
               beta1, beta2, eps, reinterpret_cast<float4*>(drift_tab));
   XDFM_LAUNCH_CHECK();
   return XDFM_OK;

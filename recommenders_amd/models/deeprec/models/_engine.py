@@ -315,6 +315,7 @@ class XDeepFMEngine(object):
         self._split = {}
         self._fused_pool = set()
         self.split_dw = os.environ.get("XDFM_SPLIT_DW", "1") != "0"
+        self.serial_plan = False  # bench.py's per-kernel timing: the id sort on the main stream
         self._late_event = None
         self._fold_dx = False
         self.overlap_dnn = self.overlap_dnn_wanted(hp) and not self.bf16
@@ -750,6 +751,8 @@ class XDeepFMEngine(object):
         update() waits for it."""
         if self._plan_complete(batch):
             return
+        if self.serial_plan:  # (measurement: the sort's kernels alone on the device)
+            return self.plan(batch)
         self._ensure_ws(batch.B, batch.nnz)
         main = torch.cuda.current_stream(self.device)
         if self._side_stream is None:

@@ -328,9 +328,10 @@ def test_graphed_step_through_run_and_run_batch_equals_eager():
             assert torch.equal(sa[k], sb[k]), k
 
 
-def _dense_adam_absent(p, m, v, s, G, lr, b1=0.9, b2=0.999, eps=1e-8):
-    """TF1 Adam on a row with a zero gradient for steps s+1 .. s+G (float64, step by step):
-    base_model.py:290 + the dense table gradient of SURVEY.md 8a A2."""
+def _dense_adam_absent(p, m, v, s, G, lr, b1=float(np.float32(0.9)), b2=float(np.float32(0.999)),
+                       eps=float(np.float32(1e-8))):
+    """TF1 Adam on a row with a zero gradient for steps s+1 .. s+G (float64, step by step, with the
+    fp32 constants TF's kernel holds): base_model.py:290 + the dense table gradient of SURVEY.md 8a A2."""
     p, m, v = (np.asarray(x, dtype=np.float64).copy() for x in (p, m, v))
     for j in range(s + 1, s + G + 1):
         m *= b1
