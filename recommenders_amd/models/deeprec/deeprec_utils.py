@@ -346,12 +346,44 @@ def _binary_logloss(labels, preds):
     return float(-np.mean(y * np.log(p) + (1.0 - y) * np.log(1.0 - p)))
 
 
+def _mrr_score(y_true, y_score):
+    order = np.argsort(y_score)[::-1]
+    y_true = np.take(y_true, order)
+    return np.sum(y_true / (np.arange(len(y_true)) + 1)) / np.sum(y_true)
+
+
+def _dcg_score(y_true, y_score, k=10):
+    k = min(np.shape(y_true)[-1], k)
+    order = np.argsort(y_score)[::-1]
+    y_true = np.take(y_true, order[:k])
+    return np.sum((2**y_true - 1) / np.log2(np.arange(len(y_true)) + 2))
+
+
+def _ndcg_score(y_true, y_score, k=10):
+    return _dcg_score(y_true, y_score, k) / _dcg_score(y_true, y_true, k)
+
+
+def _hit_score(y_true, y_score, k=10):
+    truth = set(np.where(np.asarray(y_true) == 1)[0].tolist())
+    for idx in np.argsort(y_score)[::-1][:k]:
+        if int(idx) in truth:
+            return 1
+    return 0
+
+
+def _at_list(metric):
+    parts = metric.split("@")
+    if len(parts) > 1:
+        return [int(tok) for tok in parts[1].split(";")]
+    return [1, 2]
+
+
 def cal_metric(labels, preds, metrics):
     """Compute the requested metrics (reference :514-602).
 
-    ``auc`` and ``logloss`` are the xDeepFM metrics; ``rmse``, ``acc`` and ``f1`` are the other
-    pointwise ones.  The grouped ranking metrics (``mean_mrr``, ``ndcg@..``, ``hit@..``,
-    ``group_auc``) belong to the reference's news/sequential models and raise.  Values are rounded to 4 decimals exactly where the
+    ``auc`` and ``logloss`` are the xDeepFM metrics; ``rmse``, ``acc``, ``f1`` are the other pointwise
+    ones, ``mean_mrr``, ``ndcg@..``, ``hit@..``, ``group_auc`` the grouped ranking metrics (lists of
+    per-group labels / predictions, reference :558-599).  Values are rounded to 4 decimals exactly where the
     reference rounds.  Like the reference, ``logloss`` rebinds ``preds`` to the clipped
     list for the metrics that follow it, and ``acc``/``f1`` threshold a fresh array.
     """
@@ -384,10 +416,23 @@ def cal_metric(labels, preds, metrics):
                 fn = float(np.sum((hard.reshape(-1) != 1) & (truth == 1)))
                 denom = 2 * tp + fp + fn
                 res["f1"] = round(2 * tp / denom if denom > 0 else 0.0, 4)
-        elif metric in ("mean_mrr", "group_auc") or metric.startswith(("ndcg", "hit")):
-            raise ValueError(
-                "Metric {0} is a grouped ranking metric of the reference's news/sequential models; "
-                "it is outside the xDeepFM path this package serves".format(metric)
+        elif metric == "mean_mrr":
+            res["mean_mrr"] = round(
+                np.mean([_mrr_score(l, p) for l, p in zip(labels, preds)]), 4
+            )
+        elif metric.startswith("ndcg"):
+            for k in _at_list(metric):
+                res["ndcg@{0}".format(k)] = round(
+                    np.mean([_ndcg_score(l, p, k) for l, p in zip(labels, preds)]), 4
+                )
+        elif metric.startswith("hit"):
+            for k in _at_list(metric):
+                res["hit@{0}".format(k)] = round(
+                    np.mean([_hit_score(l, p, k) for l, p in zip(labels, preds)]), 4
+                )
+        elif metric == "group_auc":
+            res["group_auc"] = round(
+                np.mean([_binary_auc(l, p) for l, p in zip(labels, preds)]), 4
             )
         else:
             raise ValueError("Metric {0} not defined".format(metric))

@@ -146,7 +146,7 @@ class FFMTextIterator(BaseIterator):
             yield from self._load_native(infile)  # raises the reader's own error
             return
         key = (os.path.abspath(str(infile)), st.st_size, st.st_mtime_ns, int(self.batch_size),
-               int(self.field_cnt), int(self.feature_cnt))
+               int(self.field_cnt), int(self.feature_cnt), str(self.col_spliter), str(self.ID_spliter))
         hit = self._parsed.get(key)
         if hit is not None:
             yield from hit
@@ -188,8 +188,8 @@ class FFMTextIterator(BaseIterator):
 
     def _disk_cached(self, infile, key):
         """The parsed batches of a file from / to XDFM_FFM_CACHE_DIR (off when unset): a re-run whose
-        file is unchanged (same path, size, mtime, batch size, FIELD_COUNT, FEATURE_COUNT) parses no
-        text at all, not even in its first epoch.  One uncompressed .npz per file, arrays written as
+        file is unchanged (same path, size, mtime, batch size, FIELD_COUNT, FEATURE_COUNT, separators) parses
+        no text at all, not even in its first epoch.  One uncompressed .npz per file, arrays written as
         the batches stream by and read back one batch at a time (nothing unpickled, allow_pickle off);
         the archive is renamed into place only when the whole file went through."""
         path = self._disk_path(key)
@@ -197,13 +197,18 @@ class FFMTextIterator(BaseIterator):
             yield from self._read_ahead(self._load_native(infile))
             return
         if os.path.exists(path):
+            # validated BEFORE the first batch is handed out (meta readable, every member of every
+            # batch present and complete): a damaged archive is then parsed again from the start
+            # instead of after some of its batches were delivered
             try:
-                yield from self._read_ahead(self._load_disk(path))
-                return
-            except (OSError, ValueError, KeyError) as exc:  # damaged or foreign archive: parse again
+                self._check_disk(path)
+            except Exception as exc:  # damaged, truncated or foreign archive (zipfile / numpy errors)
                 import warnings
 
                 warnings.warn("ignoring the parsed-batch cache %s (%s)" % (path, exc))
+            else:
+                yield from self._read_ahead(self._load_disk(path))
+                return
         import json
         import zipfile
 
@@ -239,6 +244,31 @@ class FFMTextIterator(BaseIterator):
     def _placeholders(self):
         return (self.labels, self.fm_feat_indices, self.fm_feat_values, self.fm_feat_shape,
                 self.dnn_feat_indices, self.dnn_feat_values, self.dnn_feat_weights, self.dnn_feat_shape)
+
+    def _check_disk(self, path):
+        """Raises unless the archive holds meta and, for each of its batches, all eight arrays with
+        sizes that match their zip entries (zip directory + .npy headers only: no array is read)."""
+        import zipfile
+
+        with zipfile.ZipFile(path) as zf:
+            infos = {i.filename: i for i in zf.infolist()}
+            with zf.open("meta.npy") as f:
+                meta = np.lib.format.read_array(f, allow_pickle=False)
+            version, count = (int(x) for x in meta)
+            if version != self._DISK_VERSION:
+                raise ValueError("cache version %d" % version)
+            for i in range(count):
+                for name in self._DISK_KEYS:
+                    member = "b%d_%s.npy" % (i, name)
+                    info = infos.get(member)
+                    if info is None:
+                        raise KeyError(member)
+                    with zf.open(member) as f:
+                        major, _ = np.lib.format.read_magic(f)
+                        shape, _, dt = (np.lib.format.read_array_header_1_0 if major == 1
+                                        else np.lib.format.read_array_header_2_0)(f)
+                        if f.tell() + int(np.prod(shape, dtype=np.int64)) * dt.itemsize != info.file_size:
+                            raise ValueError("%s is truncated" % member)
 
     def _load_disk(self, path):
         import json

@@ -2,7 +2,7 @@
 
 Mirrors reference ``recommenders/models/deeprec/models/base_model.py``:
 constructor (:20-73), ``train/eval/infer`` (:367-416), ``load_model`` (:418-434),
-``fit`` (:436-540), ``run_eval`` (:568-595; without the grouped ranking metrics of :542-566),
+``fit`` (:436-540), ``group_labels`` (:542-566), ``run_eval`` (:568-595),
 ``predict`` (:597-618).  What was a TensorFlow graph + session is a device engine
 (``_engine.XDeepFMEngine``) that launches the HIP kernels of libxdfm.so; ``graph`` and
 ``sess`` are accepted / exposed as inert handles.
@@ -342,6 +342,16 @@ class BaseModel:
             events.close()
         return self
 
+    def group_labels(self, labels, preds, group_keys):
+        """Divide ``labels`` and ``preds`` into groups by ``group_keys`` (reference :542-566)."""
+        all_keys = list(set(group_keys))
+        group_labels = {k: [] for k in all_keys}
+        group_preds = {k: [] for k in all_keys}
+        for label, p, k in zip(labels, preds, group_keys):
+            group_labels[k].append(label)
+            group_preds[k].append(p)
+        return [group_labels[k] for k in all_keys], [group_preds[k] for k in all_keys]
+
     def run_eval(self, filename):
         """Evaluate ``filename``; returns ``{metric: value rounded to 4 decimals}``.
 
@@ -350,13 +360,14 @@ class BaseModel:
         ``cal_metric`` on the host like the reference (:588).
         """
         eng = self.engine
-        preds, labels = [], []
-        for batch_data_input, _, data_size in self.iterator.load_data_from_file(filename):
+        preds, labels, imp_indexs = [], [], []
+        for batch_data_input, imp_index, data_size in self.iterator.load_data_from_file(filename):
             batch_data_input[self.layer_keeps] = self.keep_prob_test
             batch_data_input[self.is_train_stage] = False
             batch = self._batch_from_feed(batch_data_input)
             preds.append(eng.forward(batch, with_loss=False).clone())
             labels.append(batch.labels)
+            imp_indexs.extend(np.reshape(imp_index, -1))
         metrics = self.hparams.metrics
         if not preds:
             raise ValueError("no samples in {0}".format(filename))
@@ -378,15 +389,15 @@ class BaseModel:
         else:
             eng.check_errors()
         host_preds = host_labels = None
-        if host_metrics:
+        if host_metrics or "pairwise_metrics" in self.hparams.values():
             host_preds = list(all_preds.cpu().numpy())
             host_labels = list(all_labels.cpu().numpy())
         if host_metrics:
             res.update(cal_metric(host_labels, host_preds, host_metrics))
         res = {m: res[m] for m in res}  # insertion order: device metrics then host metrics
         if "pairwise_metrics" in self.hparams.values():
-            # grouped ranking metrics (reference :542-566, :590-594) serve the news/sequential models
-            raise ValueError("pairwise_metrics are outside the xDeepFM path this package serves")
+            group_labels, group_preds = self.group_labels(host_labels, host_preds, imp_indexs)
+            res.update(cal_metric(group_labels, group_preds, self.hparams.pairwise_metrics))
         return res
 
     def predict(self, infile_name, outfile_name):

@@ -90,6 +90,15 @@ def gen_hparams_and_metrics():
         mcases.append({"labels": y.tolist(), "preds": [float(v) for v in p],
                        "metrics": ["auc", "logloss", "rmse", "acc", "f1"],
                        "expected": {k: float(v) for k, v in res.items()}})
+    # the docstring-style grouped call (deeprec_utils.py:529-530 shows the format)
+    gl = [rng.integers(0, 2, 6).astype(float) for _ in range(5)]
+    gp = [rng.random(6) for _ in range(5)]
+    for g in gl:
+        g[0], g[1] = 1.0, 0.0
+    res = R.cal_metric(gl, gp, ["ndcg@2;4;6", "group_auc", "mean_mrr", "hit@1;3"])
+    mcases.append({"labels": [g.tolist() for g in gl], "preds": [g.tolist() for g in gp],
+                   "metrics": ["ndcg@2;4;6", "group_auc", "mean_mrr", "hit@1;3"],
+                   "expected": {k: float(v) for k, v in res.items()}})
     with open(os.path.join(HERE, "cal_metric_golden.json"), "w") as f:
         json.dump(mcases, f)
 

@@ -263,3 +263,21 @@ def test_parsed_batches_on_disk_serve_a_second_run_without_parsing(tmp_path, mon
     with pytest.warns(UserWarning):
         again = list(FFMTextIterator(hp, None).load_data_from_file(path))
     same(third, again)
+    # a TRUNCATED archive (its directory gone, or one member cut short) is found out before the first
+    # batch is handed out: every batch is delivered exactly once, from the text
+    files = sorted(os.listdir(cache))
+    for f in files:
+        os.remove(cache / f)
+    full = list(FFMTextIterator(hp, None).load_data_from_file(path))
+    (arch,) = os.listdir(cache)
+    blob = open(cache / arch, "rb").read()
+    with open(cache / arch, "wb") as fh:
+        fh.write(blob[: len(blob) * 2 // 3])
+    with pytest.warns(UserWarning):
+        cut = list(FFMTextIterator(hp, None).load_data_from_file(path))
+    same(full, cut)
+    # another separator is another key: no archive of the " " / "%" file is taken for it
+    other = FFMTextIterator(hp, None, col_spliter=" ", ID_spliter="#")
+    before = set(os.listdir(cache))
+    list(other.load_data_from_file(path))
+    assert len(set(os.listdir(cache)) - before) == 1
