@@ -324,11 +324,9 @@ def main():
         return eng.train_step(batch, next_batch=pending.get(i + 1))
 
     graphed = None
-    from recommenders_amd.models.deeprec.models._engine import graph_replay_refusal
-
-    if graph_replay_refusal() and not args.no_graph:
-        print("bench: %s -- every step launched eagerly" % graph_replay_refusal(), file=sys.stderr)
-        args.no_graph = True
+    if getattr(eng, "folded", False):
+        print("bench: GPU_MAX_HW_QUEUES=%s -- the step is folded onto one stream (its capture is a chain)"
+              % os.environ.get("GPU_MAX_HW_QUEUES"), file=sys.stderr)
     if world == 1 and not args.no_graph and not args.sharded:
         # one GPU: the whole step (copy of the batch arrays into the graph's inputs aside) is one
         # HIP graph launch; N > 1 stays eager (split sizes of the all-to-all are host values)
@@ -458,7 +456,8 @@ def main():
                            world, "" if backend == "nccl" else " [REHEARSAL over %s, ranks share GPUs: not a measurement]" % backend)},
             "roofline": roofline,
             "kernel_time_ms_per_step": round(total_ms / prof_steps, 4),
-            "launch": ("hip graph replay" if graphed is not None else
+            "launch": (("hip graph replay" + (" (folded onto one stream: GPU_MAX_HW_QUEUES < 4)"
+                                              if getattr(eng, "folded", False) else "")) if graphed is not None else
                        "exchanges eager, local forward/backward as a hip graph" if not in_situ else "eager"),
             "kernel_timing": "HIP events around every launch, %s" % (
                 "in the timed region" if in_situ else "%d eager steps right after the timed graph replays" % prof_steps),

@@ -685,13 +685,19 @@ int xdfm_head_loss(const float* part0, const float* part1, const float* part3, c
                    float* d_pooled, float* loss, float* scratch, void* stream);
 int xdfm_loss_finish(const float* scratch, int64_t B, int64_t mean_count, int32_t loss_kind, float* loss,
                      void* stream);
+/* out2 = {loss2[0], loss2[0] + loss2[1]}: data loss and total loss (data + regularisation) as a training
+ * step reports them (base_model.py:80-89, :379-388), one tiny launch. */
+int xdfm_loss_total(const float* loss2, float* out2, void* stream);
 
 /* ------------------------------------------------------------------------
  * Fused evaluation: AUC (ties grouped, == sklearn.roc_auc_score) and logloss
  * (float64, preds clipped to [1e-11, 1-1e-11]) of a whole file's predictions.
  *   cal_metric deeprec_utils.py:535-545 as called from run_eval base_model.py:588.
- *   preds[n], labels[n] float32 (device); out[4] double (device):
+ *   preds[n], labels[n] float32 (device; labels 0 / 1); out[4] double (device):
  *   out[0]=auc (NaN when only one class), out[1]=logloss, out[2]=#positives, out[3]=n
+ *   Hand-written throughout: order-preserving 32-bit keys of the scores with the label as payload
+ *   through the library's own stable radix sort, then ONE pass over the sorted pairs that forms the
+ *   tie-aware pair count in integers (twice the average rank of every positive) and the logloss sum.
  * ---------------------------------------------------------------------- */
 int xdfm_eval_workspace_bytes(int64_t n, size_t* bytes);
 int xdfm_eval_auc_logloss(const float* preds, const float* labels, int64_t n, double* out,

@@ -187,6 +187,7 @@ SIGNATURES = {
     "xdfm_cin_head_bwd": [_P, _P, _P, _I64, _I32, _P, _P, _P, _P, _P],
     "xdfm_logit_loss": [_P, _P, _P, _P, _P, _P, _I64, _I64, _I32, _I32, _P, _P, _P, _P, _P, _P],
     "xdfm_loss_finish": [_P, _I64, _I64, _I32, _P, _P],
+    "xdfm_loss_total": [_P, _P, _P],
     "xdfm_head_loss": [_P, _P, _P, _P, _P, _P, _P, _I32, _P, _I64, _I64, _I32, _I32, _P, _P, _P, _P, _P, _P, _P,
                        _P],
     "xdfm_eval_workspace_bytes": [_I64, _PSZ],

@@ -12,9 +12,9 @@
 #include <hip/hip_runtime.h>
 
 #include <cstring>
-#include <rocprim/rocprim.hpp>
 
 #include "drift.h"
+#include "sort_plan.h"
 #include "xdfm_common.h"
 
 namespace {
@@ -495,6 +495,10 @@ __device__ __forceinline__ uint32_t float_key(float f) {
   return (u & 0x80000000u) ? ~u : (u | 0x80000000u);  // ascending order-preserving
 }
 
+__device__ __forceinline__ float key_float(uint32_t k) {
+  return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
+}
+
 __global__ void eval_keys_kernel(const float* __restrict__ preds, const float* __restrict__ labels,
                                  long long n, uint32_t* __restrict__ keys, uint32_t* __restrict__ pos) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -503,98 +507,104 @@ __global__ void eval_keys_kernel(const float* __restrict__ preds, const float* _
   pos[i] = labels[i] > 0.5f ? 1u : 0u;
 }
 
-// after the sort: neg flag per sorted position
-__global__ void eval_negflag_kernel(const uint32_t* __restrict__ pos_sorted, long long n,
-                                    int32_t* __restrict__ neg) {
-  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) neg[i] = 1 - (int32_t)pos_sorted[i];
-}
-
-// per tie-group head: 2*U contribution = pos_in*(2*neg_before + neg_in); integer, exact
-__global__ __launch_bounds__(256) void eval_auc_kernel(const uint32_t* __restrict__ keys,
-                                                       const int32_t* __restrict__ cneg /*exclusive*/,
-                                                       long long n, unsigned long long* u2) {
-  __shared__ unsigned long long sh[256];
-  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-  unsigned long long c = 0;
-  if (i < n) {
+// One pass over the score-sorted (key, label) pairs (ascending), per block in a fixed order:
+//  * AUC as sklearn's roc_auc_score forms it (trapezoids over tied scores = Mann-Whitney U with average
+//    ranks; deeprec_utils.py:535-537), in integers: a positive in the tie group [s, e) has twice the
+//    average rank s + e + 1 (1-based), so 2 U = sum over positives of (s + e + 1) - n_pos (n_pos + 1).
+//    A sample whose neighbours hold other scores is its own group; only ties search for their bounds.
+//  * logloss after the reference's clip to [1e-11, 1 - 1e-11] (deeprec_utils.py:541-545), in float64
+//    (the score is recovered from its key bit for bit, the label from the payload's truth bit; the
+//    float label itself decides acc-style thresholds nowhere here: labels are 0 / 1).
+__global__ __launch_bounds__(256) void eval_reduce_kernel(const uint32_t* __restrict__ keys,
+                                                          const uint32_t* __restrict__ pos, long long n, unsigned long long* __restrict__ part_rank,
+                                                          unsigned long long* __restrict__ part_pos,
+                                                          double* __restrict__ part_ll) {
+  __shared__ unsigned long long shu[256];
+  __shared__ double shd[256];
+  unsigned long long rank2 = 0, npos = 0;
+  double ll = 0.0;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
     const uint32_t k = keys[i];
-    if (i == 0 || keys[i - 1] != k) {
-      long long lo = i + 1, hi = n;  // first position with key > k
-      while (lo < hi) {
-        const long long mid = (lo + hi) >> 1;
-        if (keys[mid] == k) lo = mid + 1; else hi = mid;
+    const bool y = pos[i] != 0u;
+    double p = (double)key_float(k);
+    p = fmin(fmax(p, 10e-12), 1.0 - 10e-12);  // deeprec_utils.py:543
+    ll += y ? -log(p) : -log(1.0 - p);
+    if (y) {
+      long long s = i, e = i + 1;
+      if (i > 0 && keys[i - 1] == k) {  // first position holding k
+        long long lo = 0, hi = i - 1;   // keys[hi] == k
+        while (lo < hi) {
+          const long long mid = (lo + hi) >> 1;
+          if (keys[mid] == k) hi = mid; else lo = mid + 1;
+        }
+        s = lo;
       }
-      const long long e = lo;
-      const long long neg_total_e = (e < n) ? cneg[e] : -1;
-      // cneg has n entries (exclusive scan); the count up to n is cneg[n-1] + neg[n-1]:
-      // the caller stores that total at cneg[n].
-      const long long neg_e = (e < n) ? neg_total_e : cneg[n];
-      const long long neg_b = cneg[i];
-      const long long neg_in = neg_e - neg_b;
-      const long long pos_in = (e - i) - neg_in;
-      c = (unsigned long long)pos_in * (unsigned long long)(2 * neg_b + neg_in);
+      if (i + 1 < n && keys[i + 1] == k) {  // first position past the run of k
+        long long lo = i + 2, hi = n;
+        while (lo < hi) {
+          const long long mid = (lo + hi) >> 1;
+          if (keys[mid] == k) lo = mid + 1; else hi = mid;
+        }
+        e = lo;
+      }
+      rank2 += (unsigned long long)(s + e + 1);
+      npos += 1;
     }
   }
-  c = block_sum<unsigned long long, 256>(c, sh);
-  if (threadIdx.x == 0 && c) atomicAdd(u2, c);  // integer: order independent
-}
-
-__global__ void eval_total_kernel(const int32_t* __restrict__ cneg, const int32_t* __restrict__ neg,
-                                  long long n, int32_t* cneg_n) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) *cneg_n = n > 0 ? cneg[n - 1] + neg[n - 1] : 0;
-}
-
-__global__ __launch_bounds__(256) void eval_logloss_kernel(const float* __restrict__ preds,
-                                                           const float* __restrict__ labels,
-                                                           long long n, double* __restrict__ partial) {
-  __shared__ double sh[256];
-  double acc = 0.0;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n;
-       i += (long long)gridDim.x * 256) {
-    double p = (double)preds[i];
-    p = fmin(fmax(p, 10e-12), 1.0 - 10e-12);  // deeprec_utils.py:543
-    const double y = (double)labels[i];
-    acc += -(y * log(p) + (1.0 - y) * log(1.0 - p));
-  }
-  acc = block_sum<double, 256>(acc, sh);
-  if (threadIdx.x == 0) partial[blockIdx.x] = acc;
-}
-
-__global__ __launch_bounds__(256) void eval_final_kernel(const double* __restrict__ partial, int n_partial,
-                                                         const unsigned long long* u2,
-                                                         const int32_t* cneg_n, long long n,
-                                                         double* out) {
-  __shared__ double sh[256];
-  double s = 0.0;
-  for (int k = threadIdx.x; k < n_partial; k += 256) s += partial[k];
-  s = block_sum<double, 256>(s, sh);
+  rank2 = block_sum<unsigned long long, 256>(rank2, shu);
+  npos = block_sum<unsigned long long, 256>(npos, shu);
+  ll = block_sum<double, 256>(ll, shd);
   if (threadIdx.x == 0) {
-    const double n_neg = (double)*cneg_n;
-    const double n_pos = (double)n - n_neg;
-    out[0] = (n_pos > 0 && n_neg > 0) ? (double)*u2 / (2.0 * n_pos * n_neg) : nan("");
+    part_rank[blockIdx.x] = rank2;
+    part_pos[blockIdx.x] = npos;
+    part_ll[blockIdx.x] = ll;
+  }
+}
+
+__global__ __launch_bounds__(256) void eval_final_kernel(const unsigned long long* __restrict__ part_rank,
+                                                         const unsigned long long* __restrict__ part_pos,
+                                                         const double* __restrict__ part_ll, int n_partial,
+                                                         long long n, double* out) {
+  __shared__ unsigned long long shu[256];
+  __shared__ double shd[256];
+  unsigned long long r = 0, c = 0;
+  double s = 0.0;
+  for (int k = threadIdx.x; k < n_partial; k += 256) {
+    r += part_rank[k];
+    c += part_pos[k];
+    s += part_ll[k];
+  }
+  r = block_sum<unsigned long long, 256>(r, shu);
+  c = block_sum<unsigned long long, 256>(c, shu);
+  s = block_sum<double, 256>(s, shd);
+  if (threadIdx.x == 0) {
+    const double n_pos = (double)c, n_neg = (double)((unsigned long long)n - c);
+    const unsigned long long u2 = r - c * (c + 1ull);  // 2 U, exact
+    out[0] = (c > 0 && (unsigned long long)n > c) ? (double)u2 / (2.0 * n_pos * n_neg) : nan("");
     out[1] = n > 0 ? s / (double)n : nan("");
     out[2] = n_pos;
     out[3] = (double)n;
   }
 }
 
+// [data loss, regularisation loss] -> [data, data + reg]: the two numbers a training step reports
+__global__ void loss_pair_kernel(const float* __restrict__ loss2, float* __restrict__ out2) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    const float d = loss2[0];
+    out2[0] = d;
+    out2[1] = d + loss2[1];
+  }
+}
+
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
+constexpr int kEvalBlocks = 1024;
+
 struct EvalLayout {
-  size_t keys_in, keys_out, pos_in, pos_out, neg, cneg, partial, u2, tmp, tmp_bytes, total;
+  size_t keys_in, pos_in, keys_out, pos_out, part_rank, part_pos, part_ll, sort_ws, sort_ws_bytes, total;
 };
 
 int eval_layout(long long n, EvalLayout* L) {
-  size_t sort_tmp = 0, scan_tmp = 0;
-  uint32_t* nul = nullptr;
-  int32_t* nuli = nullptr;
-  if (rocprim::radix_sort_pairs(nullptr, sort_tmp, nul, nul, nul, nul, (size_t)n, 0u, 32u,
-                                (hipStream_t)0, false) != hipSuccess)
-    return xdfm::fail(XDFM_E_HIP, "rocprim sort size query failed");
-  if (rocprim::exclusive_scan(nullptr, scan_tmp, nuli, nuli, 0, (size_t)n, rocprim::plus<int32_t>(),
-                              (hipStream_t)0, false) != hipSuccess)
-    return xdfm::fail(XDFM_E_HIP, "rocprim scan size query failed");
   size_t off = 0;
   auto take = [&](size_t bytes) {
     size_t o = off;
@@ -603,15 +613,14 @@ int eval_layout(long long n, EvalLayout* L) {
   };
   const size_t nn = (size_t)n;
   L->keys_in = take(nn * 4);
-  L->keys_out = take(nn * 4);
   L->pos_in = take(nn * 4);
+  L->keys_out = take(nn * 4);
   L->pos_out = take(nn * 4);
-  L->neg = take(nn * 4);
-  L->cneg = take((nn + 1) * 4);
-  L->partial = take(1024 * sizeof(double));
-  L->u2 = take(sizeof(unsigned long long));
-  L->tmp_bytes = sort_tmp > scan_tmp ? sort_tmp : scan_tmp;
-  L->tmp = take(L->tmp_bytes);
+  L->part_rank = take(kEvalBlocks * sizeof(unsigned long long));
+  L->part_pos = take(kEvalBlocks * sizeof(unsigned long long));
+  L->part_ll = take(kEvalBlocks * sizeof(double));
+  L->sort_ws_bytes = xdfm::plan_sort_workspace_bytes(n);
+  L->sort_ws = take(L->sort_ws_bytes);
   L->total = off + 256;
   return XDFM_OK;
 }
@@ -875,35 +884,33 @@ extern "C" int xdfm_eval_auc_logloss(const float* preds, const float* labels, in
   if (rc) return rc;
   if (ws_bytes < L.total)
     return xdfm::fail(XDFM_E_WORKSPACE, "xdfm_eval_auc_logloss: workspace %zu < %zu", ws_bytes, L.total);
-  char* base = (char*)ws;
+  char* base = (char*)(((uintptr_t)ws + 255) & ~(uintptr_t)255);  // (L.total has the slack)
   uint32_t* keys_in = (uint32_t*)(base + L.keys_in);
-  uint32_t* keys_out = (uint32_t*)(base + L.keys_out);
   uint32_t* pos_in = (uint32_t*)(base + L.pos_in);
+  uint32_t* keys_out = (uint32_t*)(base + L.keys_out);
   uint32_t* pos_out = (uint32_t*)(base + L.pos_out);
-  int32_t* neg = (int32_t*)(base + L.neg);
-  int32_t* cneg = (int32_t*)(base + L.cneg);
-  double* partial = (double*)(base + L.partial);
-  unsigned long long* u2 = (unsigned long long*)(base + L.u2);
-  void* tmp = base + L.tmp;
-  size_t tmp_bytes = L.tmp_bytes;
+  unsigned long long* part_rank = (unsigned long long*)(base + L.part_rank);
+  unsigned long long* part_pos = (unsigned long long*)(base + L.part_pos);
+  double* part_ll = (double*)(base + L.part_ll);
   hipStream_t st = (hipStream_t)stream;
   const unsigned blocks = (unsigned)((n + 255) / 256);
-  XDFM_HIP(hipMemsetAsync(u2, 0, sizeof(unsigned long long), st));
   XDFM_LAUNCH("eval_keys_kernel", st, eval_keys_kernel, dim3(blocks), dim3(256), 0, preds, labels, (long long)n,
-                     keys_in, pos_in);
-  XDFM_HIP(rocprim::radix_sort_pairs(tmp, tmp_bytes, keys_in, keys_out, pos_in, pos_out, (size_t)n, 0u,
-                                     32u, st, false));
-  XDFM_LAUNCH("eval_negflag_kernel", st, eval_negflag_kernel, dim3(blocks), dim3(256), 0, pos_out, (long long)n, neg);
-  tmp_bytes = L.tmp_bytes;
-  XDFM_HIP(rocprim::exclusive_scan(tmp, tmp_bytes, neg, cneg, 0, (size_t)n, rocprim::plus<int32_t>(), st,
-                                   false));
-  XDFM_LAUNCH("eval_total_kernel", st, eval_total_kernel, dim3(1), dim3(64), 0, cneg, neg, (long long)n, cneg + n);
-  XDFM_LAUNCH("eval_auc_kernel", st, eval_auc_kernel, dim3(blocks), dim3(256), 0, keys_out, cneg, (long long)n, u2);
-  unsigned lblocks = blocks > 1024 ? 1024 : blocks;
-  XDFM_LAUNCH("eval_logloss_kernel", st, eval_logloss_kernel, dim3(lblocks), dim3(256), 0, preds, labels, (long long)n,
-                     partial);
-  XDFM_LAUNCH("eval_final_kernel", st, eval_final_kernel, dim3(1), dim3(256), 0, partial, (int)lblocks, u2, cneg + n,
-                     (long long)n, out);
+              keys_in, pos_in);
+  // the in-tree stable LSD radix sort (csrc/radix_sort.hip) over the 32 key bits, label as payload
+  rc = xdfm::sort_pairs_u32(keys_in, pos_in, n, 32, keys_out, pos_out, base + L.sort_ws, L.sort_ws_bytes, st);
+  if (rc) return rc;
+  const unsigned rblocks = blocks > (unsigned)kEvalBlocks ? (unsigned)kEvalBlocks : blocks;
+  XDFM_LAUNCH("eval_reduce_kernel", st, eval_reduce_kernel, dim3(rblocks), dim3(256), 0, keys_out, pos_out,
+              (long long)n, part_rank, part_pos, part_ll);
+  XDFM_LAUNCH("eval_final_kernel", st, eval_final_kernel, dim3(1), dim3(256), 0, part_rank, part_pos, part_ll,
+              (int)rblocks, (long long)n, out);
+  XDFM_LAUNCH_CHECK();
+  return XDFM_OK;
+}
+
+extern "C" int xdfm_loss_total(const float* loss2, float* out2, void* stream) {
+  XDFM_REQUIRE(loss2 && out2, "xdfm_loss_total: null argument");
+  XDFM_LAUNCH("loss_pair_kernel", stream, loss_pair_kernel, dim3(1), dim3(64), 0, loss2, out2);
   XDFM_LAUNCH_CHECK();
   return XDFM_OK;
 }

@@ -285,6 +285,44 @@ int plan_sort(const int64_t* ids, int64_t n, int64_t N, int32_t* sorted_ids, int
   return XDFM_OK;
 }
 
+// Generic form over 32-bit keys with a 32-bit payload each (the evaluation's order-preserving score keys with
+// the label as payload): `bits` low key bits are sorted on, in digits of at most 9 bits.  Same kernels, same
+// workspace layout (plan_sort_workspace_bytes(n)); keys_in / vals_in are left untouched.
+int sort_pairs_u32(const uint32_t* keys_in, const uint32_t* vals_in, int64_t n, int bits, uint32_t* keys_out,
+                   uint32_t* vals_out, void* ws, size_t ws_bytes, hipStream_t st) {
+  XDFM_REQUIRE(n > 0 && n < ((int64_t)1 << 31) && bits >= 1 && bits <= 32, "sort_pairs_u32: bad sizes");
+  XDFM_REQUIRE(keys_in && vals_in && keys_out && vals_out && ws, "sort_pairs_u32: null argument");
+  XDFM_REQUIRE(((uintptr_t)ws & 255) == 0, "sort_pairs_u32: workspace must be 256-byte aligned");
+  if (ws_bytes < plan_sort_workspace_bytes(n))
+    return fail(XDFM_E_WORKSPACE, "sort_pairs_u32: workspace %zu < %zu", ws_bytes, plan_sort_workspace_bytes(n));
+  const size_t seg = align_up((size_t)n * sizeof(uint32_t), 256);
+  char* base = static_cast<char*>(ws);
+  uint32_t* kbuf[2] = {(uint32_t*)base, (uint32_t*)(base + 2 * seg)};
+  uint32_t* vbuf[2] = {(uint32_t*)(base + seg), (uint32_t*)(base + 3 * seg)};
+  uint32_t* table = (uint32_t*)(base + 4 * seg);
+  const int npass = (bits + 8) / 9;
+  const int64_t tile = tile_of(n);
+  const int nt = (int)((n + tile - 1) / tile);
+  const uint32_t* src_k = keys_in;
+  const uint32_t* src_v = vals_in;
+  int shift = 0;
+  for (int p = 0; p < npass; ++p) {
+    const int pbits = bits / npass + (p < bits % npass ? 1 : 0);
+    const bool last = p == npass - 1;
+    uint32_t* dst_k = last ? keys_out : kbuf[p & 1];
+    uint32_t* dst_v = last ? vals_out : vbuf[p & 1];
+    XDFM_LAUNCH("sort_hist_kernel", st, sort_hist_kernel<false>, dim3(nt), dim3(kThreads), 0, (const void*)src_k, n,
+                (int64_t)0, shift, pbits, tile, table);
+    XDFM_LAUNCH("sort_scatter_kernel", st, sort_scatter_kernel<false>, dim3(nt), dim3(kThreads), 0, (const void*)src_k,
+                src_v, dst_k, dst_v, n, (int64_t)0, shift, pbits, tile, nt, table);
+    src_k = dst_k;
+    src_v = dst_v;
+    shift += pbits;
+  }
+  XDFM_LAUNCH_CHECK();
+  return XDFM_OK;
+}
+
 }  // namespace xdfm
 
 extern "C" int xdfm_embed_plan_workspace_bytes(int64_t nnz, int64_t N, size_t* bytes) {

@@ -25,4 +25,8 @@ constexpr size_t plan_sort_workspace_bytes(int64_t n) {
 int plan_sort(const int64_t* ids, int64_t n, int64_t N, int32_t* sorted_ids, int32_t* sorted_tok,
               void* ws, size_t ws_bytes, hipStream_t stream);
 
+// The same sort over 32-bit keys with a 32-bit payload each (`bits` low key bits, stable); same workspace.
+int sort_pairs_u32(const uint32_t* keys_in, const uint32_t* vals_in, int64_t n, int bits, uint32_t* keys_out,
+                   uint32_t* vals_out, void* ws, size_t ws_bytes, hipStream_t stream);
+
 }  // namespace xdfm

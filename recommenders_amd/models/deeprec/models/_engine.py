@@ -321,6 +321,17 @@ class XDeepFMEngine(object):
         self.overlap_dnn = self.overlap_dnn_wanted(hp) and not self.bf16
         if self.bf16:
             self.early_reg = False
+        # Fewer hardware queues than the step has parallel branches (main, id sort, DNN tower / late
+        # filter gradient): hipGraphLaunch of the branched capture died inside the runtime with
+        # GPU_MAX_HW_QUEUES=2 (round 2).  The step is then FOLDED onto one stream -- the same kernels
+        # (the DNN tower's input gradient meets the CIN's in d_emb in another order: last-bit
+        # differences, test_folded_step_...) -- and its capture is a plain chain that needs one queue.
+        self.folded = hw_queue_limit() is not None and hw_queue_limit() < 4
+        if self.folded:
+            self.overlap_dnn = False
+            self.early_reg = False
+            self.split_dw = False
+            self.serial_plan = True
         self.mean_count = 0  # set by the sharded engine: global batch size of the step
         self.init_parameters(seed)
 
@@ -1596,7 +1607,8 @@ class XDeepFMEngine(object):
         if not advanced:
             self._advance_step()
         self.update(batch, True)
-        tot = torch.cumsum(self._loss2, 0)  # one launch: [data, data + reg]
+        tot = torch.empty((2,), dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.xdfm_loss_total(_ptr(self._loss2), _ptr(tot), self._stream()))  # [data, data + reg]
         return tot[1], tot[0]
 
     def capture_step(self, labels, dnn_idx, ids, weights):
@@ -1633,13 +1645,18 @@ class PackedBatch(object):
         self.buf, self.ids_src = buf, ids_src
 
 
-def graph_replay_refusal():
-    """None, or why a captured step must not be replayed in this process: the step's graph has four
-    parallel branches, and with GPU_MAX_HW_QUEUES below HIP's default of 4 this ROCm's hipGraphLaunch
-    dies with a segmentation fault inside the runtime (seen with 2 on ROCm 7.0 / MI355X)."""
+def hw_queue_limit():
+    """Hardware queues this process's HIP runtime will use when that is below its default: the runtime
+    takes the number from GPU_MAX_HW_QUEUES (default 4) and offers no call to ask for it, so the
+    variable is the runtime's own answer.  None: the default."""
     q = os.environ.get("GPU_MAX_HW_QUEUES", "").strip()
-    if q.isdigit() and int(q) < 4:
-        return "GPU_MAX_HW_QUEUES=%s: replaying the captured step needs at least 4 hardware queues (HIP's default)" % q
+    return int(q) if q.isdigit() and int(q) >= 1 else None
+
+
+def graph_replay_refusal():
+    """None, or why a captured step must not be replayed in this process.  Nothing is refused any more:
+    with fewer hardware queues than the step has branches the engine folds the step onto one stream
+    (XDeepFMEngine.folded) and its capture is a chain.  Kept for callers of earlier versions."""
     return None
 
 

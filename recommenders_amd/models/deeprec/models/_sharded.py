@@ -25,8 +25,7 @@ import torch
 import torch.distributed as dist
 
 from recommenders_amd import _lib
-from recommenders_amd.models.deeprec.models._engine import (BN_EPS, BN_MOMENTUM, XDeepFMEngine, _ptr,
-                                                            graph_replay_refusal)
+from recommenders_amd.models.deeprec.models._engine import BN_EPS, BN_MOMENTUM, XDeepFMEngine, _ptr
 
 __all__ = ["RowShardExchange", "RoutePlan", "ShardedXDeepFMEngine", "owner_of", "local_rows"]
 
@@ -285,8 +284,6 @@ class ShardedXDeepFMEngine(XDeepFMEngine):
         # xDeepFM.py:234-240, :497-503): every normalisation has one all-reduce in the forward pass
         # (moments) and one in the backward pass (sums), see _bn_fwd / _bn_bwd
         if self.use_bn and self.exchange.collective:
-            self.graph_local = False
-        if graph_replay_refusal():  # fewer hardware queues than the local graph has branches
             self.graph_local = False
         self._local_graphs = {}
 

@@ -180,10 +180,6 @@ class BaseModel:
         after = self._graph_after
         if after <= 0 or type(eng).__name__ != "XDeepFMEngine" or eng.kernel_events is not None:
             return None
-        from recommenders_amd.models.deeprec.models._engine import graph_replay_refusal
-
-        if graph_replay_refusal():  # fewer hardware queues than the graph has branches: eager steps
-            return None
         key = (batch.B, batch.nnz)
         self._shape_run = self._shape_run + 1 if key == self._shape_last else 1
         self._shape_last = key

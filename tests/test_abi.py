@@ -63,13 +63,15 @@ def test_product_never_imports_the_oracle():
     assert not bad, bad
 
 
-def test_graph_replay_is_refused_with_fewer_hardware_queues_than_branches(monkeypatch):
-    """hipGraphLaunch of the four-branch step crashes inside the runtime with GPU_MAX_HW_QUEUES < 4: the
-    host side refuses to capture (GraphedStep raises; fit() and the sharded engine launch eagerly)."""
-    from recommenders_amd.models.deeprec.models._engine import graph_replay_refusal
+def test_fewer_hardware_queues_than_branches_are_read_from_the_runtimes_own_setting(monkeypatch):
+    """hipGraphLaunch of the branched step died inside the runtime with GPU_MAX_HW_QUEUES=2 (round 2): an engine
+    built in such a process folds its step onto one stream (XDeepFMEngine.folded), so that the capture is a
+    chain.  Host side of that decision (the folded replay itself runs in tests/test_gpu_model.py)."""
+    from recommenders_amd.models.deeprec.models._engine import graph_replay_refusal, hw_queue_limit
 
     monkeypatch.delenv("GPU_MAX_HW_QUEUES", raising=False)
-    assert graph_replay_refusal() is None
-    for q, refused in (("2", True), ("1", True), ("4", False), ("8", False), ("", False), ("junk", False)):
+    assert hw_queue_limit() is None and graph_replay_refusal() is None
+    for q, limit in (("2", 2), ("1", 1), ("4", 4), ("8", 8), ("", None), ("junk", None), ("0", None)):
         monkeypatch.setenv("GPU_MAX_HW_QUEUES", q)
-        assert (graph_replay_refusal() is not None) == refused, q
+        assert hw_queue_limit() == limit, q
+        assert graph_replay_refusal() is None

@@ -30,7 +30,7 @@ def notebook_hparams(**kw):
         cross_layer_sizes=[20, 10], activation=["relu", "relu"], dropout=[0.0, 0.0], loss="log_loss",
         method="classification", metrics=["auc", "logloss"], use_Linear_part=True, use_FM_part=False,
         use_CIN_part=True, use_DNN_part=True, init_method="tnormal", init_value=0.1, learning_rate=0.002,
-        optimizer="adam", embed_l2=0.01, layer_l2=0.01, cross_l2=0.01, batch_size=4096, epochs=2,
+        optimizer="adam", embed_l2=0.01, layer_l2=0.01, cross_l2=0.01, batch_size=4096, epochs=3,
         show_step=200000, save_model=False, save_epoch=2)
     cfg.update(kw)
     return prepare_hparams(None, **cfg)
@@ -39,8 +39,9 @@ def notebook_hparams(**kw):
 @pytest.fixture(scope="module")
 def files(tmp_path_factory):
     d = tmp_path_factory.mktemp("criteo_like")
-    # 30 000 rows: 24 000 train (6 steps of 4096 per epoch), 3 000 valid, 3 000 test
-    return write_criteo_like(str(d / "c"), rows=30000, feature_count=N, seed=42)
+    # configs[1]'s size: 100 000 rows = 80 000 train (20 steps of 4096 per epoch, 60 optimizer steps over the
+    # 3 epochs), 10 000 valid, 10 000 test (the 80/10/10 split of SURVEY.md 8(d) S2)
+    return write_criteo_like(str(d / "c"), rows=100000, feature_count=N, seed=42)
 
 
 def _oracle_fit(hp, params, train, valid, mode):
