@@ -503,7 +503,7 @@ __global__ void eval_keys_kernel(const float* __restrict__ preds, const float* _
                                  long long n, uint32_t* __restrict__ keys, uint32_t* __restrict__ pos) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  keys[i] = float_key(preds[i]);
+  keys[i] = float_key(preds[i] + 0.f);  // (-0.0 + 0.0 = +0.0: the two zeros are one score, a tie)
   pos[i] = labels[i] > 0.5f ? 1u : 0u;
 }
 
