@@ -239,6 +239,16 @@ int xdfm_embed_gather(const float* table, const float* lin_w, int64_t table_stri
  *     block_scratch   xdfm_route_scratch_ints(n) int32 of scratch
  * ---------------------------------------------------------------------- */
 int xdfm_route_keys(const int64_t* ids, int64_t n, int64_t N, int32_t G, int64_t* keys, void* stream);
+/* The request in fixed-capacity form (what lets every exchange of a step move G x cap records without
+ * sizes from the host): rows_padded[G*cap] = owner g's distinct rows in [g*cap, g*cap + count_g), pad_row
+ * in the rest of its slots (a scratch row the owner keeps past its real ones); slot_sorted_p / inverse_p =
+ * xdfm_route_uniq's slot numbers renumbered to owner*cap + position; counts[G+1] = distinct rows per owner
+ * and, in [G], their maximum (a batch whose maximum exceeds cap does not fit: its padded arrays must not be
+ * used).  At most 64 owners. */
+int xdfm_route_pad(const int32_t* first_slot, const int64_t* uniq_rows, const int32_t* slot_sorted,
+                   const int64_t* inverse, int64_t n, int32_t G, int64_t cap, int64_t pad_row,
+                   int64_t* rows_padded, int32_t* slot_sorted_p, int64_t* inverse_p, int32_t* counts,
+                   void* stream);
 int xdfm_route_scratch_ints(int64_t n, size_t* ints);
 int xdfm_route_uniq(const int32_t* sorted_keys, const int32_t* sorted_tok, int64_t n, int64_t N, int32_t G,
                     int32_t* slot_sorted, int64_t* inverse, int64_t* uniq_rows, int32_t* first_slot,
@@ -282,6 +292,10 @@ int xdfm_embed_plan_gather(const int32_t* sorted_tok, const int32_t* tok_row, co
  *   lin_w, lin_m, lin_v; grad_table / grad_lin are always dense)
  *   mode 1 (scatter)    : store the sums into grad_table[N,D] / grad_lin[N] (rows of untouched
  *                         ids are left as they are: the caller keeps them zero).
+ *   mode 2 (scatter from records): as mode 1 into DENSE grad_table[N,D] / grad_lin[N], but d_emb /
+ *                         g_logit are read at grad_stride like mode 0 does (the owner side of the
+ *                         row-sharded table under the reference's dense-exact update: the records that
+ *                         arrived are summed per row into the dense gradient image xdfm_dense_update reads).
  *   pieces: float scratch of 2*(nnz/64 + 1)*(D + 2) elements (partial sums of the segments that
  *   cross a 64-token chunk boundary).
  *   sorted_tok = NULL: tok_row and weights are already in sorted order (xdfm_embed_plan_gather).

@@ -480,7 +480,8 @@ struct BwdArgs {
   float *table, *slot_m, *slot_v, *lin_w, *lin_m, *lin_v, *grad_table, *grad_lin;
   int64_t N, B, nnz;
   int64_t TS, LS;  // row strides (floats) of table / slots and of lin_w / its slots
-  int64_t GS, GLS;  // strides of the gradient rows / scalars this call reads (mode 0) or writes (mode 1)
+  int64_t GS, GLS;  // strides of the gradient rows / scalars this call writes (modes 1, 2)
+  int64_t RS, RLS;  // strides of the d_emb rows / g_logit scalars it reads
   int D, F;
   const int32_t *sorted_ids, *sorted_tok, *tok_row;
   const float *weights, *d_emb, *d_emb2, *g_logit, *fm_sum;
@@ -631,7 +632,7 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(BwdArgs a) {
   const int row = a.tok_row[tok];
   const float w = pv ? a.weights[tok] : 0.f;
   float gw = 0.f;
-  if (need_g) gw = pv ? a.g_logit[(int64_t)(row / a.F) * (MODE == 0 ? a.GLS : 1)] * w : 0.f;
+  if (need_g) gw = pv ? a.g_logit[(int64_t)(row / a.F) * a.RLS] * w : 0.f;
   const int prev_key = (p0 > 0) ? a.sorted_ids[p0 - 1] : -1;
   const int next_key = (p0 + kChunk < a.nnz) ? a.sorted_ids[p0 + kChunk] : -2;
   const int first_key = __shfl(key, 0);
@@ -689,7 +690,7 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(BwdArgs a) {
     for (int k = 0; k < VEC; ++k) v[k] = 0.f;
     if (on) {
       float de[VEC];
-      const int64_t ds = MODE == 0 ? a.GS : (int64_t)a.D;  // mode 1 writes records, it reads dense rows
+      const int64_t ds = a.RS;
       load_vec<VEC>(a.d_emb + (int64_t)row_q * ds + c * VEC, de);
       if (a.d_emb2) {  // a second producer's gradient (the DNN tower's), summed on the fly
         float de2[VEC];
@@ -1076,7 +1077,7 @@ extern "C" int xdfm_embed_bwd(int32_t mode, float* table, float* slot_m, float* 
                               int32_t use_fm, const xdfm_opt_args* opt, float* pieces,
                               const float* d_emb2, int64_t grad_stride, const xdfm_row_age* age,
                               void* stream) {
-  XDFM_REQUIRE(mode == 0 || mode == 1, "xdfm_embed_bwd: mode must be 0 or 1");
+  XDFM_REQUIRE(mode >= 0 && mode <= 2, "xdfm_embed_bwd: mode must be 0, 1 or 2");
   XDFM_REQUIRE(N > 0 && D > 0 && F > 0 && B >= 0 && nnz >= 0, "xdfm_embed_bwd: bad sizes");
   if (nnz == 0) return XDFM_OK;
   XDFM_REQUIRE(sorted_ids && tok_row && weights && d_emb && pieces,
@@ -1135,8 +1136,11 @@ extern "C" int xdfm_embed_bwd(int32_t mode, float* table, float* slot_m, float* 
   a.TS = table_stride;
   a.LS = lin_stride;
   XDFM_REQUIRE(grad_stride == 0 || (grad_stride >= D && grad_stride % vec == 0), "xdfm_embed_bwd: bad grad_stride");
-  a.GS = grad_stride ? grad_stride : D;
-  a.GLS = grad_stride ? grad_stride : 1;
+  // mode 0 reads records; mode 1 reads dense rows and writes records; mode 2 reads records and writes dense
+  a.RS = (mode != 1 && grad_stride) ? grad_stride : D;
+  a.RLS = (mode != 1 && grad_stride) ? grad_stride : 1;
+  a.GS = (mode == 1 && grad_stride) ? grad_stride : D;
+  a.GLS = (mode == 1 && grad_stride) ? grad_stride : 1;
   int rc = make_age(mode == 0 ? age : nullptr, lin_w, lin_stride, false, &a.age);
   if (rc) return rc;
   a.age.packed_tail = (mode == 0 && tail_is_packed(a.age, lin_w, lin_m, lin_v, lin_stride)) ? 1 : 0;

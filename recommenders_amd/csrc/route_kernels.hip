@@ -108,7 +108,76 @@ __global__ __launch_bounds__(kUT) void route_write_kernel(const int32_t* __restr
   }
 }
 
+// Fixed-capacity form of a request: owner g's distinct rows in slots [g cap, g cap + count_g), the rest of
+// its cap slots naming pad_row (a scratch row the owner keeps past its real ones), so that every exchange
+// of the step moves G x cap records whatever the batch holds and needs no sizes.  Slots are renumbered
+// accordingly (slot' = owner cap + position inside the owner).  counts[g] = count_g, counts[G] = their
+// maximum: a batch whose maximum exceeds cap does not fit (nothing is written out of bounds for it, its
+// padded arrays are not to be used).
+__global__ __launch_bounds__(256) void route_pad_kernel(const int32_t* __restrict__ first_slot,
+                                                        const int64_t* __restrict__ uniq_rows,
+                                                        const int32_t* __restrict__ slot_sorted,
+                                                        const int64_t* __restrict__ inverse, int64_t n, int32_t G,
+                                                        int64_t cap, int64_t pad_row, int64_t* __restrict__ rows_padded,
+                                                        int32_t* __restrict__ slot_sorted_p,
+                                                        int64_t* __restrict__ inverse_p, int32_t* __restrict__ counts) {
+  __shared__ int start[65];
+  if (threadIdx.x == 0) {
+    // an owner without a row (-1) starts where the next one does; no token at all: everything 0
+    int nxt = first_slot[G] < 0 ? 0 : first_slot[G];
+    start[G] = nxt;
+    for (int g = G - 1; g >= 0; --g) {
+      const int f = first_slot[g];
+      if (f >= 0 && first_slot[G] >= 0) nxt = f;
+      start[g] = nxt;
+    }
+  }
+  __syncthreads();
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t == 0) {
+    int mx = 0;
+    for (int g = 0; g < G; ++g) {
+      const int c = start[g + 1] - start[g];
+      counts[g] = c;
+      mx = c > mx ? c : mx;
+    }
+    counts[G] = mx;
+  }
+  if (t < (int64_t)G * cap) {
+    const int g = (int)(t / cap);
+    const int64_t k = t - (int64_t)g * cap;
+    rows_padded[t] = k < start[g + 1] - start[g] ? uniq_rows[start[g] + k] : pad_row;
+  }
+  if (t < n) {
+    auto renumber = [&](int slot) -> int64_t {
+      int g = 0;
+      while (g + 1 < G && slot >= start[g + 1]) ++g;
+      const int64_t k = slot - start[g];
+      return k < cap ? (int64_t)g * cap + k : 0;  // (k >= cap: the batch does not fit, see above)
+    };
+    slot_sorted_p[t] = (int32_t)renumber(slot_sorted[t]);
+    inverse_p[t] = renumber((int)inverse[t]);
+  }
+}
+
 }  // namespace
+
+extern "C" int xdfm_route_pad(const int32_t* first_slot, const int64_t* uniq_rows, const int32_t* slot_sorted,
+                              const int64_t* inverse, int64_t n, int32_t G, int64_t cap, int64_t pad_row,
+                              int64_t* rows_padded, int32_t* slot_sorted_p, int64_t* inverse_p, int32_t* counts,
+                              void* stream) {
+  XDFM_REQUIRE(n >= 0 && G > 0 && G <= 64 && cap > 0 && (int64_t)G * cap < ((int64_t)1 << 31),
+               "xdfm_route_pad: bad sizes (at most 64 owners)");
+  XDFM_REQUIRE(first_slot && rows_padded && counts, "xdfm_route_pad: null argument");
+  XDFM_REQUIRE(n == 0 || (uniq_rows && slot_sorted && inverse && slot_sorted_p && inverse_p),
+               "xdfm_route_pad: null argument");
+  const int64_t threads = n > (int64_t)G * cap ? n : (int64_t)G * cap;
+  XDFM_LAUNCH("route_pad_kernel", stream, route_pad_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0,
+              first_slot, uniq_rows, slot_sorted, inverse, n, G, cap, pad_row, rows_padded, slot_sorted_p, inverse_p,
+              counts);
+  XDFM_LAUNCH_CHECK();
+  return XDFM_OK;
+}
 
 extern "C" int xdfm_route_keys(const int64_t* ids, int64_t n, int64_t N, int32_t G, int64_t* keys, void* stream) {
   XDFM_REQUIRE(n >= 0 && N > 0 && G > 0, "xdfm_route_keys: bad sizes");

@@ -19,6 +19,7 @@ GPUs.  ``ShardedXDeepFMEngine`` composes it with the kernels of libxdfm.so.
 """
 
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -52,7 +53,13 @@ class RoutePlan(object):
     owner_sorted_ids / owner_sorted_tok: the owner-side sort of recv_rows (engine)"""
 
     __slots__ = ("n_tok", "order", "slot_sorted", "inverse", "uniq_rows", "send_counts", "recv_counts",
-                 "recv_rows", "n_send", "n_recv", "owner_sorted_ids", "owner_sorted_tok", "gen")
+                 "recv_rows", "n_send", "n_recv", "owner_sorted_ids", "owner_sorted_tok", "gen",
+                 "fixed", "cap", "gmax", "fit_host", "fit_event")
+
+    def __init__(self):
+        # fixed: the request has G x cap slots whatever the batch holds (route_fixed): the exchanges
+        # need no sizes; send_counts / recv_counts are then None (equal splits)
+        self.fixed, self.cap, self.gmax, self.fit_host, self.fit_event = False, 0, None, None, None
 
 
 class _Bufs(object):
@@ -87,6 +94,9 @@ class RowShardExchange(object):
         self.collective = self.world > 1 or bool(force_collectives)
         self._bufs = {}
         self._calls = 0
+        # slots per owner of a fixed-capacity request (0: none chosen yet); the same on every rank
+        # (it is derived from counts every rank has seen: grow_capacity)
+        self.cap = 0
 
     def _a2a(self, out, x, out_splits=None, in_splits=None):
         if self.host_staged and x.is_cuda:
@@ -179,6 +189,112 @@ class RowShardExchange(object):
                                        _ptr(uniq_rows), _ptr(first), _ptr(scratch), st))
         return order[:n], slot_sorted[:n], inverse[:n], uniq_rows, first
 
+    @staticmethod
+    def capacity_for(gmax, factor=1.25):
+        """Slots per owner that hold a request of at most gmax distinct rows per owner with `factor` of
+        room, a multiple of 64."""
+        want = int(np.ceil(max(int(gmax), 1) * float(factor)))
+        return (want + 63) // 64 * 64
+
+    def grow_capacity(self, gmax, factor=1.25):
+        """Make room for gmax distinct rows per (source, owner) pair.  gmax must be a number every rank
+        holds (the maximum over all ranks), so that the ranks agree on the capacity."""
+        cap = self.capacity_for(gmax, factor)
+        if cap > self.cap:
+            self.cap = cap
+        return self.cap
+
+    def _pad(self, uniq_rows, slot_sorted, inverse, first, n, G, cap, pad_row):
+        """xdfm_route_pad (device) or its torch restatement (CPU tensors): the request in G x cap slots."""
+        dev = first.device
+        if first.is_cuda:
+            from recommenders_amd.models.deeprec.models._engine import _ptr
+
+            bufs = self._bufs.setdefault((dev, self._calls & 1), _Bufs(dev))
+            rows_p = bufs.get("rows_padded", G * cap, torch.int64)
+            ss_p = bufs.get("slot_sorted_p", max(n, 1), torch.int32)
+            inv_p = bufs.get("inverse_p", max(n, 1), torch.int64)
+            counts = bufs.get("counts", G + 1, torch.int32)
+            st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+            _lib.check(_lib.lib.xdfm_route_pad(_ptr(first), _ptr(uniq_rows), _ptr(slot_sorted), _ptr(inverse), n, G,
+                                               cap, int(pad_row), _ptr(rows_p), _ptr(ss_p), _ptr(inv_p), _ptr(counts),
+                                               st))
+            return rows_p, ss_p[:n], inv_p[:n], counts
+        f = first.tolist()
+        start = [0] * (G + 1)
+        nxt = 0 if f[G] < 0 else f[G]
+        start[G] = nxt
+        for g in range(G - 1, -1, -1):
+            if f[g] >= 0 and f[G] >= 0:
+                nxt = f[g]
+            start[g] = nxt
+        cnt = [start[g + 1] - start[g] for g in range(G)]
+        rows_p = torch.full((G * cap,), int(pad_row), dtype=torch.int64)
+        for g in range(G):
+            k = min(cnt[g], cap)
+            rows_p[g * cap:g * cap + k] = uniq_rows[start[g]:start[g] + k]
+        st_t = torch.tensor(start[:G], dtype=torch.int64)
+
+        def renumber(slot):
+            slot = slot.to(torch.int64)
+            g = torch.bucketize(slot, torch.tensor(start[1:G], dtype=torch.int64), right=True) if G > 1 else torch.zeros_like(slot)
+            k = slot - st_t[g]
+            return torch.where(k < cap, g * cap + k, torch.zeros_like(k))
+
+        counts = torch.tensor(cnt + [max(cnt) if cnt else 0], dtype=torch.int32)
+        return rows_p, renumber(slot_sorted).to(torch.int32), renumber(inverse), counts
+
+    def route_fixed(self, ids, n_rows, pad_row):
+        """route() without a host round trip: the tokens are partitioned and de-duplicated as there, but the
+        request to every owner has self.cap slots (the owner's scratch row pad_row in the unused ones), so
+        the ids travel -- and the rows and gradients will -- in equally sized messages and nothing of the
+        step waits for sizes.  Whether the batch FITS (at most cap distinct rows per owner on every rank) is
+        answered by fits(plan), from a small all-gather whose result travels to the host on its own: asked a
+        step later, it never waits.  A plan that does not fit must not be used (route() serves that batch)."""
+        G = self.world
+        if self.cap <= 0:
+            raise RuntimeError("route_fixed needs a capacity (grow_capacity)")
+        self._calls += 1
+        plan = RoutePlan()
+        n = int(ids.numel())
+        plan.n_tok = n
+        plan.fixed, plan.cap = True, self.cap
+        part = self._partition_device if ids.is_cuda else self._partition_host
+        plan.order, slot_sorted, inverse, uniq_rows, first = part(ids, int(n_rows), G)
+        rows_p, plan.slot_sorted, plan.inverse, counts = self._pad(uniq_rows, slot_sorted, inverse, first, n, G,
+                                                                   self.cap, pad_row)
+        plan.uniq_rows = rows_p
+        plan.n_send = plan.n_recv = G * self.cap
+        plan.send_counts = plan.recv_counts = None
+        mx = counts[G:G + 1]
+        if self.collective:
+            if self.host_staged or not mx.is_cuda:
+                h = mx.cpu()
+                allmx = torch.empty((self.world,), dtype=h.dtype)
+                dist.all_gather_into_tensor(allmx, h, group=self.group)
+            else:
+                allmx = torch.empty((self.world,), dtype=mx.dtype, device=mx.device)
+                dist.all_gather_into_tensor(allmx, mx, group=self.group)
+        else:
+            allmx = mx
+        if allmx.is_cuda:
+            plan.fit_host = torch.empty(allmx.shape, dtype=allmx.dtype, pin_memory=True)
+            plan.fit_host.copy_(allmx, non_blocking=True)
+            plan.fit_event = torch.cuda.Event()
+            plan.fit_event.record(torch.cuda.current_stream(allmx.device))
+        else:
+            plan.fit_host = allmx.clone()
+        plan.recv_rows = self.to_owner(plan, rows_p)
+        return plan
+
+    def fits(self, plan):
+        """Whether a fixed-capacity plan holds its batch on every rank (plan.gmax = the largest number of
+        distinct rows any rank asks of any owner)."""
+        if plan.fit_event is not None:
+            plan.fit_event.synchronize()
+        plan.gmax = int(plan.fit_host.max())
+        return plan.gmax <= plan.cap
+
     def route(self, ids, n_rows):
         """ids: int64 [n] global feature ids of this rank's tokens; n_rows: FEATURE_COUNT.  Sorts the
         tokens by (owner, row), de-duplicates, sends every distinct row to its owner (as a local
@@ -202,6 +318,7 @@ class RowShardExchange(object):
             return [starts[g + 1] - starts[g] for g in range(V)], starts
 
         mine, starts = counts_of(table[self.rank])
+        plan.gmax = max(max(counts_of(row)[0]) for row in table)  # the same number on every rank
         plan.n_send = starts[V]
         plan.uniq_rows = uniq_rows[:plan.n_send]
         if not self.collective:
@@ -230,7 +347,7 @@ class RowShardExchange(object):
             out.copy_(x)
             return out
         if out is None:
-            out = x.new_empty((plan.n_recv,) + tuple(x.shape[1:]))
+            out = self._exchange_buf("to_owner", x, plan.n_recv)
         self._a2a(out, x.contiguous(), plan.recv_counts, plan.send_counts)
         return out
 
@@ -243,9 +360,20 @@ class RowShardExchange(object):
             out.copy_(y)
             return out
         if out is None:
-            out = y.new_empty((plan.n_send,) + tuple(y.shape[1:]))
+            out = self._exchange_buf("to_source", y, plan.n_send)
         self._a2a(out, y.contiguous(), plan.send_counts, plan.recv_counts)
         return out
+
+    def _exchange_buf(self, name, like, rows):
+        """Grow-only receive buffer of a call that named none (two generations: the routing of the next
+        batch runs while this one's buffers are in use)."""
+        width = 1
+        for d in like.shape[1:]:
+            width *= int(d)
+        key = (like.device, "x", self._calls & 1)
+        bufs = self._bufs.setdefault(key, _Bufs(like.device))
+        flat = bufs.get("%s/%s/%d" % (name, like.dtype, width), max(rows * width, 1), like.dtype)
+        return flat[:rows * width].view((rows,) + tuple(like.shape[1:]))
 
 
 class ShardedXDeepFMEngine(XDeepFMEngine):
@@ -256,13 +384,23 @@ class ShardedXDeepFMEngine(XDeepFMEngine):
                  force_collectives=False, compute_dtype=None):
         self.exchange = RowShardExchange(group, virtual_world=virtual_world, force_collectives=force_collectives)
         self.world, self.rank = self.exchange.world, self.exchange.rank
-        if embedding_update == "dense_exact":
-            raise ValueError("the row-sharded engine updates rows at their owners: sparse_rows or sparse_lazy")
+        if embedding_update == "dense_exact" and hp.is_clip_norm:
+            raise ValueError("the row-sharded dense-exact update does not clip (clip_by_norm of the table needs the "
+                             "norm of the whole table's gradient)")
         self.global_rows = int(hp.FEATURE_COUNT)
         rows = local_rows(self.global_rows, self.rank, self.world)
+        # one scratch row past the real ones: the unused slots of a fixed-capacity request name it
+        self.n_local = max(rows, 1)
         XDeepFMEngine.__init__(self, hp, device=device, seed=None if seed is None else seed + 7919 * self.rank,
-                               embedding_update=embedding_update, table_rows=max(rows, 1),
+                               embedding_update=embedding_update, table_rows=self.n_local + 1,
                                compute_dtype=compute_dtype)
+        # requests of a fixed number of slots per owner: no sizes from the host, the step's exchanges move
+        # equally sized messages (XDFM_SHARD_FIXED=0: sized requests, one host synchronisation per step)
+        self.fixed = os.environ.get("XDFM_SHARD_FIXED", "1") != "0" and self.exchange.virtual_world == 1
+        self.cap_factor = float(os.environ.get("XDFM_SHARD_CAP_FACTOR", "1.25"))
+        self.fixed_steps = self.sized_steps = 0
+        # dense_exact: the regularisation loss of this rank's rows (summed over the ranks by the caller)
+        self.reg_table = torch.zeros((1,), dtype=torch.float32, device=self.device)
         if self.world > 1:
             self.exchange.broadcast(self.dense, 0)  # replicated parameters start identical
         self.dropout_seed ^= (0x632BE59BD9B4E019 * self.rank) & (2 ** 64 - 1)  # ranks draw different masks
@@ -287,6 +425,48 @@ class ShardedXDeepFMEngine(XDeepFMEngine):
             self.graph_local = False
         self._local_graphs = {}
 
+    # ------------------------------------------------------------------ scratch row
+    _ROW_KEYS = ("embedding", "lin_w", "slot/table_m", "slot/table_v", "slot/lin_m", "slot/lin_v")
+
+    def _clear_scratch_row(self):
+        """The scratch row (index n_local) holds zeros in every array: it takes zero gradients only, so it
+        stays zero under every optimizer and adds nothing to a regularisation loss."""
+        from recommenders_amd.models.deeprec.models._engine import _SLOT_M_INIT
+
+        r = self.n_local
+        for t in (self.table, self.lin_w, self.table_v, self.lin_v):
+            if t is not None:
+                t[r:].zero_()
+        for t in (self.table_m, self.lin_m):  # accumulators keep their starting value (Adagrad / FTRL 0.1, RMSProp 1)
+            if t is not None:
+                t[r:].fill_(_SLOT_M_INIT.get(self.opt_kind, 0.0))
+        if self.row_step is not None:
+            self.row_step[r:] = 0
+
+    def init_parameters(self, seed=None):
+        XDeepFMEngine.init_parameters(self, seed)
+        self._clear_scratch_row()
+
+    def load_state(self, sd, strict=True):
+        """load_state of this rank's rows: arrays of n_local rows get the scratch row appended."""
+        local = dict(sd)
+        for key in self._ROW_KEYS:
+            if key in local:
+                t = torch.as_tensor(np.asarray(local[key]) if not torch.is_tensor(local[key]) else local[key])
+                if t.shape[0] == self.n_local:
+                    t = torch.cat([t, torch.zeros((1,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)])
+                local[key] = t
+        XDeepFMEngine.load_state(self, local, strict=strict)
+        self._clear_scratch_row()
+
+    def state_dict(self):
+        """This rank's rows (without the scratch row) and the replicated parameters."""
+        sd = XDeepFMEngine.state_dict(self)
+        for key in self._ROW_KEYS:
+            if key in sd:
+                sd[key] = sd[key][:self.n_local]
+        return sd
+
     # ------------------------------------------------------------------ helpers
     def _arange32(self, n):
         t = self._consts.get("arange32")
@@ -306,9 +486,18 @@ class ShardedXDeepFMEngine(XDeepFMEngine):
         return self._owner_ws.get(name, max(int(numel), 1), dtype)
 
     # -------------------------------------------------------------------- step
-    def _prepare(self, batch):
-        """Route the batch's ids and sort, at this owner, the rows it is asked for (current stream)."""
-        plan = self.exchange.route(batch.ids, self.global_rows)
+    def _prepare(self, batch, sized=False):
+        """Route the batch's ids and sort, at this owner, the rows it is asked for (current stream).
+        With a capacity chosen the request has a fixed number of slots and nothing here waits for the
+        device; sized=True (or no capacity yet) sends exactly the distinct rows, which costs one host
+        synchronisation for the sizes."""
+        ex = self.exchange
+        if self.fixed and ex.cap > 0 and not sized:
+            plan = ex.route_fixed(batch.ids, self.global_rows, self.n_local)
+        else:
+            plan = ex.route(batch.ids, self.global_rows)
+            if self.fixed and plan.gmax is not None:
+                ex.grow_capacity(plan.gmax, self.cap_factor)  # room for the batches to come
         n = plan.n_recv
         # two generations alive at a time: this step's and the prefetched next one's
         gen = plan.gen = self.exchange._calls & 1
@@ -326,16 +515,32 @@ class ShardedXDeepFMEngine(XDeepFMEngine):
             self._done(ev)
         return plan
 
-    def fetch_rows(self, batch, static=None, train=True):
+    def resolve_plan(self, batch):
+        """The routing of `batch`: the one prefetched for it, or made now; a fixed-capacity request that
+        turns out not to hold the batch is replaced by a sized one."""
+        plan = self._take_prefetched_route(batch)
+        if plan is None:
+            plan = self._prepare(batch)
+        if plan.fixed and not self.exchange.fits(plan):
+            # more distinct rows for some owner than a request holds: this batch goes with sized
+            # requests, the ones to come get more room (every rank reads the same maximum: same decision)
+            self.exchange.grow_capacity(plan.gmax, self.cap_factor)
+            plan = self._prepare(batch, sized=True)
+        if plan.fixed:
+            self.fixed_steps += 1
+        else:
+            self.sized_steps += 1
+        return plan
+
+    def fetch_rows(self, batch, static=None, train=True, plan=None):
         """Route the batch's ids (unless that was prefetched), gather the requested rows at their owners (aged
         to the current step as they are read), bring them back.  Afterwards the batch reads its embeddings from the fetched rows
         (token j -> fetched row inverse[j]).  static: a _LocalGraph whose buffers receive the rows."""
         hp, lib, st = self.hp, self.lib, self._stream()
         D = self.D
         use_lin = bool(hp.use_Linear_part)
-        plan = self._take_prefetched_route(batch)
         if plan is None:
-            plan = self._prepare(batch)
+            plan = self.resolve_plan(batch)
         n_recv = plan.n_recv
         # [row | linear weight | pad] records: rows and weights come back in one all-to-all
         DP = D + 4 if use_lin else D
@@ -413,7 +618,7 @@ class ShardedXDeepFMEngine(XDeepFMEngine):
         _lib.check(
             lib.xdfm_embed_bwd(
                 1, _ptr(batch.src_table), None, None, None, None, None, batch.src_table.stride(0), 0, _ptr(send_c),
-                _ptr(send_c[:, D]) if use_lin else None, max(nnz, 1), D, self.F, batch.B,
+                _ptr(send_c[:, D]) if use_lin else None, max(int(send_c.shape[0]), 1), D, self.F, batch.B,
                 _ptr(seg_ids), _ptr(order32), _ptr(batch.tok_row), _ptr(batch.weights), nnz,
                 _ptr(ws["d_emb"]), _ptr(ws["g_logit"]) if (use_lin or use_fm) else None,
                 _ptr(ws["fm_sum"]) if use_fm else None, 1 if use_fm else 0, ctypes.byref(opt),
@@ -434,7 +639,9 @@ class ShardedXDeepFMEngine(XDeepFMEngine):
         DP = send_c.shape[1]
         recv_c = self.exchange.to_owner(plan, send_c[:plan.n_send],
                                         out=self._owner_buf("recv_c", n * DP).view(n, DP) if n else None)
-        if n:
+        if n and not self.sparse:
+            self._owner_update_dense(plan, recv_c, n)
+        elif n:
             pieces = self._owner_buf("pieces", 2 * (n // 64 + 1) * (D + 2))
             ev = self._mark("owner_update")
             _lib.check(
@@ -452,25 +659,78 @@ class ShardedXDeepFMEngine(XDeepFMEngine):
             if self.catchup_on:
                 self._rows_stale = True
 
+    def _owner_update_dense(self, plan, recv_c, n):
+        """The reference's dense update at the owner (dense_exact; SURVEY.md 8(e): regularisers and the
+        dense-exact optimizer are shard-local): the records that arrived are summed per row into this
+        rank's dense gradient image (xdfm_embed_bwd mode 2), then apply_gradients streams this rank's rows
+        with embed_l2 / embed_l1 (lin_w: layer_l2 / layer_l1) folded in, as base_model.py:121-149, :322 do
+        for the whole table; the regularisation loss of these rows goes to reg_table (the ranks' values add
+        up to the reference's term)."""
+        hp, lib, st = self.hp, self.lib, self._stream()
+        D = self.D
+        use_lin = bool(hp.use_Linear_part)
+        opt = self._opt_args()
+        pieces = self._owner_buf("pieces", 2 * (n // 64 + 1) * (D + 2))
+        ev = self._mark("owner_update")
+        _lib.check(
+            lib.xdfm_embed_bwd(
+                2, None, None, None, None, None, None, 0, 0, _ptr(self.grad_table),
+                _ptr(self.grad_lin) if use_lin else None, self.N, D, 1, n,
+                _ptr(plan.owner_sorted_ids), _ptr(plan.owner_sorted_tok), _ptr(self._arange32(n)),
+                _ptr(self._ones(n)), n, _ptr(recv_c), _ptr(recv_c[:, D]) if use_lin else None, None, 0,
+                ctypes.byref(opt), _ptr(pieces), None, recv_c.stride(0) if use_lin else 0, None, st,
+            )
+        )
+        one = np.asarray([0, self.N * D], dtype=np.int64)
+        _lib.check(
+            lib.xdfm_dense_update(
+                _ptr(self.table), _ptr(self.grad_table), _ptr(self.table_m), _ptr(self.table_v), 1,
+                one.ctypes.data_as(ctypes.c_void_p),
+                np.asarray([hp.embed_l2], dtype=np.float32).ctypes.data_as(ctypes.c_void_p),
+                np.asarray([hp.embed_l1], dtype=np.float32).ctypes.data_as(ctypes.c_void_p),
+                None, ctypes.byref(opt), _ptr(self.stats), _ptr(self.reg_table), 0, st,
+            )
+        )
+        if use_lin:
+            one = np.asarray([0, self.N], dtype=np.int64)
+            _lib.check(
+                lib.xdfm_dense_update(
+                    _ptr(self.lin_w), _ptr(self.grad_lin), _ptr(self.lin_m), _ptr(self.lin_v), 1,
+                    one.ctypes.data_as(ctypes.c_void_p),
+                    np.asarray([hp.layer_l2], dtype=np.float32).ctypes.data_as(ctypes.c_void_p),
+                    np.asarray([hp.layer_l1], dtype=np.float32).ctypes.data_as(ctypes.c_void_p),
+                    None, ctypes.byref(opt), _ptr(self.stats), _ptr(self.reg_table), 1, st,
+                )
+            )
+        _lib.check(lib.xdfm_embed_clear_rows(_ptr(self.grad_table), _ptr(self.grad_lin) if use_lin else None, D,
+                                             _ptr(plan.owner_sorted_ids), n, st))
+        self._done(ev)
+
     def _update_embedding(self, batch):
         nnz = batch.nnz
         plan = batch.route
         DP = self.D + 4 if self.hp.use_Linear_part else self.D
-        send_c = self._owner_buf("send_c", max(nnz, 1) * DP).view(max(nnz, 1), DP)
+        slots = max(plan.n_send if plan.fixed else nnz, 1)
+        send_c = self._owner_buf("send_c", slots * DP).view(slots, DP)
+        if plan.fixed:
+            send_c.zero_()
         self._token_grads(batch, plan.slot_sorted, plan.order, send_c)
         self._owner_update(batch, send_c)
         return True
 
     # ------------------------------------------------------ graph of the local part
-    def _local_graph(self, batch):
-        key = (batch.B, batch.nnz)
+    def _local_graph(self, batch, plan):
+        # rows arrive one per slot: as many as the batch has distinct rows at most (sized requests) or the
+        # request's fixed number
+        slots = plan.n_send if plan.fixed else batch.nnz
+        key = (batch.B, batch.nnz, slots, bool(plan.fixed))
         g = self._local_graphs.get(key)
         if g is not None and g.ws_token != self._ws_token:
             # the workspace was re-allocated (a larger batch came through): its addresses are stale
             self._local_graphs.clear()
             g = None
-        if g is None and len(self._local_graphs) < 4:
-            g = _LocalGraph(self, batch)
+        if g is None and len(self._local_graphs) < 6:
+            g = _LocalGraph(self, batch, slots, bool(plan.fixed))
             self._local_graphs[key] = g
         return g
 
@@ -485,10 +745,11 @@ class ShardedXDeepFMEngine(XDeepFMEngine):
         self._ensure_ws(batch.B, batch.nnz)
         g = None
         rmse = None
+        plan = self.resolve_plan(batch)
         if self.graph_local and self.kernel_events is None and batch.nnz > 0:
-            g = self._local_graph(batch)  # None: too many shapes seen, stay eager
+            g = self._local_graph(batch, plan)  # None: too many shapes seen, stay eager
         if g is not None:
-            self.fetch_rows(batch, static=g)
+            self.fetch_rows(batch, static=g, plan=plan)
             g.load(batch)
             if g.graph is None:
                 try:
@@ -507,14 +768,14 @@ class ShardedXDeepFMEngine(XDeepFMEngine):
             else:
                 # the fetched rows already sit in g's buffers: finish this step without the graph
                 batch.src_table, batch.src_lin, batch.src_ids = g.src_table, g.src_lin, g.src_ids
-                batch.src_N = max(batch.nnz, 1)
+                batch.src_N = max(g.slots, 1)
                 self.forward(batch, with_loss=True, with_grad=True)
                 rmse = self._square_loss_global(batch)
                 self.backward(batch)
                 self._advance_step()
                 self._update_embedding(batch)
         else:
-            self.fetch_rows(batch)
+            self.fetch_rows(batch, plan=plan)
             self.forward(batch, with_loss=True, with_grad=True)
             rmse = self._square_loss_global(batch)
             self.backward(batch)
@@ -537,6 +798,8 @@ class ShardedXDeepFMEngine(XDeepFMEngine):
         if self._square and self.exchange.collective and rmse is not None:
             self.data_loss.copy_(rmse / self.world)  # shares that add up to the global root mean square
         reg = self.reg_loss if self.rank == 0 else torch.zeros_like(self.reg_loss)
+        if not self.sparse:
+            reg = reg + self.reg_table  # every rank's rows carry their share of the table's terms
         return (self.data_loss + reg)[0], self.data_loss[0].clone()
 
     def _bn_fwd(self, x, y, where, k, B, C, inner, act):
@@ -634,7 +897,8 @@ class ShardedXDeepFMEngine(XDeepFMEngine):
         lin = torch.zeros((n,), dtype=torch.float32, device=self.device) if self.lin_w is not None else None
         for r in range(G):
             rows = local_rows(n, r, G)
-            buf = self.table[:rows].clone() if r == self.rank else torch.empty((rows, self.D), device=self.device)
+            buf = (self.table[:rows].contiguous().clone() if r == self.rank
+                   else torch.empty((rows, self.D), device=self.device))
             if G > 1:
                 self.exchange.broadcast(buf, r)
             full[r::G] = buf
@@ -650,14 +914,19 @@ class _LocalGraph(object):
     """forward + backward + per-token gradients of one rank for batches of one shape, captured
     as a HIP graph over static buffers (the rows fetched from the owners land in src_table)."""
 
-    def __init__(self, eng, batch):
+    def __init__(self, eng, batch, slots=None, fixed=False):
+        """slots: rows fetched from the owners = gradient records sent back (the batch's token count bounds
+        them under sized requests; a fixed-capacity request has world x cap, used or not: the unused
+        records must leave as zeros, so send_c is cleared inside the graph)."""
         from recommenders_amd.models.deeprec.models._engine import DeviceBatch
 
         dev, nnz, B, D = eng.device, batch.nnz, batch.B, eng.D
         use_lin = bool(eng.hp.use_Linear_part)
         f32 = torch.float32
         self.eng = eng
-        self.src_comb = torch.zeros((nnz, D + 4 if use_lin else D), dtype=f32, device=dev)
+        self.slots = slots = int(slots) if slots is not None else nnz
+        self.fixed = bool(fixed)
+        self.src_comb = torch.zeros((slots, D + 4 if use_lin else D), dtype=f32, device=dev)
         self.src_table = self.src_comb[:, :D]
         self.src_lin = self.src_comb[:, D] if use_lin else None
         self.src_ids = torch.zeros((nnz,), dtype=torch.int64, device=dev)
@@ -666,7 +935,7 @@ class _LocalGraph(object):
         # launch keeps the address it was recorded with)
         self.seg_ids = torch.zeros((nnz,), dtype=torch.int32, device=dev)
         self.ws_token = eng._ws_token
-        self.send_c = torch.zeros((nnz, D + 4 if use_lin else D), dtype=f32, device=dev)
+        self.send_c = torch.zeros((slots, D + 4 if use_lin else D), dtype=f32, device=dev)
         sb = DeviceBatch()
         sb.B, sb.nnz = B, nnz
         sb.labels = torch.zeros_like(batch.labels)
@@ -674,7 +943,7 @@ class _LocalGraph(object):
         sb.row_ptr = torch.zeros_like(batch.row_ptr)
         sb.tok_row = torch.zeros_like(batch.tok_row)
         sb.ids = None  # never read: the embeddings come from src_table
-        sb.src_table, sb.src_lin, sb.src_ids, sb.src_N = self.src_table, self.src_lin, self.src_ids, max(nnz, 1)
+        sb.src_table, sb.src_lin, sb.src_ids, sb.src_N = self.src_table, self.src_lin, self.src_ids, max(slots, 1)
         sb.sorted_ids = sb.sorted_tok = None
         sb.planned = True
         sb.plan_event = None
@@ -704,6 +973,8 @@ class _LocalGraph(object):
 
     def _run(self):
         eng = self.eng
+        if self.fixed:
+            self.send_c.zero_()  # the request's unused slots send zero gradients (to the owners' scratch rows)
         eng.forward(self.batch, with_loss=True, with_grad=True)
         eng.backward(self.batch)
         eng._token_grads(self.batch, self.seg_ids, self.order32, self.send_c)

@@ -28,7 +28,7 @@ def test_sharded_step_equals_plain_engine_and_oracle(optimizer, virtual_world):
     p32 = X.init_params(hp, seed=9)
     plain = XDeepFMEngine(hp, embedding_update="sparse_rows")
     shard = ShardedXDeepFMEngine(hp, virtual_world=virtual_world)
-    assert shard.world == 1 and shard.N == 300
+    assert shard.world == 1 and shard.n_local == 300 and shard.N == 301  # one scratch row past the real ones
     plain.load_state({k: v.clone() for k, v in p32.items()})
     shard.load_global_state({k: v.clone() for k, v in p32.items()})
     p64 = {k: v.double() for k, v in p32.items()}
@@ -39,6 +39,12 @@ def test_sharded_step_equals_plain_engine_and_oracle(optimizer, virtual_world):
         l0, d0 = plain.train_step(_upload(plain, b))
         # steps 0-2 announce their successor (routing one step ahead), 3 does not, 4 does
         nxt = dev[step + 1] if (step + 1 < len(dev) and step != 3) else None
+        if step == 2 and virtual_world == 1:
+            # a request too small for the batch that was routed ahead with it: found out (without a wait:
+            # the answer travelled to the host a step ago), the batch goes with sized requests instead and
+            # the capacity grows
+            assert shard._route_pre is not None and shard._route_pre[1].fixed
+            shard._route_pre[1].cap = 1
         l1, d1 = shard.train_step(dev[step], next_batch=nxt)
         # the reference's semantics: every row moves every step (rows are caught up at their owner)
         o_loss, o_dl, _, _ = X.train_step(p64, st, b, hp, mode="dense_exact")
@@ -48,6 +54,12 @@ def test_sharded_step_equals_plain_engine_and_oracle(optimizer, virtual_world):
         assert float(d0) == float(d1)
     torch.cuda.synchronize()
     shard.check_errors()
+    if virtual_world == 1:
+        # the first batch finds the capacity (sized), the forced miss is the other sized step; the rest moved
+        # fixed-size requests and never asked the host for sizes
+        assert (shard.sized_steps, shard.fixed_steps) == (2, 4) and shard.exchange.cap >= 64
+    else:
+        assert shard.fixed_steps == 0  # (virtual owners are a sized-request test vehicle)
     table, lin = shard.gather_global_table()
     tol = 2e-4 if optimizer == "adam" else 2e-5
     for got, name in ((table, "embedding"), (lin.view(-1, 1), "lin_w")):
@@ -58,6 +70,8 @@ def test_sharded_step_equals_plain_engine_and_oracle(optimizer, virtual_world):
         exp = p64[k].numpy().reshape(shard.dense_shapes[k])
         err = np.abs(shard.views[k].cpu().numpy() - exp).max()
         assert err <= tol * max(np.abs(exp).max(), 1e-30), (k, err)
+    # the scratch row took zero gradients only
+    assert not shard.table[shard.n_local:].any()
     # plain engine took the same steps
     assert np.abs(plain.state_dict()["embedding"].cpu().numpy() - table.cpu().numpy()).max() <= 1e-6
 
@@ -107,6 +121,20 @@ def test_device_partition_equals_its_torch_restatement():
         for h, d, name in zip(host[:3], devp[:3], ("order", "slot_sorted", "inverse")):
             assert torch.equal(h, d.cpu()), (name, n, n_rows, G)
         assert torch.equal(host[3], devp[3][:n_uniq].cpu())
+        # the request in fixed-capacity form: kernel against its torch restatement, for a capacity that
+        # holds the batch and (values of the slots that exist) for one that does not
+        counts_ref = None
+        nt = int(ids.numel())
+        for cap in (max(64, nt), 3):
+            hp_ = ex._pad(host[3], host[1], host[2], host[4], nt, G, cap, 12345)
+            dp_ = ex._pad(devp[3], devp[1], devp[2], devp[4], nt, G, cap, 12345)
+            torch.cuda.synchronize()
+            assert torch.equal(hp_[3], dp_[3].cpu()), (n, G, cap)
+            counts_ref = hp_[3]
+            if int(hp_[3][G]) <= cap:
+                for h, d, name in zip(hp_[:3], dp_[:3], ("rows_padded", "slot_sorted_p", "inverse_p")):
+                    assert torch.equal(h, d.cpu()), (name, n, n_rows, G, cap)
+        assert int(counts_ref[:G].sum()) == n_uniq
 
 
 def _free_port():
@@ -134,7 +162,13 @@ def _two_rank_worker(rank, world, port, optimizer, loss, out):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         bn = loss == "batch_norm"
-        if bn:
+        dense = loss == "dense_exact"
+        if dense:
+            # the notebook's kind of configuration (xdeepfm_criteo.ipynb:142-163: all three l2 = 0.01) plus the
+            # l1 terms: the table's regularisers and the dense-exact optimizer are shard-local
+            hp = make_hp(optimizer=optimizer, learning_rate=0.01, FEATURE_COUNT=301, cross_l2=0.01, cross_l1=0.001,
+                         embed_l2=0.01, layer_l2=0.01, embed_l1=0.001, layer_l1=0.001)
+        elif bn:
             # cross_entropy_loss: see test_batch_norm_training_matches_oracle (logits of +-10 under log_loss)
             hp = make_hp(optimizer=optimizer, learning_rate=0.01, FEATURE_COUNT=301, cross_l2=0.01,
                          loss="cross_entropy_loss", enable_BN=True)
@@ -143,8 +177,9 @@ def _two_rank_worker(rank, world, port, optimizer, loss, out):
                          loss=loss)
         F, N = hp.FIELD_COUNT, hp.FEATURE_COUNT
         p32 = X.init_params(hp, seed=9)
-        eng = ShardedXDeepFMEngine(hp, seed=7)
-        assert eng.world == world and eng.exchange.host_staged and eng.catchup_on == (optimizer == "adam")
+        eng = ShardedXDeepFMEngine(hp, seed=7, embedding_update="dense_exact" if dense else "sparse_rows")
+        assert eng.world == world and eng.exchange.host_staged
+        assert eng.catchup_on == (optimizer == "adam" and not dense)
         eng.load_global_state({k: v.clone() for k, v in p32.items()})
         p64 = {k: v.double() for k, v in p32.items()}
         st = X.new_opt_state(p64, hp)
@@ -169,6 +204,8 @@ def _two_rank_worker(rank, world, port, optimizer, loss, out):
             assert abs(float(tot[0]) - o_loss) <= 2e-5 * abs(o_loss), (step, float(tot[0]), o_loss)
         torch.cuda.synchronize()
         eng.check_errors()
+        # the first batch found the capacity with sized requests, every later one moved fixed-size messages
+        assert (eng.sized_steps, eng.fixed_steps) == (1, len(steps) - 1)
         table, lin = eng.gather_global_table()
         tol = 2e-4 if optimizer == "adam" else 2e-5
         for got, name in ((table, "embedding"), (lin.view(-1, 1), "lin_w")):
@@ -198,11 +235,12 @@ def _two_rank_worker(rank, world, port, optimizer, loss, out):
 
 
 @pytest.mark.parametrize("optimizer,loss", [("adam", "log_loss"), ("adagrad", "log_loss"), ("adam", "square_loss"),
-                                            ("adam", "batch_norm")])
+                                            ("adam", "batch_norm"), ("adam", "dense_exact")])
 def test_two_ranks_sharing_the_gpu_match_the_oracle_on_the_global_batch(optimizer, loss):
     """world_size 2, one process per rank: ids to their owners, rows back, gradient rows to the
     owners, owner-side update, dense all-reduce -- against the oracle stepping on the
-    concatenated batch.  square_loss (a root of a mean over the GLOBAL batch) adds one scalar all-reduce
+    concatenated batch.  "dense_exact" = embedding_update="dense_exact" with embed / layer / cross l1 and l2 all on
+    (the owners stream their rows with the regularisers folded in, the ranks' loss shares add up).  square_loss (a root of a mean over the GLOBAL batch) adds one scalar all-reduce
     between the forward and the backward pass; "batch_norm" = enable_BN, whose statistics are those of the global
     batch: one all-reduce per normalisation and pass.  (RCCL needs one GPU per rank; the driver's scaling bench is that run.)"""
     import torch.multiprocessing as mp
@@ -245,11 +283,14 @@ def _rccl_worker(port, bn, out):
         batches = [random_batch(rng, hp, 64) for _ in range(4)]
         dev = [_upload(eng, b) for b in batches]
         for k, b in enumerate(batches):
+            if k == 2 and not bn:
+                eng._route_pre[1].cap = 1  # one forced miss: that batch goes with sized requests over RCCL
             loss, dloss = eng.train_step(dev[k], next_batch=dev[k + 1] if k + 1 < len(dev) else None)
             o_loss, o_dl, _, _ = X.train_step(p64, st, b, hp, mode="dense_exact")
             assert abs(float(dloss) - o_dl) <= 2e-5 * abs(o_dl), (k, float(dloss), o_dl)
         torch.cuda.synchronize()
         eng.check_errors()
+        assert (eng.sized_steps, eng.fixed_steps) == ((1, 3) if bn else (2, 2))
         table, _ = eng.gather_global_table()
         err = np.abs(table.cpu().numpy() - p64["embedding"].numpy()).max()
         assert err <= (5e-4 if bn else 2e-4) * np.abs(p64["embedding"].numpy()).max(), err

@@ -74,6 +74,31 @@ def _worker(rank, world, port, n_rows, dim, out):
         # arrival order = (source rank, source token order): reproducible
         counts = plan.recv_counts
         assert sum(counts) == plan.n_recv and len(counts) == world
+        # ---- the same exchange with requests of a fixed number of slots per owner: no sizes travel, the
+        # unused slots name the owner's scratch row (kept past its real rows) and carry zero gradients
+        gmax = plan.gmax
+        assert gmax == max(max(np.bincount((np.unique(i.numpy()) % world), minlength=world)) for i in all_ids)
+        cap = ex.grow_capacity(gmax)
+        assert cap % 64 == 0 and cap >= gmax * 1.25
+        pad_row = (n_rows + world - 1) // world        # one index every rank may use as its scratch row
+        fp = ex.route_fixed(ids, n_rows, pad_row)
+        assert ex.fits(fp) and fp.gmax == gmax and fp.fixed and fp.n_send == fp.n_recv == world * cap
+        shard_p = torch.zeros(pad_row + 1, dim)
+        shard_p[:shard.shape[0]] = shard
+        assert int(fp.recv_rows.max()) <= pad_row
+        rows_back = ex.to_source(fp, shard_p[fp.recv_rows])
+        assert torch.equal(rows_back[fp.inverse], table[ids])
+        assert torch.equal(fp.inverse[fp.order.long()], fp.slot_sorted.long())
+        pre = torch.zeros(fp.n_send, dim, dtype=torch.float64).index_add_(0, fp.inverse, grads)
+        recv_g = ex.to_owner(fp, pre)
+        acc = torch.zeros(pad_row + 1, dim, dtype=torch.float64)
+        acc.index_add_(0, fp.recv_rows, recv_g)
+        assert torch.allclose(acc[:shard.shape[0]], ref[rank::world], rtol=1e-12, atol=1e-12)
+        assert not acc[pad_row].any()                  # the scratch row got zeros only
+        # a request too small for the batch says so on every rank (the caller then routes with sizes)
+        ex.cap = 8
+        small = ex.route_fixed(ids, n_rows, pad_row)
+        assert not ex.fits(small) and small.gmax == gmax
         out.put((rank, "ok"))
     except Exception as e:  # noqa: BLE001
         out.put((rank, repr(e)))
