@@ -28,7 +28,7 @@ def test_sharded_step_equals_plain_engine_and_oracle(optimizer, virtual_world):
     p32 = X.init_params(hp, seed=9)
     plain = XDeepFMEngine(hp, embedding_update="sparse_rows")
     shard = ShardedXDeepFMEngine(hp, virtual_world=virtual_world)
-    assert shard.world == 1 and shard.n_local == 300 and shard.N == 301  # one scratch row past the real ones
+    assert shard.world == 1 and shard.n_local == 300 and shard.pad_row == 300 and shard.N == 301  # + scratch row
     plain.load_state({k: v.clone() for k, v in p32.items()})
     shard.load_global_state({k: v.clone() for k, v in p32.items()})
     p64 = {k: v.double() for k, v in p32.items()}
