@@ -310,18 +310,24 @@ def main():
     nnz = int(resident[0][2].numel())
     uniq = float(np.mean([len(np.unique(hb["dnn_feat_values"])) for hb in host_batches]))
 
-    pending = {}
+    made = {}
+
+    def device_batch(k):
+        # the resident batch as the engine's DeviceBatch (CSR offsets built once, like the packed batches of
+        # the captured step)
+        k %= n_batches
+        if k not in made:
+            made[k] = eng.make_batch(*resident[k])
+        return made[k]
 
     def eager_step(i):
-        labels, idx, ids, w = resident[i % n_batches]
-        batch = pending.pop(i, None)
-        if batch is None:
-            batch = eng.make_batch(labels, idx, ids, w)  # CSR offsets built on the device
         if world > 1 or args.sharded:
-            # the following batch is announced: its routing to the owners (ids out, exchange sizes,
-            # owner-side sort) runs beside this step
-            pending[i + 1] = eng.make_batch(*resident[(i + 1) % n_batches])
-        return eng.train_step(batch, next_batch=pending.get(i + 1))
+            # the following batch is announced: its routing to the owners (ids out, owner-side sort) runs
+            # beside this step
+            return eng.train_step(device_batch(i), next_batch=device_batch(i + 1))
+        b = device_batch(i)
+        b.planned = b.planned_gather = False  # every step sorts its ids, as the captured step does
+        return eng.train_step(b)
 
     graphed = None
     if getattr(eng, "folded", False):

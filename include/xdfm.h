@@ -239,16 +239,21 @@ int xdfm_embed_gather(const float* table, const float* lin_w, int64_t table_stri
  *     block_scratch   xdfm_route_scratch_ints(n) int32 of scratch
  * ---------------------------------------------------------------------- */
 int xdfm_route_keys(const int64_t* ids, int64_t n, int64_t N, int32_t G, int64_t* keys, void* stream);
-/* The request in fixed-capacity form (what lets every exchange of a step move G x cap records without
- * sizes from the host): rows_padded[G*cap] = owner g's distinct rows in [g*cap, g*cap + count_g), pad_row
- * in the rest of its slots (a scratch row the owner keeps past its real ones); slot_sorted_p / inverse_p =
- * xdfm_route_uniq's slot numbers renumbered to owner*cap + position; counts[G+1] = distinct rows per owner
- * and, in [G], their maximum (a batch whose maximum exceeds cap does not fit: its padded arrays must not be
- * used).  At most 64 owners. */
+/* The request in fixed-capacity form (what lets every exchange of a step move equally sized messages without
+ * sizes from the host).  S = cap + 1 slots per owner: rows_padded[G*S] = owner g's distinct rows in
+ * [g*S, g*S + count_g), pad_row (a scratch row the owner keeps past its real ones) in its unused slots, and
+ * in the block's last slot a header: pad_row in the low 32 bits, this rank's largest per-owner count in the
+ * high ones -- the message that carries the rows also tells every owner whether this source's batch fits.
+ * slot_sorted_p / inverse_p = xdfm_route_uniq's slot numbers renumbered to owner*S + position; counts[G+1] =
+ * distinct rows per owner and, in [G], their maximum (a batch whose maximum exceeds cap does not fit: its
+ * padded arrays must not be used).  At most 64 owners.
+ * xdfm_route_decode (owner side): the G blocks that arrived -> rows[G*S] plain row indices (headers -> the
+ * scratch row) and src_max[G] every source's largest count. */
 int xdfm_route_pad(const int32_t* first_slot, const int64_t* uniq_rows, const int32_t* slot_sorted,
                    const int64_t* inverse, int64_t n, int32_t G, int64_t cap, int64_t pad_row,
                    int64_t* rows_padded, int32_t* slot_sorted_p, int64_t* inverse_p, int32_t* counts,
                    void* stream);
+int xdfm_route_decode(const int64_t* raw, int32_t G, int64_t cap, int64_t* rows, int32_t* src_max, void* stream);
 int xdfm_route_scratch_ints(int64_t n, size_t* ints);
 int xdfm_route_uniq(const int32_t* sorted_keys, const int32_t* sorted_tok, int64_t n, int64_t N, int32_t G,
                     int32_t* slot_sorted, int64_t* inverse, int64_t* uniq_rows, int32_t* first_slot,

@@ -118,6 +118,7 @@ SIGNATURES = {
     "xdfm_embed_gather": [_P, _P, _I64, _I64, _I64, _I32, _P, _I64, _P, _P, _I64, _P, ctypes.POINTER(RowAge), _P],
     "xdfm_route_keys": [_P, _I64, _I64, _I32, _P, _P],
     "xdfm_route_pad": [_P, _P, _P, _P, _I64, _I32, _I64, _I64, _P, _P, _P, _P, _P],
+    "xdfm_route_decode": [_P, _I32, _I64, _P, _P, _P],
     "xdfm_route_scratch_ints": [_I64, _PSZ],
     "xdfm_route_uniq": [_P, _P, _I64, _I64, _I32, _P, _P, _P, _P, _P, _P],
     "xdfm_embed_plan_workspace_bytes": [_I64, _I64, _PSZ],

@@ -108,12 +108,14 @@ __global__ __launch_bounds__(kUT) void route_write_kernel(const int32_t* __restr
   }
 }
 
-// Fixed-capacity form of a request: owner g's distinct rows in slots [g cap, g cap + count_g), the rest of
-// its cap slots naming pad_row (a scratch row the owner keeps past its real ones), so that every exchange
-// of the step moves G x cap records whatever the batch holds and needs no sizes.  Slots are renumbered
-// accordingly (slot' = owner cap + position inside the owner).  counts[g] = count_g, counts[G] = their
-// maximum: a batch whose maximum exceeds cap does not fit (nothing is written out of bounds for it, its
-// padded arrays are not to be used).
+// Fixed-capacity form of a request: owner g's distinct rows in slots [g S, g S + count_g) of its block of
+// S = cap + 1 slots, pad_row (a scratch row the owner keeps past its real ones) in the unused ones, so that every
+// exchange of the step moves G x S records whatever the batch holds and needs no sizes.  Slots are renumbered
+// accordingly (slot' = owner S + position inside the owner).  The last slot of every block is a header: the low
+// 32 bits name pad_row like an unused slot, the high 32 bits carry this rank's LARGEST per-owner count, so the
+// message that takes the rows to their owners also tells every owner whether this source's batch fits its
+// capacity (xdfm_route_decode).  counts[g] = count_g, counts[G] = their maximum: a batch whose maximum exceeds cap
+// does not fit (nothing is written out of bounds for it, its padded arrays are not to be used).
 __global__ __launch_bounds__(256) void route_pad_kernel(const int32_t* __restrict__ first_slot,
                                                         const int64_t* __restrict__ uniq_rows,
                                                         const int32_t* __restrict__ slot_sorted,
@@ -122,6 +124,7 @@ __global__ __launch_bounds__(256) void route_pad_kernel(const int32_t* __restric
                                                         int32_t* __restrict__ slot_sorted_p,
                                                         int64_t* __restrict__ inverse_p, int32_t* __restrict__ counts) {
   __shared__ int start[65];
+  __shared__ int mx_s;
   if (threadIdx.x == 0) {
     // an owner without a row (-1) starts where the next one does; no token at all: everything 0
     int nxt = first_slot[G] < 0 ? 0 : first_slot[G];
@@ -131,33 +134,52 @@ __global__ __launch_bounds__(256) void route_pad_kernel(const int32_t* __restric
       if (f >= 0 && first_slot[G] >= 0) nxt = f;
       start[g] = nxt;
     }
-  }
-  __syncthreads();
-  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t == 0) {
     int mx = 0;
     for (int g = 0; g < G; ++g) {
       const int c = start[g + 1] - start[g];
-      counts[g] = c;
       mx = c > mx ? c : mx;
     }
-    counts[G] = mx;
+    mx_s = mx;
   }
-  if (t < (int64_t)G * cap) {
-    const int g = (int)(t / cap);
-    const int64_t k = t - (int64_t)g * cap;
-    rows_padded[t] = k < start[g + 1] - start[g] ? uniq_rows[start[g] + k] : pad_row;
+  __syncthreads();
+  const int64_t S = cap + 1;
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t == 0) {
+    for (int g = 0; g < G; ++g) counts[g] = start[g + 1] - start[g];
+    counts[G] = mx_s;
+  }
+  if (t < (int64_t)G * S) {
+    const int g = (int)(t / S);
+    const int64_t k = t - (int64_t)g * S;
+    int64_t v = pad_row;
+    if (k == cap)
+      v = pad_row | ((int64_t)mx_s << 32);
+    else if (k < start[g + 1] - start[g])
+      v = uniq_rows[start[g] + k];
+    rows_padded[t] = v;
   }
   if (t < n) {
     auto renumber = [&](int slot) -> int64_t {
       int g = 0;
       while (g + 1 < G && slot >= start[g + 1]) ++g;
       const int64_t k = slot - start[g];
-      return k < cap ? (int64_t)g * cap + k : 0;  // (k >= cap: the batch does not fit, see above)
+      return k < cap ? (int64_t)g * S + k : 0;  // (k >= cap: the batch does not fit, see above)
     };
     slot_sorted_p[t] = (int32_t)renumber(slot_sorted[t]);
     inverse_p[t] = renumber((int)inverse[t]);
   }
+}
+
+// owner side: the G blocks that arrived -> plain row indices (headers become the scratch row) and every
+// source's largest per-owner count
+__global__ void route_decode_kernel(const int64_t* __restrict__ raw, int32_t G, int64_t cap,
+                                    int64_t* __restrict__ rows, int32_t* __restrict__ src_max) {
+  const int64_t S = cap + 1;
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (int64_t)G * S) return;
+  const int64_t v = raw[t];
+  rows[t] = v & 0xffffffffll;
+  if (t % S == cap) src_max[t / S] = (int32_t)(v >> 32);
 }
 
 }  // namespace
@@ -166,15 +188,27 @@ extern "C" int xdfm_route_pad(const int32_t* first_slot, const int64_t* uniq_row
                               const int64_t* inverse, int64_t n, int32_t G, int64_t cap, int64_t pad_row,
                               int64_t* rows_padded, int32_t* slot_sorted_p, int64_t* inverse_p, int32_t* counts,
                               void* stream) {
-  XDFM_REQUIRE(n >= 0 && G > 0 && G <= 64 && cap > 0 && (int64_t)G * cap < ((int64_t)1 << 31),
+  XDFM_REQUIRE(n >= 0 && G > 0 && G <= 64 && cap > 0 && (int64_t)G * (cap + 1) < ((int64_t)1 << 31),
                "xdfm_route_pad: bad sizes (at most 64 owners)");
+  XDFM_REQUIRE(pad_row >= 0 && pad_row < ((int64_t)1 << 31), "xdfm_route_pad: pad_row out of range");
   XDFM_REQUIRE(first_slot && rows_padded && counts, "xdfm_route_pad: null argument");
   XDFM_REQUIRE(n == 0 || (uniq_rows && slot_sorted && inverse && slot_sorted_p && inverse_p),
                "xdfm_route_pad: null argument");
-  const int64_t threads = n > (int64_t)G * cap ? n : (int64_t)G * cap;
+  const int64_t slots = (int64_t)G * (cap + 1);
+  const int64_t threads = n > slots ? n : slots;
   XDFM_LAUNCH("route_pad_kernel", stream, route_pad_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0,
               first_slot, uniq_rows, slot_sorted, inverse, n, G, cap, pad_row, rows_padded, slot_sorted_p, inverse_p,
               counts);
+  XDFM_LAUNCH_CHECK();
+  return XDFM_OK;
+}
+
+extern "C" int xdfm_route_decode(const int64_t* raw, int32_t G, int64_t cap, int64_t* rows, int32_t* src_max,
+                                 void* stream) {
+  XDFM_REQUIRE(raw && rows && src_max && G > 0 && cap > 0, "xdfm_route_decode: bad argument");
+  const int64_t slots = (int64_t)G * (cap + 1);
+  XDFM_LAUNCH("route_decode_kernel", stream, route_decode_kernel, dim3((unsigned)((slots + 255) / 256)), dim3(256), 0, raw,
+              G, cap, rows, src_max);
   XDFM_LAUNCH_CHECK();
   return XDFM_OK;
 }

@@ -107,7 +107,8 @@ class DeviceBatch(object):
     """One mini-batch resident in HBM (the dnn view of the iterator as CSR)."""
 
     __slots__ = ("B", "nnz", "labels", "ids", "weights", "row_ptr", "tok_row", "sorted_ids",
-                 "sorted_tok", "sorted_row", "sorted_w", "planned", "planned_gather", "plan_event", "ready_event", "src_table", "src_lin", "src_ids", "src_N", "route")
+                 "sorted_tok", "sorted_row", "sorted_w", "planned", "planned_gather", "plan_event", "ready_event", "src_table", "src_lin", "src_ids", "src_N", "route",
+                 "flat")
 
 
 class XDeepFMEngine(object):

@@ -77,6 +77,38 @@ class _Bufs(object):
         return t[:numel]
 
 
+class _Captured(object):
+    """A fixed launch sequence (kernels of libxdfm.so over buffers that stay where they are) run eagerly the
+    first time and replayed as one HIP graph from then on: the host pays one launch instead of a dozen.
+    `key` names everything the sequence depends on (sizes, buffer addresses); another key captures anew.
+    A runtime that cannot capture the sequence keeps running it eagerly."""
+
+    def __init__(self):
+        self.graphs = {}
+        self.failed = False
+
+    def run(self, key, fn, device):
+        g = self.graphs.get(key)
+        if g is not None:
+            g.replay()
+            return
+        fn()
+        if self.failed or os.environ.get("XDFM_SHARD_GRAPHS", "1") == "0":
+            return
+        try:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                fn()
+            if len(self.graphs) >= 16:
+                self.graphs.clear()
+            self.graphs[key] = g
+        except Exception as exc:  # noqa: BLE001
+            import warnings
+
+            warnings.warn("HIP graph capture of a routing sequence failed (%s); it stays eager" % (exc,))
+            self.failed = True
+
+
 class RowShardExchange(object):
     def __init__(self, group=None, virtual_world=1, force_collectives=False):
         """virtual_world > 1 (single process only, for tests): partition the tokens as if there
@@ -97,6 +129,8 @@ class RowShardExchange(object):
         # slots per owner of a fixed-capacity request (0: none chosen yet); the same on every rank
         # (it is derived from counts every rank has seen: grow_capacity)
         self.cap = 0
+        self._route_graphs = _Captured()
+        self._pinned = {}
 
     def _a2a(self, out, x, out_splits=None, in_splits=None):
         if self.host_staged and x.is_cuda:
@@ -205,13 +239,15 @@ class RowShardExchange(object):
         return self.cap
 
     def _pad(self, uniq_rows, slot_sorted, inverse, first, n, G, cap, pad_row):
-        """xdfm_route_pad (device) or its torch restatement (CPU tensors): the request in G x cap slots."""
+        """xdfm_route_pad (device) or its torch restatement (CPU tensors): the request in G blocks of cap + 1
+        slots (the last one of a block is its header, see include/xdfm.h)."""
+        S = cap + 1
         dev = first.device
         if first.is_cuda:
             from recommenders_amd.models.deeprec.models._engine import _ptr
 
             bufs = self._bufs.setdefault((dev, self._calls & 1), _Bufs(dev))
-            rows_p = bufs.get("rows_padded", G * cap, torch.int64)
+            rows_p = bufs.get("rows_padded", G * S, torch.int64)
             ss_p = bufs.get("slot_sorted_p", max(n, 1), torch.int32)
             inv_p = bufs.get("inverse_p", max(n, 1), torch.int64)
             counts = bufs.get("counts", G + 1, torch.int32)
@@ -229,17 +265,18 @@ class RowShardExchange(object):
                 nxt = f[g]
             start[g] = nxt
         cnt = [start[g + 1] - start[g] for g in range(G)]
-        rows_p = torch.full((G * cap,), int(pad_row), dtype=torch.int64)
+        rows_p = torch.full((G * S,), int(pad_row), dtype=torch.int64)
         for g in range(G):
             k = min(cnt[g], cap)
-            rows_p[g * cap:g * cap + k] = uniq_rows[start[g]:start[g] + k]
+            rows_p[g * S:g * S + k] = uniq_rows[start[g]:start[g] + k]
+            rows_p[g * S + cap] = int(pad_row) | ((max(cnt) if cnt else 0) << 32)
         st_t = torch.tensor(start[:G], dtype=torch.int64)
 
         def renumber(slot):
             slot = slot.to(torch.int64)
             g = torch.bucketize(slot, torch.tensor(start[1:G], dtype=torch.int64), right=True) if G > 1 else torch.zeros_like(slot)
             k = slot - st_t[g]
-            return torch.where(k < cap, g * cap + k, torch.zeros_like(k))
+            return torch.where(k < cap, g * S + k, torch.zeros_like(k))
 
         counts = torch.tensor(cnt + [max(cnt) if cnt else 0], dtype=torch.int32)
         return rows_p, renumber(slot_sorted).to(torch.int32), renumber(inverse), counts
@@ -259,33 +296,70 @@ class RowShardExchange(object):
         n = int(ids.numel())
         plan.n_tok = n
         plan.fixed, plan.cap = True, self.cap
-        part = self._partition_device if ids.is_cuda else self._partition_host
-        plan.order, slot_sorted, inverse, uniq_rows, first = part(ids, int(n_rows), G)
-        rows_p, plan.slot_sorted, plan.inverse, counts = self._pad(uniq_rows, slot_sorted, inverse, first, n, G,
-                                                                   self.cap, pad_row)
-        plan.uniq_rows = rows_p
-        plan.n_send = plan.n_recv = G * self.cap
-        plan.send_counts = plan.recv_counts = None
-        mx = counts[G:G + 1]
-        if self.collective:
-            if self.host_staged or not mx.is_cuda:
-                h = mx.cpu()
-                allmx = torch.empty((self.world,), dtype=h.dtype)
-                dist.all_gather_into_tensor(allmx, h, group=self.group)
+        if ids.is_cuda and n > 0:
+            # partition + padding are a dozen launches over this generation's buffers: replayed as one graph
+            # (the ids are copied into a buffer of the generation's first)
+            bufs = self._bufs.setdefault((ids.device, self._calls & 1), _Bufs(ids.device))
+            ids_in = bufs.get("ids_in", n, torch.int64)
+            ids_in.copy_(ids)
+            res = {}
+
+            def seq():
+                order, slot_sorted, inverse, uniq_rows, first = self._partition_device(ids_in, int(n_rows), G)
+                res["v"] = (order,) + self._pad(uniq_rows, slot_sorted, inverse, first, n, G, self.cap, pad_row)
+
+            seq_key = ("route", n, int(n_rows), G, self.cap, int(pad_row), self._calls & 1, ids_in.data_ptr())
+            hit = self._route_out.get(seq_key) if hasattr(self, "_route_out") else None
+            if hit is None:
+                self._route_graphs.run(seq_key, seq, ids.device)
+                if not hasattr(self, "_route_out"):
+                    self._route_out = {}
+                if len(self._route_out) >= 16:
+                    self._route_out.clear()
+                self._route_out[seq_key] = res["v"]
+                hit = res["v"]
             else:
-                allmx = torch.empty((self.world,), dtype=mx.dtype, device=mx.device)
-                dist.all_gather_into_tensor(allmx, mx, group=self.group)
+                self._route_graphs.run(seq_key, seq, ids.device)
+            plan.order, rows_p, plan.slot_sorted, plan.inverse, counts = hit
         else:
-            allmx = mx
-        if allmx.is_cuda:
-            plan.fit_host = torch.empty(allmx.shape, dtype=allmx.dtype, pin_memory=True)
-            plan.fit_host.copy_(allmx, non_blocking=True)
+            part = self._partition_device if ids.is_cuda else self._partition_host
+            plan.order, slot_sorted, inverse, uniq_rows, first = part(ids, int(n_rows), G)
+            rows_p, plan.slot_sorted, plan.inverse, counts = self._pad(uniq_rows, slot_sorted, inverse, first, n, G,
+                                                                       self.cap, pad_row)
+        plan.uniq_rows = rows_p
+        plan.n_send = plan.n_recv = G * (self.cap + 1)
+        plan.send_counts = plan.recv_counts = None
+        # ids to their owners (equal splits); every block's header tells the owner its source's largest count
+        raw = self.to_owner(plan, rows_p)
+        plan.recv_rows, src_max = self._decode(raw, G, self.cap)
+        if src_max.is_cuda:
+            gen = self._calls & 1
+            pin = self._pinned.get((gen, G))
+            if pin is None:
+                pin = self._pinned[(gen, G)] = torch.empty((G,), dtype=torch.int32, pin_memory=True)
+            pin.copy_(src_max, non_blocking=True)
+            plan.fit_host = pin
             plan.fit_event = torch.cuda.Event()
-            plan.fit_event.record(torch.cuda.current_stream(allmx.device))
+            plan.fit_event.record(torch.cuda.current_stream(src_max.device))
         else:
-            plan.fit_host = allmx.clone()
-        plan.recv_rows = self.to_owner(plan, rows_p)
+            plan.fit_host = src_max
         return plan
+
+    def _decode(self, raw, G, cap):
+        """xdfm_route_decode or its torch form: (row indices with the headers turned into scratch rows, every
+        source's largest per-owner count)."""
+        if raw.is_cuda:
+            from recommenders_amd.models.deeprec.models._engine import _ptr
+
+            bufs = self._bufs.setdefault((raw.device, self._calls & 1), _Bufs(raw.device))
+            rows = bufs.get("recv_rows", G * (cap + 1), torch.int64)
+            src_max = bufs.get("src_max", G, torch.int32)
+            st = ctypes.c_void_p(torch.cuda.current_stream(raw.device).cuda_stream)
+            _lib.check(_lib.lib.xdfm_route_decode(_ptr(raw), G, cap, _ptr(rows), _ptr(src_max), st))
+            return rows, src_max
+        rows = raw & 0xFFFFFFFF
+        src_max = (raw.view(G, cap + 1)[:, cap] >> 32).to(torch.int32)
+        return rows, src_max
 
     def fits(self, plan):
         """Whether a fixed-capacity plan holds its batch on every rank (plan.gmax = the largest number of
@@ -407,6 +481,7 @@ class ShardedXDeepFMEngine(XDeepFMEngine):
             self.exchange.broadcast(self.dense, 0)  # replicated parameters start identical
         self.dropout_seed ^= (0x632BE59BD9B4E019 * self.rank) & (2 ** 64 - 1)  # ranks draw different masks
         self._consts = {}
+        self._owner_graphs = _Captured()
         self._owner_ws = _Bufs(self.device)
         self._route_stream = None
         self._route_pre = None
@@ -511,12 +586,22 @@ class ShardedXDeepFMEngine(XDeepFMEngine):
             sz = ctypes.c_size_t()
             _lib.check(self.lib.xdfm_embed_plan_workspace_bytes(n, self.N, ctypes.byref(sz)))
             ws = self._owner_buf("plan_ws%d" % gen, sz.value, torch.uint8)
-            ev = self._mark("owner_plan")
-            _lib.check(
-                self.lib.xdfm_embed_plan(_ptr(plan.recv_rows), n, self.N, _ptr(plan.owner_sorted_ids),
-                                         _ptr(plan.owner_sorted_tok), _ptr(ws), ws.numel(), self._stream())
-            )
-            self._done(ev)
+
+            def sort():
+                _lib.check(
+                    self.lib.xdfm_embed_plan(_ptr(plan.recv_rows), n, self.N, _ptr(plan.owner_sorted_ids),
+                                             _ptr(plan.owner_sorted_tok), _ptr(ws), ws.numel(), self._stream())
+                )
+
+            if plan.fixed and self.kernel_events is None:
+                # a fixed-capacity request arrives in the same buffer every other step: the sort's six launches
+                # replay as one graph
+                self._owner_graphs.run(("osort", n, self.N, gen, plan.recv_rows.data_ptr(),
+                                        plan.owner_sorted_ids.data_ptr(), ws.data_ptr()), sort, self.device)
+            else:
+                ev = self._mark("owner_plan")
+                sort()
+                self._done(ev)
         return plan
 
     def resolve_plan(self, batch):
@@ -727,16 +812,48 @@ class ShardedXDeepFMEngine(XDeepFMEngine):
         # rows arrive one per slot: as many as the batch has distinct rows at most (sized requests) or the
         # request's fixed number
         slots = plan.n_send if plan.fixed else batch.nnz
-        key = (batch.B, batch.nnz, slots, bool(plan.fixed))
+        # a fixed-capacity plan lives in its generation's buffers (the same addresses every other step): the
+        # graph reads the partition order / slot maps there instead of from copies
+        direct = bool(plan.fixed and plan.order.is_cuda)
+        key = (batch.B, batch.nnz, slots, bool(plan.fixed)) + (
+            (plan.gen, plan.order.data_ptr(), plan.slot_sorted.data_ptr(), plan.inverse.data_ptr()) if direct else ())
         g = self._local_graphs.get(key)
         if g is not None and g.ws_token != self._ws_token:
             # the workspace was re-allocated (a larger batch came through): its addresses are stale
             self._local_graphs.clear()
             g = None
-        if g is None and len(self._local_graphs) < 6:
-            g = _LocalGraph(self, batch, slots, bool(plan.fixed))
+        if g is None and len(self._local_graphs) < 8:
+            g = _LocalGraph(self, batch, slots, bool(plan.fixed), plan if direct else None)
             self._local_graphs[key] = g
         return g
+
+    def make_batch(self, labels, dnn_idx, ids, weights):
+        """XDeepFMEngine.make_batch with the arrays the local graph reads (labels, weights, CSR offsets, token
+        rows) as views of ONE flat buffer: handing the batch to the graph is one copy."""
+        from recommenders_amd.models.deeprec.models._engine import DeviceBatch
+
+        B, nnz = int(labels.numel()), int(ids.numel())
+        lay, flat = _flat_layout(B, nnz, self.F, self.device)
+        b = DeviceBatch()
+        b.B, b.nnz, b.ids = B, nnz, ids
+        b.flat = flat
+        b.labels, b.weights, b.row_ptr, b.tok_row = (_flat_view(flat, lay, k) for k in ("labels", "weights", "row_ptr", "tok_row"))
+        b.labels.copy_(labels.reshape(-1))
+        if nnz:
+            b.weights[:nnz].copy_(weights.reshape(-1))
+        _lib.check(
+            self.lib.xdfm_build_row_ptr(_ptr(dnn_idx), nnz, B * self.F, _ptr(b.row_ptr), _ptr(b.tok_row),
+                                        _ptr(self.err_flag), self._stream())
+        )
+        b.sorted_ids = b.sorted_tok = b.sorted_row = b.sorted_w = None
+        b.planned = b.planned_gather = False
+        b.plan_event = None
+        b.ready_event = torch.cuda.Event()
+        b.ready_event.record(torch.cuda.current_stream(self.device))
+        b.route = None
+        b.src_table = b.src_lin = b.src_ids = None
+        b.src_N = 0
+        return b
 
     def train_step(self, batch, next_batch=None):
         """One optimisation step on this rank's share of the global batch.  Returns this
@@ -801,10 +918,15 @@ class ShardedXDeepFMEngine(XDeepFMEngine):
         self._gen_free[batch.route.gen] = done
         if self._square and self.exchange.collective and rmse is not None:
             self.data_loss.copy_(rmse / self.world)  # shares that add up to the global root mean square
-        reg = self.reg_loss if self.rank == 0 else torch.zeros_like(self.reg_loss)
+        # this rank's share: the data loss, the replicated parameters' regularisation on rank 0 only, and (dense-exact)
+        # the terms of this rank's table rows
+        if self.rank != 0:
+            self.reg_loss.zero_()
         if not self.sparse:
-            reg = reg + self.reg_table  # every rank's rows carry their share of the table's terms
-        return (self.data_loss + reg)[0], self.data_loss[0].clone()
+            self.reg_loss.add_(self.reg_table)
+        tot = torch.empty((2,), dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.xdfm_loss_total(_ptr(self._loss2), _ptr(tot), self._stream()))  # [data, data + reg]
+        return tot[1], tot[0]
 
     def _bn_fwd(self, x, y, where, k, B, C, inner, act):
         """Batch normalisation over the GLOBAL batch: every rank's (count, mean, sum of squared deviations)
@@ -914,11 +1036,26 @@ class ShardedXDeepFMEngine(XDeepFMEngine):
         return full, lin
 
 
+def _flat_layout(B, nnz, F, device):
+    """(name -> (byte offset, dtype, elements), a new flat buffer) for the per-batch arrays of the local graph."""
+    lay, off = {}, 0
+    for name, dt, n in (("labels", torch.float32, B), ("weights", torch.float32, max(nnz, 1)),
+                        ("row_ptr", torch.int32, B * F + 1), ("tok_row", torch.int32, max(nnz, 1))):
+        lay[name] = (off, dt, n)
+        off += (n * 4 + 255) // 256 * 256
+    return lay, torch.zeros((max(off, 256),), dtype=torch.uint8, device=device)
+
+
+def _flat_view(flat, lay, name):
+    off, dt, n = lay[name]
+    return flat[off:off + n * 4].view(dt)
+
+
 class _LocalGraph(object):
     """forward + backward + per-token gradients of one rank for batches of one shape, captured
     as a HIP graph over static buffers (the rows fetched from the owners land in src_table)."""
 
-    def __init__(self, eng, batch, slots=None, fixed=False):
+    def __init__(self, eng, batch, slots=None, fixed=False, plan=None):
         """slots: rows fetched from the owners = gradient records sent back (the batch's token count bounds
         them under sized requests; a fixed-capacity request has world x cap, used or not: the unused
         records must leave as zeros, so send_c is cleared inside the graph)."""
@@ -933,19 +1070,23 @@ class _LocalGraph(object):
         self.src_comb = torch.zeros((slots, D + 4 if use_lin else D), dtype=f32, device=dev)
         self.src_table = self.src_comb[:, :D]
         self.src_lin = self.src_comb[:, D] if use_lin else None
-        self.src_ids = torch.zeros((nnz,), dtype=torch.int64, device=dev)
-        self.order32 = torch.zeros((nnz,), dtype=torch.int32, device=dev)
-        # the segment keys of the per-slot pre-reduction: a buffer of this graph's own (a captured
-        # launch keeps the address it was recorded with)
-        self.seg_ids = torch.zeros((nnz,), dtype=torch.int32, device=dev)
+        self.direct = plan is not None
+        if self.direct:
+            # the plan's own (generation) buffers: nothing to copy per step
+            self.src_ids, self.order32, self.seg_ids = plan.inverse, plan.order, plan.slot_sorted
+        else:
+            self.src_ids = torch.zeros((nnz,), dtype=torch.int64, device=dev)
+            self.order32 = torch.zeros((nnz,), dtype=torch.int32, device=dev)
+            # the segment keys of the per-slot pre-reduction: a buffer of this graph's own (a captured
+            # launch keeps the address it was recorded with)
+            self.seg_ids = torch.zeros((nnz,), dtype=torch.int32, device=dev)
         self.ws_token = eng._ws_token
         self.send_c = torch.zeros((slots, D + 4 if use_lin else D), dtype=f32, device=dev)
         sb = DeviceBatch()
         sb.B, sb.nnz = B, nnz
-        sb.labels = torch.zeros_like(batch.labels)
-        sb.weights = torch.zeros_like(batch.weights)
-        sb.row_ptr = torch.zeros_like(batch.row_ptr)
-        sb.tok_row = torch.zeros_like(batch.tok_row)
+        self.lay, self.flat = _flat_layout(B, nnz, eng.F, dev)
+        sb.labels, sb.weights, sb.row_ptr, sb.tok_row = (_flat_view(self.flat, self.lay, k)
+                                                          for k in ("labels", "weights", "row_ptr", "tok_row"))
         sb.ids = None  # never read: the embeddings come from src_table
         sb.src_table, sb.src_lin, sb.src_ids, sb.src_N = self.src_table, self.src_lin, self.src_ids, max(slots, 1)
         sb.sorted_ids = sb.sorted_tok = None
@@ -987,10 +1128,15 @@ class _LocalGraph(object):
     def load(self, batch):
         """Copy the per-batch arrays (and the partition order) into the graph's inputs."""
         sb, plan = self.batch, batch.route
-        sb.labels.copy_(batch.labels)
-        sb.weights.copy_(batch.weights)
-        sb.row_ptr.copy_(batch.row_ptr)
-        sb.tok_row.copy_(batch.tok_row)
-        self.order32.copy_(plan.order)
-        self.seg_ids.copy_(plan.slot_sorted)
-        self.src_ids.copy_(plan.inverse)
+        flat = getattr(batch, "flat", None)
+        if flat is not None and flat.numel() == self.flat.numel():
+            self.flat.copy_(flat)  # labels, weights, CSR offsets, token rows in one copy
+        else:
+            sb.labels.copy_(batch.labels)
+            sb.weights[:batch.weights.numel()].copy_(batch.weights)
+            sb.row_ptr.copy_(batch.row_ptr)
+            sb.tok_row[:batch.tok_row.numel()].copy_(batch.tok_row)
+        if not self.direct:
+            self.order32.copy_(plan.order)
+            self.seg_ids.copy_(plan.slot_sorted)
+            self.src_ids.copy_(plan.inverse)

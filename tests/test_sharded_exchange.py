@@ -82,7 +82,7 @@ def _worker(rank, world, port, n_rows, dim, out):
         assert cap % 64 == 0 and cap >= gmax * 1.25
         pad_row = (n_rows + world - 1) // world        # one index every rank may use as its scratch row
         fp = ex.route_fixed(ids, n_rows, pad_row)
-        assert ex.fits(fp) and fp.gmax == gmax and fp.fixed and fp.n_send == fp.n_recv == world * cap
+        assert ex.fits(fp) and fp.gmax == gmax and fp.fixed and fp.n_send == fp.n_recv == world * (cap + 1)
         shard_p = torch.zeros(pad_row + 1, dim)
         shard_p[:shard.shape[0]] = shard
         assert int(fp.recv_rows.max()) <= pad_row
