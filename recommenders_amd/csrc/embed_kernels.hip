@@ -343,14 +343,16 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(FwdArgs a) {
     // tokens, then the table rows of those tokens are each requested in one go, so a sample
     // costs three memory round trips instead of three per row.  Further tokens of a multi-hot
     // row follow in column order (the sums stay bit-identical to the sequential form).
-    // (under ageing a row is four loads, not one: 2 rows per group keep the kernel at 110 registers and
-    // 26 us on the bench workload; 4 rows take 161 registers and 32 us, 1 row 88 and 25 us)
-    constexpr int PU = AGE ? 2 : 4;
+    // Under ageing a row is four loads, not one: the CSR bounds and tokens of PU rows are still requested
+    // together, their table rows RB at a time (2 rows in flight per lane group keep the kernel at ~110
+    // registers; 4 take 161 registers and 32 us instead of 26 on the bench workload).
+    constexpr int PU = 4;
+    constexpr int RB = AGE ? 2 : 4;
     for (int f0 = g; f0 < F; f0 += PU * RPP) {
       int beg[PU], end[PU];
       int64_t id0[PU];
       float w0[PU];
-      bool has[PU];
+      bool has[PU], ok0[PU];
       // The CSR bounds and, speculatively, the token a single-hot batch keeps at position r (one
       // token per row: row_ptr is the identity) are requested together: two memory round trips
       // instead of three when the guess holds, which it does for every row of Criteo-shaped data.
@@ -374,59 +376,62 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(FwdArgs a) {
           id0[u] = ids[beg[u]];
           w0[u] = weights[beg[u]];
         }
-      }
-      RowReq<VEC> rq[PU];
-      bool ok0[PU];
-#pragma unroll
-      for (int u = 0; u < PU; ++u) {
         ok0[u] = has[u] && (uint64_t)id0[u] < (uint64_t)N;
-        row_request<VEC, AGE>(table, lin_w, TS, LS, a.age, ok0[u] ? id0[u] : 0, c, want_lin, rq[u]);
       }
 #pragma unroll
-      for (int u = 0; u < PU; ++u) {
-        const int f = f0 + u * RPP;
-        if (f >= F) continue;
-        const int64_t r = b * F + f;
-        float acc[VEC];
+      for (int u0 = 0; u0 < PU; u0 += RB) {
+        if (f0 + u0 * RPP >= F) break;  // (wave-uniform per lane group; lanes past F idle anyway)
+        RowReq<VEC> rq[RB];
 #pragma unroll
-        for (int v = 0; v < VEC; ++v) acc[v] = 0.f;
-        if (has[u]) {
-          if (ok0[u]) {
-            row_resolve<VEC, AGE>(a.age, cur_s, done, want_lin, rq[u]);
+        for (int v = 0; v < RB; ++v)
+          row_request<VEC, AGE>(table, lin_w, TS, LS, a.age, ok0[u0 + v] ? id0[u0 + v] : 0, c, want_lin, rq[v]);
 #pragma unroll
-            for (int v = 0; v < VEC; ++v) {
-              const float t = w0[u] * rq[u].r.p[v];  // one rounding (TF: embeddings *= weights)
-              acc[v] = t;
-              q_acc[v] += t * t;
+        for (int v = 0; v < RB; ++v) {
+          const int u = u0 + v;
+          const int f = f0 + u * RPP;
+          if (f >= F) continue;
+          const int64_t r = b * F + f;
+          float acc[VEC];
+#pragma unroll
+          for (int k = 0; k < VEC; ++k) acc[k] = 0.f;
+          if (has[u]) {
+            if (ok0[u]) {
+              row_resolve<VEC, AGE>(a.age, cur_s, done, want_lin, rq[v]);
+#pragma unroll
+              for (int k = 0; k < VEC; ++k) {
+                const float t = w0[u] * rq[v].r.p[k];  // one rounding (TF: embeddings *= weights)
+                acc[k] = t;
+                q_acc[k] += t * t;
+              }
+              if (want_lin) lin_acc += w0[u] * rq[v].l.p[0];
+            } else {
+              err |= XDFM_DEVERR_ID_RANGE;
             }
-            if (want_lin) lin_acc += w0[u] * rq[u].l.p[0];
-          } else {
-            err |= XDFM_DEVERR_ID_RANGE;
           }
-        }
-        bool first = !(has[u] && ok0[u]);  // no valid token summed yet
-        for (int k = beg[u] + 1; k < end[u]; ++k) {
-          const int64_t id = ids[k];
-          const float w = weights[k];
-          if ((uint64_t)id >= (uint64_t)N) {
-            err |= XDFM_DEVERR_ID_RANGE;
-            continue;
-          }
-          RowReq<VEC> q;
-          row_request<VEC, AGE>(table, lin_w, TS, LS, a.age, id, c, want_lin, q);
-          row_resolve<VEC, AGE>(a.age, cur_s, done, want_lin, q);
+          bool first = !(has[u] && ok0[u]);  // no valid token summed yet
+          for (int k = beg[u] + 1; k < end[u]; ++k) {
+            const int64_t id = ids[k];
+            const float w = weights[k];
+            if ((uint64_t)id >= (uint64_t)N) {
+              err |= XDFM_DEVERR_ID_RANGE;
+              continue;
+            }
+            RowReq<VEC> q;
+            row_request<VEC, AGE>(table, lin_w, TS, LS, a.age, id, c, want_lin, q);
+            row_resolve<VEC, AGE>(a.age, cur_s, done, want_lin, q);
 #pragma unroll
-          for (int v = 0; v < VEC; ++v) {
-            const float t = w * q.r.p[v];
-            acc[v] = first ? t : acc[v] + t;  // segment_sum in column order
-            q_acc[v] += t * t;
+            for (int kk = 0; kk < VEC; ++kk) {
+              const float t = w * q.r.p[kk];
+              acc[kk] = first ? t : acc[kk] + t;  // segment_sum in column order
+              q_acc[kk] += t * t;
+            }
+            first = false;
+            if (want_lin) lin_acc += w * q.l.p[0];
           }
-          first = false;
-          if (want_lin) lin_acc += w * q.l.p[0];
-        }
-        store_vec<VEC>(emb_out + r * D + c * VEC, acc);
+          store_vec<VEC>(emb_out + r * D + c * VEC, acc);
 #pragma unroll
-        for (int v = 0; v < VEC; ++v) s_acc[v] += acc[v];
+          for (int k = 0; k < VEC; ++k) s_acc[k] += acc[k];
+        }
       }
     }
   }
