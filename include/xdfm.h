@@ -75,6 +75,14 @@ const char* xdfm_last_error(void);
  * text into `json` and forgets them.  bench.py's roofline line is computed from this. */
 int xdfm_prof_enable(int32_t on);
 int xdfm_prof_collect(char* json, size_t cap);
+/* Measurement only (no reference counterpart): device-side time stamps, for the timeline of a replayed HIP
+ * graph, which neither events nor a tracer show unchanged.  With a device buffer of XDFM_STAMP_SLOTS pairs
+ * installed (the caller fills it with {UINT64_MAX, 0} pairs first), every kernel of the training step adds
+ * the constant 100 MHz clock to its pair: [2 id] = minimum over its blocks and launches (start), [2 id + 1]
+ * = maximum (end); ids in csrc/stamp.h, names in tools/stamp_timeline.py.  NULL removes the buffer (the
+ * cost is then one scalar load per block).  Applies to the calling thread's current device. */
+#define XDFM_STAMP_SLOTS 32
+int xdfm_debug_stamps(uint64_t* device_buf);
 
 /* ------------------------------------------------------------------------
  * libffm text ingest (host).  Replaces FFMTextIterator.parser_one_line /
@@ -468,7 +476,10 @@ int xdfm_cin_pool_unpack(const float* dwp, int32_t F, int32_t H, int32_t L, int3
  * xdfm_cin_bwd with n_hidden = 0 and masked = 0; the same sums in another association (1e-6).
  *   xdfm_cin_pooled_workspace_floats: 0 = this shape is not served (use xdfm_cin_fwd / xdfm_cin_bwd).
  *   xdfm_cin_pooled_bwd: d_xk[B,H,D] written, d_x0[B,F,D] written or added to (accumulate_x0),
- *     d_w[(f,h), 0..L) written with row stride ldw (0 = L). */
+ *     d_w[(f,h), 0..L) written with row stride ldw (0 = L).  The filter gradient is a short second
+ *     kernel (a sum of per-block partial sums from the workspace) that nothing of the backward pass waits
+ *     for: d_w == NULL leaves the partial sums in the workspace, and a later call with x0 == NULL (same B
+ *     and shape, same workspace, any stream ordered after the first) writes d_w from them. */
 int xdfm_cin_pooled_workspace_floats(int64_t B, int32_t F, int32_t H, int32_t D, int32_t L, size_t* floats);
 int xdfm_cin_pooled_fwd(const float* x0, const float* xk, const float* w, int64_t B, int32_t F, int32_t H,
                         int32_t D, int32_t L, int32_t ldw, float* pooled, int32_t pool_stride, int32_t pool_off,

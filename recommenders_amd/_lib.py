@@ -108,6 +108,7 @@ SIGNATURES = {
     "xdfm_abi_version": [],
     "xdfm_prof_enable": [_I32],
     "xdfm_prof_collect": [ctypes.c_char_p, _SZ],
+    "xdfm_debug_stamps": [_P],
     "xdfm_ffm_open": [ctypes.c_char_p, _I64, _I64, ctypes.c_char, ctypes.c_char, ctypes.POINTER(_P)],
     "xdfm_ffm_next": [_P, _I64, ctypes.POINTER(BatchInfo)],
     "xdfm_ffm_fill": [_P] * 11,

@@ -29,6 +29,7 @@
 #include "cin_common.h"
 #include "cin_stage.h"
 #include "xdfm_common.h"
+#include "stamp.h"
 
 namespace xdfm_cin {
 
@@ -106,6 +107,7 @@ __global__ __launch_bounds__(256) void cin_fwd2_mfma_kernel(
     CinDims c, const float* __restrict__ xi, const float* __restrict__ xo, int Ki, int Ko,
     const float* __restrict__ wq, const int* __restrict__ stab, float* __restrict__ xnext,
     float* __restrict__ pooled, int pool_stride, int pool_off, int SPB, int ngrp, int NQ) {
+  xdfm::Stamp stamp_(xdfm::kStampCinFwd);
   extern __shared__ float lds[];
   constexpr int RT = 4;
   constexpr int ROWS = 64 * RT;
@@ -265,6 +267,128 @@ __global__ __launch_bounds__(256) void cin_fwd2_mfma_kernel(
       float s = 0.f;
       for (int d = 0; d < c.D; ++d) s += outs[p * Tp + bl * c.D + d];  // reduce_sum over D (:270)
       pooled[(b0 + bl) * pool_stride + pool_off + p] = s;
+    }
+  }
+}
+
+// ------------------------------------------------------------ forward, masked layer, static form
+// The same contraction, image and operand layout as cin_fwd2_mfma_kernel for the layer whose two inputs are
+// one tensor (x0 (x) x0, pairs h > f), with the step list known at compile time (NKS = ceil(F / 4) steps of
+// 4 features; tile oq runs ks = oq .. NKS-1):
+//   * a lane's B operands are the same 4 NKS values for every tile and channel group (x[4ks + g][m0 .. m0+3]),
+//     and the value that folds tile oq in is the one of step ks = oq: they are read ONCE, straight from
+//     the tensor into registers (one 16-byte load per step: D % 4 == 0), and the loop touches no LDS,
+//     reads no descriptors and computes no addresses
+//   * the filter image of a channel group (NKS (NKS+1) / 2 steps, one float4 per 4 steps) is requested a
+//     whole group ahead: each register is refilled for the next group behind the last step that reads it
+//   * a tile's fold (16 FMAs) is issued behind the first matrix instructions of the next tile
+// What the generic kernel spends between its matrix instructions (branches on step flags, scalar descriptor
+// loads and the full lgkmcnt wait each phase ends with, LDS reads at computed addresses: 43 % matrix-pipe
+// busy) is gone; sums keep their order, so the two kernels agree bit for bit.
+template <int NKS>
+__global__ __launch_bounds__(256, 2) void cin_fwd_static_kernel(
+    CinDims c, const float* __restrict__ x, const float* __restrict__ wq, float* __restrict__ xnext,
+    float* __restrict__ pooled, int pool_stride, int pool_off, int SPB, int ngrp4, int NQ) {
+  xdfm::Stamp stamp_(xdfm::kStampCinFwd);
+  extern __shared__ float lds[];
+  constexpr int RT = 4;
+  constexpr int ROWS = 64 * RT;
+  constexpr int Tp = ROWS + kPad;
+  constexpr int NS = NKS * (NKS + 1) / 2;
+  constexpr int NG = (NS + 3) / 4;
+  float* outs = lds;  // [npool][Tp]  pooled channels only
+  const int npool = c.L - c.n_hidden;
+  const int64_t b0 = (int64_t)blockIdx.x * SPB;
+  const int nb = (int)((c.B - b0 < SPB) ? (c.B - b0) : SPB);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane & 15, g = lane >> 4;
+  const int cols = nb * c.D;
+  const int m0 = wave * 64 + 4 * j;  // this lane's 4 rows: m0 .. m0+3, 4 consecutive d of one sample
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  const bool on = m0 < cols;
+  const int bl = on ? m0 / c.D : 0, dd = on ? m0 - bl * c.D : 0;
+
+  f32x4 bx[NKS];
+  {
+    const float* xrow = x + ((b0 + bl) * c.F) * c.D + dd;
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+      const int f = 4 * ks + g;
+      bx[ks] = (on && f < c.F) ? *reinterpret_cast<const f32x4*>(xrow + (int64_t)f * c.D) : zero4;
+    }
+  }
+  const f32x4* img = reinterpret_cast<const f32x4*>(wq) + lane;
+  float* xn = xnext + b0 * c.n_hidden * c.D;
+
+  f32x4 A[NG];
+#pragma unroll
+  for (int gi = 0; gi < NG; ++gi) A[gi] = img[gi * 64];
+  for (int nq = 0; nq < NQ; ++nq) {
+    // the next group's image (the last group re-reads its own: no branch in the loop)
+    const f32x4* nxt = img + (size_t)(nq + 1 < NQ ? nq + 1 : nq) * ngrp4 * 64;
+    f32x4 U[2][RT];
+    f32x2 oacc[RT][2];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) oacc[rt][0] = oacc[rt][1] = f32x2{0.f, 0.f};
+    // two packed FMAs per row tile (the pairs follow the accumulator's registers: no moves)
+    auto fold = [&](int oq) {
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) {
+        const f32x2 xx = {bx[oq][rt], bx[oq][rt]};
+        const f32x4 u = U[oq & 1][rt];
+        oacc[rt][0] = __builtin_elementwise_fma(xx, f32x2{u[0], u[1]}, oacc[rt][0]);
+        oacc[rt][1] = __builtin_elementwise_fma(xx, f32x2{u[2], u[3]}, oacc[rt][1]);
+      }
+    };
+#pragma unroll
+    for (int oq = 0; oq < NKS; ++oq) {
+#pragma unroll
+      for (int ks = oq; ks < NKS; ++ks) {
+        const int s = oq * NKS - oq * (oq - 1) / 2 + (ks - oq);
+        const float a = A[s >> 2][s & 3];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+          U[oq & 1][rt] = mfma(a, bx[ks][rt], ks == oq ? zero4 : U[oq & 1][rt]);
+        if ((s & 3) == 3 || s == NS - 1) A[s >> 2] = nxt[(s >> 2) * 64];  // its four steps are done
+        // the previous tile is folded in behind the second step of this one (8 matrix instructions after
+        // its last: the results are there, nothing waits)
+        if (oq > 0 && ks == (oq + 1 < NKS ? oq + 1 : oq)) {
+          __builtin_amdgcn_sched_barrier(0);
+          fold(oq - 1);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    }
+    fold(NKS - 1);
+    // add the 4 oi groups (fixed order), then group g owns channel 4*nq + g of rows m0..m0+3
+    const int ch = 4 * nq + g;
+    f32x4 o;
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+      f32x4 v = {oacc[rt][0][0], oacc[rt][0][1], oacc[rt][1][0], oacc[rt][1][1]};
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float t = v[r];
+        t += __shfl_xor(t, 16);
+        t += __shfl_xor(t, 32);
+        v[r] = t;
+      }
+      o[rt] = (g == 0 ? v[0] : (g == 1 ? v[1] : (g == 2 ? v[2] : v[3]))) * 2.f;  // the masked layer's factor
+    }
+    if (ch < c.n_hidden) {
+      if (on) *reinterpret_cast<f32x4*>(xn + (bl * c.n_hidden + ch) * c.D + dd) = o;
+    } else if (ch < c.L) {
+      *reinterpret_cast<f32x4*>(outs + (ch - c.n_hidden) * Tp + m0) = o;
+    }
+  }
+  if (npool > 0) {
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < npool * nb; idx += blockDim.x) {
+      const int p = idx / nb;
+      const int bq = idx - p * nb;
+      float s = 0.f;
+      for (int d = 0; d < c.D; ++d) s += outs[p * Tp + bq * c.D + d];  // reduce_sum over D (:270)
+      pooled[(b0 + bq) * pool_stride + pool_off + p] = s;
     }
   }
 }
@@ -551,6 +675,7 @@ struct PackJobs {
 };
 
 __global__ void cin_pack_all_kernel(PackJobs jobs) {
+  xdfm::Stamp stamp_(xdfm::kStampCinPack);
   int k = 0;
   while (k + 1 < jobs.n && blockIdx.x >= jobs.j[k + 1].first_block) ++k;
   const PackJob& J = jobs.j[k];
@@ -1049,12 +1174,14 @@ __device__ __forceinline__ void dw_body(const BwdIn& in, const DwArgs& aw, int b
 
 template <int NFT, int S, int SH, int P0>
 __global__ __launch_bounds__(256) void cin_bwd_dx2_mfma_kernel(BwdIn in, Dx2Args ax) {
+  xdfm::Stamp stamp_(xdfm::kStampCinDx);
   extern __shared__ float lds[];
   dx2_body<NFT, S, SH, P0>(in, ax, blockIdx.x, lds);
 }
 
 template <int PT, int NT, int XU, int SD>
 __global__ __launch_bounds__(256) void cin_bwd_dw_mfma_kernel(BwdIn in, DwArgs aw) {
+  xdfm::Stamp stamp_(xdfm::kStampCinDw);
   extern __shared__ float lds[];
   dw_body<PT, NT, XU, SD>(in, aw, blockIdx.x, blockIdx.y, blockIdx.z, lds);
 }
@@ -1064,6 +1191,7 @@ __global__ __launch_bounds__(256) void cin_bwd_dw_mfma_kernel(BwdIn in, DwArgs a
 // group order (fixed association, bit-identical from run to run).
 __global__ __launch_bounds__(256) void cin_dw_unpack_kernel(CinDims c, const float* __restrict__ part,
                                                             int n_splits, float* __restrict__ d_w) {
+  xdfm::Stamp stamp_(xdfm::kStampCinDwUnpack);
   __shared__ float red[8][33];
   const int e = threadIdx.x & 31, g = threadIdx.x >> 5;
   const int64_t idx = (int64_t)blockIdx.x * 32 + e;
@@ -1158,6 +1286,12 @@ bool mfma_supported(int64_t B, int F, int H, int D, int L) {
   return true;
 }
 
+// XDFM_CIN_FWD_STATIC=0 keeps the masked layer on the generic forward kernel (A/B runs, tests of both)
+static bool fwd_static_off() {
+  const char* e = getenv("XDFM_CIN_FWD_STATIC");
+  return e && e[0] == '0';
+}
+
 // which input is the K side of the forward product: the longer feature axis
 static bool fwd_swap(int F, int H, int masked) { return !masked && F > H; }
 
@@ -1192,6 +1326,34 @@ int fwd_mfma(const CinDims& c, const float* x0, const float* xk, const float* w,
   constexpr int ROWS = 256;
   XDFM_REQUIRE(c.D <= ROWS, "xdfm_cin_fwd: dim %d does not fit a row tile", c.D);
   const int SPB = ROWS / c.D;
+  if (c.masked && xi == xo && (c.D & 3) == 0 && nks <= 10 && !fwd_static_off() &&
+      (reinterpret_cast<uintptr_t>(xi) & 15) == 0 && (reinterpret_cast<uintptr_t>(xnext) & 15) == 0) {
+    const size_t lds_bytes = (size_t)(c.L - c.n_hidden) * (ROWS + kPad) * sizeof(float);
+    XDFM_REQUIRE(lds_bytes <= kLdsLimit, "xdfm_cin_fwd: pooled channels do not fit the LDS");
+    dim3 grid((unsigned)((c.B + SPB - 1) / SPB));
+#define CALLF(N)                                                                                            \
+  case N: {                                                                                                 \
+    int rc = allow_lds(cin_fwd_static_kernel<N>, lds_bytes);                                                \
+    if (rc) return rc;                                                                                      \
+    XDFM_LAUNCH("cin_fwd_static_kernel<" #N ">", st, cin_fwd_static_kernel<N>, grid, dim3(256), lds_bytes, \
+                c, xi, ws, xnext, pooled, pool_stride, pool_off, SPB, nsteps_img / 4, NQ);                  \
+  } break
+    switch (nks) {
+      CALLF(1);
+      CALLF(2);
+      CALLF(3);
+      CALLF(4);
+      CALLF(5);
+      CALLF(6);
+      CALLF(7);
+      CALLF(8);
+      CALLF(9);
+      CALLF(10);
+    }
+#undef CALLF
+    XDFM_LAUNCH_CHECK();
+    return XDFM_OK;
+  }
   const int lds_rows = Kip + ((xi == xo) ? 0 : Kop) + (c.L - c.n_hidden);
   const size_t lds_bytes = (size_t)lds_rows * (ROWS + kPad) * sizeof(float);
   XDFM_REQUIRE(lds_bytes <= kLdsLimit, "xdfm_cin_fwd: tile does not fit the LDS");
@@ -1481,3 +1643,5 @@ int pack_all(const xdfm_cin_pack_job* jobs, int n_jobs, int64_t B, int D, hipStr
 }
 
 }  // namespace xdfm_cin
+
+XDFM_STAMP_UNIT(stamp_unit_cin)

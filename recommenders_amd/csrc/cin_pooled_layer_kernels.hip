@@ -26,6 +26,7 @@
 #include <cstring>
 
 #include "xdfm_common.h"
+#include "stamp.h"
 
 namespace {
 
@@ -180,6 +181,7 @@ template <int T, int LN, bool HEAD>
 __global__ __launch_bounds__(256, (T * LN <= 30 ? 2 : 1)) void cin_pooled_fwd_kernel(
     PoolDims c, const float* __restrict__ x0, const float* __restrict__ xk, const float* __restrict__ w,
     float* __restrict__ pooled, int pool_stride, int pool_off, PoolHead hd) {
+  xdfm::Stamp stamp_(xdfm::kStampPooledFwd);
   extern __shared__ __align__(16) float lds[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float loss_acc = 0.f;  // HEAD: this wave's loss terms, in sample order
@@ -301,6 +303,7 @@ __global__ __launch_bounds__(256) void cin_pooled_bwd_kernel(PoolDims c, const f
                                                              int pool_off, float* __restrict__ d_xk,
                                                              float* __restrict__ d_x0, int accumulate_x0,
                                                              float* __restrict__ part) {
+  xdfm::Stamp stamp_(xdfm::kStampPooledBwd);
   extern __shared__ __align__(16) float lds[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lc = lane & 15, g = lane >> 4;
   const int FD = c.F * c.D, HD = c.H * c.D;
@@ -474,6 +477,7 @@ __global__ __launch_bounds__(256) void cin_pooled_bwd_kernel(PoolDims c, const f
 __global__ __launch_bounds__(1024) void cin_pooled_dw_reduce_kernel(PoolDims c, const float* __restrict__ part,
                                                                     int n_blocks, int LN, int kN,
                                                                     float* __restrict__ d_w) {
+  xdfm::Stamp stamp_(xdfm::kStampPooledDwReduce);
   __shared__ float sums[16][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i = blockIdx.x;
@@ -653,13 +657,13 @@ extern "C" int xdfm_cin_pooled_bwd(const float* x0, const float* xk, const float
   XDFM_REQUIRE(supported(F, H, D, L),
                "xdfm_cin_pooled_bwd: shape not served (xdfm_cin_pooled_workspace_floats says 0)");
   XDFM_REQUIRE(B >= 0, "xdfm_cin_pooled_bwd: bad sizes");
-  XDFM_REQUIRE(d_w && workspace, "xdfm_cin_pooled_bwd: null d_w / workspace");
+  XDFM_REQUIRE(workspace && (d_w || x0), "xdfm_cin_pooled_bwd: null d_w / workspace");
   const PoolDims c = make(B, F, H, D, L, ldw);
   hipStream_t st = (hipStream_t)stream;
   const unsigned blocks = n_blocks(B, kSpwBwd);
   const int LN = ln_for(L), kN = 4 * tiles_for(F) * LN;
-  if (B > 0) {
-    XDFM_REQUIRE(x0 && xk && w && d_pooled && d_x0 && d_xk, "xdfm_cin_pooled_bwd: null argument");
+  if (B > 0 && x0) {  // x0 == NULL: only the reduction of the partial sums an earlier call left
+    XDFM_REQUIRE(xk && w && d_pooled && d_x0 && d_xk, "xdfm_cin_pooled_bwd: null argument");
     const size_t lds = lds_bytes(c, true);
     const void* fn = pick(F, L, true);
     if (lds > 64 * 1024) XDFM_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -668,8 +672,11 @@ extern "C" int xdfm_cin_pooled_bwd(const float* x0, const float* xk, const float
                     (void*)&pool_off, (void*)&d_xk, (void*)&d_x0, (void*)&accumulate_x0, (void*)&workspace};
     XDFM_HIP(hipLaunchKernel(fn, dim3(blocks), dim3(256), args, lds, st));
   }
-  XDFM_LAUNCH("cin_pooled_dw_reduce_kernel", st, cin_pooled_dw_reduce_kernel, dim3((unsigned)kN), dim3(1024), 0, c,
-              workspace, (int)blocks, LN, kN, d_w);
+  if (d_w)  // d_w == NULL: the filter gradient stays as per-block partial sums in the workspace
+    XDFM_LAUNCH("cin_pooled_dw_reduce_kernel", st, cin_pooled_dw_reduce_kernel, dim3((unsigned)kN), dim3(1024), 0, c,
+                workspace, (int)blocks, LN, kN, d_w);
   XDFM_LAUNCH_CHECK();
   return XDFM_OK;
 }
+
+XDFM_STAMP_UNIT(stamp_unit_pooled)

@@ -17,6 +17,7 @@
 
 #include "act.h"
 #include "xdfm_common.h"
+#include "stamp.h"
 
 namespace {
 
@@ -34,6 +35,8 @@ template <int NT>
 __global__ __launch_bounds__(256) void dense_fwd_mfma_kernel(
     const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
     int64_t B, int K, int Nout, int act, float* __restrict__ y) {
+  xdfm::Stamp stamp_(xdfm::kStampDenseFwd);
+  side_chain_priority();
   __shared__ float red[3][NT][64][4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i = lane & 15, kk = lane >> 4;
@@ -132,6 +135,8 @@ template <int SMAX>
 __global__ __launch_bounds__(256) void dense_bwd_dx_mfma_kernel(
     const float* __restrict__ w, const float* __restrict__ y, const float* __restrict__ dy,
     int64_t B, int K, int Nout, int n0, int n1, int act, int accumulate, float* __restrict__ dx) {
+  xdfm::Stamp stamp_(xdfm::kStampDenseBwdDx);
+  side_chain_priority();
   // channels [n0, n1) of the layer's Nout: wide layers are summed over several launches
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i = lane & 15, kk = lane >> 4;
@@ -183,6 +188,8 @@ template <int PT, int NT>
 __global__ __launch_bounds__(256) void dense_bwd_dw_mfma_kernel(
     const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ dy,
     int64_t B, int K, int Nout, int act, int rows_per_split, float* __restrict__ part) {
+  xdfm::Stamp stamp_(xdfm::kStampDenseBwdDw);
+  side_chain_priority();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i = lane & 15, kk = lane >> 4;
   const int ktiles = (K + 1 + 15) / 16;
@@ -294,6 +301,8 @@ __global__ __launch_bounds__(256) void dense_bwd_dw_mfma_kernel(
 __global__ __launch_bounds__(256) void dense_dw_reduce_kernel(const float* __restrict__ part, int n_splits,
                                                               int K, int Nout, float* __restrict__ dw,
                                                               float* __restrict__ db) {
+  xdfm::Stamp stamp_(xdfm::kStampDenseBwdDw);
+  side_chain_priority();
   __shared__ float red[8][33];
   const int e = threadIdx.x & 31, g = threadIdx.x >> 5;
   const int64_t idx = (int64_t)blockIdx.x * 32 + e;
@@ -549,3 +558,5 @@ extern "C" int xdfm_dropout_act_bwd(const float* y, const float* dy, const float
   XDFM_LAUNCH_CHECK();
   return XDFM_OK;
 }
+
+XDFM_STAMP_UNIT(stamp_unit_dnn)

@@ -20,6 +20,7 @@
 
 #include "drift.h"
 #include "xdfm_common.h"
+#include "stamp.h"
 
 namespace {
 
@@ -299,6 +300,7 @@ struct FwdArgs {
 
 template <int VEC, bool AGE>
 __global__ __launch_bounds__(256) void embed_fwd_kernel(FwdArgs a) {
+  xdfm::Stamp stamp_(xdfm::kStampEmbedFwd);
   __shared__ float red_s[4][kWave][VEC];
   __shared__ float red_q[4][kWave][VEC];
   __shared__ float red_l[4][kWave];
@@ -610,6 +612,7 @@ __device__ __forceinline__ Pieces pieces_of(const BwdArgs& a, int64_t nchunks) {
 
 template <int VEC, int MODE, bool AGE>
 __global__ __launch_bounds__(256) void embed_bwd_kernel(BwdArgs a) {
+  xdfm::Stamp stamp_(xdfm::kStampEmbedBwd);
   __shared__ float4 cur_s[AGE ? xdfm::kDriftG : 1];
   int done = 0;
   if (AGE) {
@@ -757,6 +760,7 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(BwdArgs a) {
 // adds the segment's pieces in chunk order and finishes the row.
 template <int VEC, int MODE, bool AGE>
 __global__ __launch_bounds__(256) void embed_bwd_long_kernel(BwdArgs a) {
+  xdfm::Stamp stamp_(xdfm::kStampEmbedBwdLong);
   __shared__ float4 cur_s[AGE ? xdfm::kDriftG : 1];
   int done = 0;
   if (AGE) {
@@ -834,6 +838,7 @@ __global__ __launch_bounds__(256) void embed_bwd_long_kernel(BwdArgs a) {
 __global__ void plan_gather_kernel(const int32_t* __restrict__ sorted_tok, const int32_t* __restrict__ tok_row,
                                    const float* __restrict__ weights, int64_t nnz,
                                    int32_t* __restrict__ row_sorted, float* __restrict__ w_sorted) {
+  xdfm::Stamp stamp_(xdfm::kStampPlanGather);
   const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= nnz) return;
   const int tok = sorted_tok[p];
@@ -1290,3 +1295,5 @@ extern "C" int xdfm_embed_plan_gather(const int32_t* sorted_tok, const int32_t* 
   XDFM_LAUNCH_CHECK();
   return XDFM_OK;
 }
+
+XDFM_STAMP_UNIT(stamp_unit_embed)

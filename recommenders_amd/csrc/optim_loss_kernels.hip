@@ -16,6 +16,7 @@
 #include "drift.h"
 #include "sort_plan.h"
 #include "xdfm_common.h"
+#include "stamp.h"
 
 namespace {
 
@@ -65,6 +66,8 @@ __global__ __launch_bounds__(256) void dense_stats_kernel(SegTable tab, const fl
                                                           const float* __restrict__ grad,
                                                           const float* __restrict__ stats, int pass,
                                                           float* __restrict__ partial) {
+  xdfm::Stamp stamp_(xdfm::kStampDenseStats);
+  side_chain_priority();
   __shared__ float sh[256];
   const int s = blockIdx.y;
   const long long beg = tab.off[s], end = tab.off[s + 1];
@@ -98,6 +101,8 @@ __global__ __launch_bounds__(256) void dense_stats_kernel(SegTable tab, const fl
 __global__ __launch_bounds__(1024) void dense_stats_final_kernel(
     SegTable tab, const float* __restrict__ partial, int pass, float* __restrict__ stats,
     float* reg_loss, int accumulate) {
+  xdfm::Stamp stamp_(xdfm::kStampDenseStats);
+  side_chain_priority();
   static_assert(kStatBlocks == 128, "two partials per lane");
   __shared__ float regs[32];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -134,6 +139,7 @@ __global__ __launch_bounds__(256) void dense_update_kernel(SegTable tab, OptDev 
                                                            float* __restrict__ slot_m,
                                                            float* __restrict__ slot_v,
                                                            const float* __restrict__ stats) {
+  xdfm::Stamp stamp_(xdfm::kStampDenseUpdate);
   const long long total = tab.off[tab.n];
   const float alpha = o.state ? o.state[2] : o.alpha;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total;
@@ -241,6 +247,7 @@ __device__ __forceinline__ void drift_fill_cur(float4* tab, int t, float lr, flo
 // the other slot) by adding step t's term:  C_k(t - G, G) = C_k(t - G, G - 1) + alpha_t (b1/g)^G d_G^k.
 __global__ __launch_bounds__(xdfm::kDriftG) void opt_advance_kernel(float* st, float lr, float beta1, float beta2,
                                                                     float eps, float4* tab) {
+  xdfm::Stamp stamp_(xdfm::kStampOptAdvance);
   const float b1p = st[0] * beta1, b2p = st[1] * beta2, t = st[3] + 1.f;
   const float alpha = lr * sqrtf(1.f - b2p) / (1.f - b1p);
   __syncthreads();  // every thread has read the old state
@@ -479,6 +486,8 @@ __global__ __launch_bounds__(kHeadThreads) void head_loss_kernel(LossArgs a, Hea
 __global__ __launch_bounds__(kHeadThreads) void loss_finish_kernel(const float* __restrict__ partial, int n,
                                                                    float count, int root,
                                                                    float* __restrict__ loss_out) {
+  xdfm::Stamp stamp_(xdfm::kStampLossFinish);
+  side_chain_priority();
   __shared__ float sh[kHeadThreads];
   float s = 0.f;
   for (int k = threadIdx.x; k < n; k += kHeadThreads) s += partial[k];
@@ -589,6 +598,7 @@ __global__ __launch_bounds__(256) void eval_final_kernel(const unsigned long lon
 
 // [data loss, regularisation loss] -> [data, data + reg]: the two numbers a training step reports
 __global__ void loss_pair_kernel(const float* __restrict__ loss2, float* __restrict__ out2) {
+  xdfm::Stamp stamp_(xdfm::kStampLossPair);
   if (threadIdx.x == 0 && blockIdx.x == 0) {
     const float d = loss2[0];
     out2[0] = d;
@@ -914,3 +924,5 @@ extern "C" int xdfm_loss_total(const float* loss2, float* out2, void* stream) {
   XDFM_LAUNCH_CHECK();
   return XDFM_OK;
 }
+
+XDFM_STAMP_UNIT(stamp_unit_optim)

@@ -16,6 +16,7 @@
 
 #include "sort_plan.h"
 #include "xdfm_common.h"
+#include "stamp.h"
 
 namespace {
 
@@ -58,6 +59,7 @@ template <bool FIRST>
 __global__ __launch_bounds__(kThreads) void sort_hist_kernel(const void* __restrict__ keys, int64_t n, int64_t N,
                                                              int shift, int bits, int64_t tile,
                                                              uint32_t* __restrict__ table) {
+  xdfm::Stamp stamp_(xdfm::kStampSort);
   __shared__ uint32_t h[kBins];
   const int tid = threadIdx.x;
   h[tid] = 0;
@@ -93,6 +95,7 @@ __global__ __launch_bounds__(kThreads) void sort_scatter_kernel(
     const void* __restrict__ src_keys, const uint32_t* __restrict__ src_vals, uint32_t* __restrict__ dst_keys,
     uint32_t* __restrict__ dst_vals, int64_t n, int64_t N, int shift, int bits, int64_t tile, int nt,
     const uint32_t* __restrict__ table) {
+  xdfm::Stamp stamp_(xdfm::kStampSort);
   __shared__ uint32_t whist[kWaves][kBins];  // per wave: keys of each digit seen so far
   __shared__ uint32_t gbase[kBins];          // where this block's next key of each digit goes
   __shared__ uint32_t tstart[kBins];         // start of each digit inside the ordered sub-tile
@@ -337,3 +340,5 @@ extern "C" int xdfm_embed_plan(const int64_t* ids, int64_t nnz, int64_t N, int32
   if (nnz == 0) return XDFM_OK;
   return xdfm::plan_sort(ids, nnz, N, sorted_ids, sorted_tok, plan_ws, plan_ws_bytes, (hipStream_t)stream);
 }
+
+XDFM_STAMP_UNIT(stamp_unit_sort)

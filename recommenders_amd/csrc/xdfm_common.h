@@ -54,3 +54,17 @@ class ProfScope {
   } while (0)
 
 #define XDFM_LAUNCH_CHECK() XDFM_HIP(hipGetLastError())
+
+// Wave priority of the small kernels on the step's side chains (DNN tower, statistics, loss): they share
+// the chip with a matrix-bound CIN kernel whose waves issue back to back, and each of them gates the next
+// node of its chain.  (A build-time knob for A/B runs; 0 = leave the default.)
+#ifndef XDFM_SIDE_PRIO
+#define XDFM_SIDE_PRIO 0
+#endif
+#if defined(__HIP__)
+__device__ __forceinline__ void side_chain_priority() {
+#if XDFM_SIDE_PRIO
+  __builtin_amdgcn_s_setprio(XDFM_SIDE_PRIO);
+#endif
+}
+#endif

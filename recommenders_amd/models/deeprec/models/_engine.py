@@ -316,8 +316,15 @@ class XDeepFMEngine(object):
         self._split = {}
         self._fused_pool = set()
         self.split_dw = os.environ.get("XDFM_SPLIT_DW", "1") != "0"
+        # the side work of backward() on two streams (what the large kernels wait for | the rest)
+        self.side_split = os.environ.get("XDFM_SIDE_SPLIT", "1") != "0"
+        self._dnn_stream2 = None
+        self.main_first = os.environ.get("XDFM_MAIN_FIRST", "1") != "0"
+        self.defer_dw = os.environ.get("XDFM_DEFER_DW", "1") != "0"
         self.serial_plan = False  # bench.py's per-kernel timing: the id sort on the main stream
         self._late_event = None
+        self._late_event2 = None
+        self._late_work = None
         self._fold_dx = False
         self.overlap_dnn = self.overlap_dnn_wanted(hp) and not self.bf16
         if self.bf16:
@@ -854,7 +861,11 @@ class XDeepFMEngine(object):
         dnn_done = None
         if self.overlap_dnn:
             # fork: the DNN tower starts on its stream as soon as emb_out is there
-            side = self._branch_stream()
+            if self._dnn_stream is None:
+                self._dnn_stream = torch.cuda.Stream(device=self.device)
+            side = self._dnn_stream
+            emb_ready = torch.cuda.Event()
+            emb_ready.record(torch.cuda.current_stream(self.device))
             # d_emb without a clear and without a second array: the CIN layer whose backward runs
             # first writes it, the one that runs last folds the DNN tower's gradient in
             self._fold_dx = bool(with_grad and hp.use_CIN_part and not self.fast_d and not self.cross_path
@@ -863,15 +874,23 @@ class XDeepFMEngine(object):
                                          or k in self._fused_pool
                                          for k, (_, _, nh) in enumerate(cin_shapes(hp)))
                                  and self._dnn_plain() and os.environ.get("XDFM_FOLD_DX", "1") != "0")
-            with torch.cuda.stream(side):
-                self._dnn_forward(B)
-                if with_grad:
-                    if not self._fold_dx:
+            def fork_tower():
+                side.wait_event(emb_ready)
+                with torch.cuda.stream(side):
+                    self._dnn_forward(B)
+                    if with_grad and not self._fold_dx:
                         ws["d_emb"][:B].zero_()  # the CIN backward accumulates into it
-                    if self.early_reg:
+                    done = torch.cuda.Event()
+                    done.record(side)
+                    # behind the join's event: the regularisation statistics gate nothing of the forward pass
+                    if with_grad and self.early_reg:
                         self._reg_loss_early()
-                dnn_done = torch.cuda.Event()
-                dnn_done.record(side)
+                return done
+
+            # main_first: the CIN kernels are issued (captured) ahead of the tower's, so that the runtime keeps
+            # the chain of large kernels on one hardware queue (a replayed graph continues a queue with the
+            # FIRST node captured behind a node; a hop to another queue costs ~10 us against ~3)
+            dnn_done = fork_tower if self.main_first else fork_tower()
         # training step with a CIN: head, logit, loss, d(loss)/d(logit) and d_pooled in one launch
         fused_head = bool(hp.use_CIN_part and with_grad and with_loss)
         self._head_fused = fused_head
@@ -907,6 +926,8 @@ class XDeepFMEngine(object):
                         # the rest of the forward pass rides in the last layer's launch (one operation
                         # fewer on the step's chain): it needs the DNN tower's output first
                         if dnn_done is not None:
+                            if callable(dnn_done):
+                                dnn_done = dnn_done()
                             torch.cuda.current_stream(self.device).wait_event(dnn_done)
                             dnn_done = None
                         elif hp.use_DNN_part and not self.overlap_dnn:
@@ -994,6 +1015,8 @@ class XDeepFMEngine(object):
                 )
             self._done(ev)
         if dnn_done is not None:
+            if callable(dnn_done):
+                dnn_done = dnn_done()
             torch.cuda.current_stream(self.device).wait_event(dnn_done)
         elif hp.use_DNN_part:
             self._dnn_forward(B)
@@ -1218,11 +1241,12 @@ class XDeepFMEngine(object):
         self._done(ev)
 
     # ---------------------------------------------------------------- backward
-    def backward(self, batch, advance=False):
+    def backward(self, batch, advance=False, defer_late=False):
         """Gradients of the data loss w.r.t. every dense parameter (into dense_grad) and
         w.r.t. emb_out (into ws['d_emb'] [+ d_emb2()]).  forward(with_grad=True) must have run.
         advance: also move the optimizer's step scalars on (beside the backward pass when the DNN
-        tower has its own stream); returns True when that was done."""
+        tower has its own stream); returns True when that was done.
+        defer_late: the caller runs run_late_work() once it has issued the table gradient (train_step)."""
         hp, lib, ws, st = self.hp, self.lib, self.ws, self._stream()
         B, F, D = batch.B, self.F, self.D
         g = ws["g_logit"]
@@ -1231,53 +1255,92 @@ class XDeepFMEngine(object):
         wrote_d_emb = False
         fused_head = bool(hp.use_CIN_part and getattr(self, "_head_fused", False))
 
-        def small_grads(part):
+        def small_grads(part, stream):
             """lin_b and CIN head weight gradients: read g and pooled only."""
             if hp.use_Linear_part:
                 # d lin_b = sum_b g  -- the bias row of a [1]->[1] identity layer
                 _lib.check(
                     lib.xdfm_dense_bwd(_ptr(g), _ptr(self.views["lin_b"]), _ptr(g), _ptr(g), B, 1, 1, 0, None,
-                                       0, _ptr(ws["dummy"]), _ptr(gv["lin_b"]), _ptr(part), st)
+                                       0, _ptr(ws["dummy"]), _ptr(gv["lin_b"]), _ptr(part), stream)
                 )
             if hp.use_CIN_part:
                 _lib.check(
                     lib.xdfm_cin_head_bwd(_ptr(ws["pooled"]), _ptr(self.views["cin_w_out"]), _ptr(g), B,
                                           ws["pooled"].shape[1], None if fused_head else _ptr(ws["d_pooled"]),
-                                          _ptr(gv["cin_w_out"]), _ptr(gv["cin_b_out"]), _ptr(part), st)
+                                          _ptr(gv["cin_w_out"]), _ptr(gv["cin_b_out"]), _ptr(part), stream)
                 )
 
         dnn_done = None
         if self.overlap_dnn:
             # fork: everything of the DNN tower but its gradient w.r.t. emb_out runs beside the CIN,
             # and so do the small weight gradients that hang off g_logit
-            side = self._branch_stream()
-            with torch.cuda.stream(side):
-                st = self._stream()
+            if self._dnn_stream is None:
+                self._dnn_stream = torch.cuda.Stream(device=self.device)
+            side = self._dnn_stream
+            head_ready = torch.cuda.Event()
+            head_ready.record(torch.cuda.current_stream(self.device))
+            # What the chain of large kernels waits for comes first on that stream and nothing else does: the
+            # optimizer's scalars (the table update reads them) and the tower's gradient w.r.t. emb_out (the
+            # first CIN layer's input-gradient kernel adds it in).  Everything else that hangs off g_logit --
+            # the loss, the small gradients, the tower's weight gradients: a dozen launches of ~5 us that
+            # wait for room beside kernels which fill the chip (tools/stamp_timeline.py: 100-150 us for the
+            # lot) -- goes to a second stream that only the dense update joins (join_late()).
+            third = bool(self._fold_dx and self.side_split)
+            side_state = {"done": None, "dx_done": None, "forked": False}
+
+            def head_work():
                 if getattr(self, "_loss_deferred", False):
-                    self._finish_loss(B, st)
+                    self._finish_loss(B, self._stream())
                     self._loss_deferred = False
                 if fused_head:
-                    small_grads(ws["part_dnn"])
-                dnn_dx_done = None
-                if self._fold_dx:
-                    self._dnn_backward(B, (ws["d_emb_dnn"], 0), phase="dx")
-                    dnn_dx_done = torch.cuda.Event()
-                    dnn_dx_done.record(side)
-                    self._dnn_backward(B, None, phase="dw")
-                else:
-                    self._dnn_backward(B, (ws["d_emb_dnn"], 0))
-                if advance:
-                    self._advance_step()  # nothing reads the scalars before the join
-                dnn_done = torch.cuda.Event()
-                dnn_done.record(side)
+                    small_grads(ws["part_dnn"], self._stream())
+
+            def fork_side():
+                # (with main_first this runs behind the first CIN kernel of the backward pass: see forward())
+                if side_state["forked"]:
+                    return
+                side_state["forked"] = True
+                side.wait_event(head_ready)
+                with torch.cuda.stream(side):
+                    if third:
+                        if advance:
+                            self._advance_step()
+                    else:
+                        head_work()
+                    if self._fold_dx:
+                        self._dnn_backward(B, (ws["d_emb_dnn"], 0), phase="dx")
+                        side_state["dx_done"] = torch.cuda.Event()
+                        side_state["dx_done"].record(side)
+                        if not third:
+                            self._dnn_backward(B, None, phase="dw")
+                    else:
+                        self._dnn_backward(B, (ws["d_emb_dnn"], 0))
+                    if advance and not third:
+                        self._advance_step()  # nothing reads the scalars before the join
+                    side_state["done"] = torch.cuda.Event()
+                    side_state["done"].record(side)
+                if third:
+                    if self._dnn_stream2 is None:
+                        self._dnn_stream2 = torch.cuda.Stream(device=self.device)
+                    side2 = self._dnn_stream2
+                    side2.wait_event(side_state["dx_done"])  # (the weight gradients read the d_h the chain left)
+                    with torch.cuda.stream(side2):
+                        head_work()
+                        self._dnn_backward(B, None, phase="dw")
+                        self._late_event2 = torch.cuda.Event()
+                        self._late_event2.record(side2)
+
+            if not (self.main_first and hp.use_CIN_part):
+                fork_side()
+            dnn_done = True
             st = self._stream()
             if not fused_head:
-                small_grads(ws["part"])
+                small_grads(ws["part"], st)
                 if not self._fold_dx:
                     d_emb[:B].zero_()
             wrote_d_emb = True  # zeroed beside the forward pass (or just above), or written by the CIN
         else:
-            small_grads(ws["part"])
+            small_grads(ws["part"], st)
             if hp.use_DNN_part:
                 self._dnn_backward(B, (d_emb, 0))
                 wrote_d_emb = True
@@ -1354,6 +1417,8 @@ class XDeepFMEngine(object):
                                                 _ptr(d_xk), _ptr(d_emb), 0 if first_writer else 1,
                                                 _ptr(gv["cin_f_%d" % k]), _ptr(ws["part"]), st)
                     )
+                    if dnn_done is not None:
+                        fork_side()
                     continue
                 Lk, pair_after = L, False
                 if k in self._split:
@@ -1378,7 +1443,8 @@ class XDeepFMEngine(object):
                     add0 = None if first_writer else d_emb
                     add1 = ws["d_emb_dnn"] if (fold and k == 0) else None
                     if add1 is not None:
-                        torch.cuda.current_stream(self.device).wait_event(dnn_dx_done)
+                        fork_side()
+                        torch.cuda.current_stream(self.device).wait_event(side_state["dx_done"])
 
                     def layer_bwd(phases, stream):
                         _lib.check(
@@ -1412,13 +1478,22 @@ class XDeepFMEngine(object):
                         # (latency bound), which only needs d_emb
                         layer_bwd(1, st)
                         pair_bwd()
+                        fork_side()
                         dx_done = torch.cuda.Event()
                         dx_done.record(torch.cuda.current_stream(self.device))
-                        side.wait_event(dx_done)
-                        with torch.cuda.stream(side):
-                            layer_bwd(2, self._stream())
-                            self._late_event = torch.cuda.Event()
-                            self._late_event.record(side)
+
+                        def late_dw(layer_bwd=layer_bwd, dx_done=dx_done):
+                            side.wait_event(dx_done)
+                            with torch.cuda.stream(side):
+                                layer_bwd(2, self._stream())
+                                self._late_event = torch.cuda.Event()
+                                self._late_event.record(side)
+
+                        # main_first: issued behind the table gradient (run_late_work(), from the update)
+                        if defer_late and self.main_first and self.defer_dw:
+                            self._late_work = late_dw
+                        else:
+                            late_dw()
                     else:
                         layer_bwd(3, st)
                         pair_bwd()
@@ -1431,7 +1506,8 @@ class XDeepFMEngine(object):
                 )
             self._done(ev)
         if dnn_done is not None:
-            torch.cuda.current_stream(self.device).wait_event(dnn_done)  # join
+            fork_side()
+            torch.cuda.current_stream(self.device).wait_event(side_state["done"])  # join
             return bool(advance)
         return False
 
@@ -1444,12 +1520,23 @@ class XDeepFMEngine(object):
             _lib.check(self.lib.xdfm_loss_finish(_ptr(self.loss_scratch), B, int(self.mean_count or 0),
                                                  _LOSS[self.hp.loss], _ptr(self.data_loss), st))
 
+    def run_late_work(self):
+        """Issue what backward(defer_late=True) held back (the first layer's filter gradient on the side
+        stream)."""
+        work, self._late_work = self._late_work, None
+        if work is not None:
+            work()
+
     def join_late(self):
-        """Make the current stream wait for the filter gradient that backward() left running on
-        the side stream (dense_grad is complete only after this)."""
-        if self._late_event is not None:
-            torch.cuda.current_stream(self.device).wait_event(self._late_event)
-            self._late_event = None
+        """Make the current stream wait for what backward() left running on the side streams: the first
+        layer's filter gradient, the tower's weight gradients and the loss (dense_grad and data_loss are
+        complete only after this)."""
+        self.run_late_work()
+        for name in ("_late_event", "_late_event2"):
+            ev = getattr(self, name)
+            if ev is not None:
+                torch.cuda.current_stream(self.device).wait_event(ev)
+                setattr(self, name, None)
 
     def d_emb2(self):
         """Second summand of the gradient w.r.t. emb_out (None when d_emb holds all of it)."""
@@ -1511,6 +1598,7 @@ class XDeepFMEngine(object):
             )
         )
         self._done(ev)
+        self.run_late_work()  # (behind the table gradient in issue order: backward(defer_late=True))
         if sparse and self.catchup_on:
             self._rows_stale = True
         first = True  # the first dense_update writes reg_loss, the others accumulate
@@ -1604,7 +1692,7 @@ class XDeepFMEngine(object):
         aged where they are read, nothing has to be prepared a step ahead)."""
         self.plan_async(batch)
         self.forward(batch, with_loss=True, with_grad=True)
-        advanced = self.backward(batch, advance=True)
+        advanced = self.backward(batch, advance=True, defer_late=True)
         if not advanced:
             self._advance_step()
         self.update(batch, True)
