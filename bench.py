@@ -163,7 +163,12 @@ def kernel_models(hp, nnz, uniq):
             add("cin_pooled_bwd_kernel", "hbm", 2.0 * fwd_bytes + 4.0 * B * F * D)
             continue
         nt_total = (L + 15) // 16
-        add("cin_fwd2_mfma_kernel", "mfma", 2.0 * rows * pairs * L + 2.0 * rows * min(F, H) * L)
+        fwd_flops = 2.0 * rows * pairs * L + 2.0 * rows * min(F, H) * L
+        # the masked layer of up to 40 fields runs the unrolled form (csrc/cin_mfma_kernels.hip, fwd_mfma)
+        if masked and D % 4 == 0 and (F + 3) // 4 <= 10 and os.environ.get("XDFM_CIN_FWD_STATIC", "1") != "0":
+            add("cin_fwd_static_kernel<%d>" % ((F + 3) // 4), "mfma", fwd_flops)
+        else:
+            add("cin_fwd2_mfma_kernel", "mfma", fwd_flops)
         nft, nht = (F + 3) // 4, (H + 3) // 4
         S = (L + 3) // 4
         nf = 3 if nft <= 3 else 10
@@ -381,6 +386,10 @@ def main():
         # the forward pass) are switched off here
         eng.split_dw = False
         eng.serial_plan = True
+        if hasattr(eng, "overlap_dnn") and not args.sharded and world == 1:
+            # ... and so is the DNN tower's stream (its kernels and the CIN's stretch each other to twice
+            # their time when they share the chip: tools/stamp_timeline.py)
+            eng.overlap_dnn = eng.early_reg = False
         for i in range(prof_steps):
             eager_step(args.warmup + args.steps + i)
         fence()

@@ -589,6 +589,49 @@ int xdfm_dense_bwd(const float* x, const float* w, const float* y, const float* 
                    int32_t K, int32_t Nout, int32_t act, float* dx, int32_t accumulate_dx,
                    float* dw, float* db, float* part, void* stream);
 
+/* Several weight gradients in one launch: the dw / db halves of xdfm_dense_bwd for up to 8 layers that share
+ * the batch (the tower's layers, the linear bias as a [1] -> [1] layer, the CIN head as [n] -> [1]), over
+ * common row splits, and one second launch that adds the partial sums (fixed order, as xdfm_dense_bwd).
+ * Taken one by one these are a dozen ~5 us launches, each waiting for room beside the kernels that fill the
+ * chip.  x[B,K], y[B,Nout] (the layer's saved output), dy[B,Nout], dw[K,Nout], db[Nout]; part: float scratch
+ * of xdfm_dense_bwd_dw_multi_workspace_floats elements.  No counterpart in the reference (one sess.run). */
+typedef struct xdfm_dw_job {
+  const float* x;
+  const float* y;
+  const float* dy;
+  float* dw;
+  float* db;
+  int32_t K;
+  int32_t Nout;
+  int32_t act;
+  int32_t reserved;
+} xdfm_dw_job;
+int xdfm_dense_bwd_dw_multi_workspace_floats(const xdfm_dw_job* jobs, int32_t n_jobs, int64_t B, size_t* floats);
+int xdfm_dense_bwd_dw_multi(const xdfm_dw_job* jobs, int32_t n_jobs, int64_t B, float* part, void* stream);
+
+/* A plain DNN tower in_dim -> size[0] -> ... -> size[n_hidden-1] -> 1 (xDeepFM.py:473-533 without batch norm,
+ * dropout or softmax; size[0] <= 32, the other widths <= 64, at most 4 hidden layers) as ONE launch per pass:
+ * a row's activations depend on that row alone, so 16 rows go through all layers in one block.
+ *   xdfm_tower_fwd:    h[l][B,size[l]] = act_l(...) for every hidden layer and out[B] (identity output).
+ *   xdfm_tower_bwd_dx: from g[B] = d(loss)/d(out): d_h[l][B,size[l]] (the gradient w.r.t. each hidden output,
+ *                      what the weight-gradient pass takes as dy) and dx[B,in_dim], written or added to.
+ * The same sums as the per-layer calls in another association (fp32, 1e-6). */
+typedef struct xdfm_tower_desc {
+  int32_t n_hidden;
+  int32_t in_dim;
+  int32_t size[4];
+  int32_t act[4];
+  const float* w[4];   /* [in][out] per hidden layer */
+  const float* b[4];
+  const float* w_out;  /* [size[n_hidden-1]] */
+  const float* b_out;  /* [1] */
+  float* h[4];
+  float* d_h[4];       /* xdfm_tower_bwd_dx only */
+} xdfm_tower_desc;
+int xdfm_tower_fwd(const xdfm_tower_desc* desc, const float* x, int64_t B, float* out, void* stream);
+int xdfm_tower_bwd_dx(const xdfm_tower_desc* desc, const float* g, int64_t B, float* dx, int32_t accumulate_dx,
+                      void* stream);
+
 /* The same layer on the bf16 matrix cores (fp32 accumulation; x, w and the upstream gradient are
  * rounded to bf16 on their way into the product: 2e-2 relative bar), for wide layers
  * (BASELINE configs[4]: 2496 -> 1024 -> 512) and the pooled-channel products of the CIN.

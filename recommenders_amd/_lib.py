@@ -68,6 +68,39 @@ class RowAge(ctypes.Structure):
     ]
 
 
+class DwJob(ctypes.Structure):
+    """struct xdfm_dw_job"""
+
+    _fields_ = [
+        ("x", ctypes.c_void_p),
+        ("y", ctypes.c_void_p),
+        ("dy", ctypes.c_void_p),
+        ("dw", ctypes.c_void_p),
+        ("db", ctypes.c_void_p),
+        ("K", ctypes.c_int32),
+        ("Nout", ctypes.c_int32),
+        ("act", ctypes.c_int32),
+        ("reserved", ctypes.c_int32),
+    ]
+
+
+class TowerDesc(ctypes.Structure):
+    """struct xdfm_tower_desc"""
+
+    _fields_ = [
+        ("n_hidden", ctypes.c_int32),
+        ("in_dim", ctypes.c_int32),
+        ("size", ctypes.c_int32 * 4),
+        ("act", ctypes.c_int32 * 4),
+        ("w", ctypes.c_void_p * 4),
+        ("b", ctypes.c_void_p * 4),
+        ("w_out", ctypes.c_void_p),
+        ("b_out", ctypes.c_void_p),
+        ("h", ctypes.c_void_p * 4),
+        ("d_h", ctypes.c_void_p * 4),
+    ]
+
+
 class CinPackJob(ctypes.Structure):
     """struct xdfm_cin_pack_job"""
 
@@ -178,6 +211,10 @@ SIGNATURES = {
     "xdfm_dense_bf16_bwd": [_P, _P, _P, _P, _I64, _I32, _I32, _I32, _P, _I32, _P, _P, _P, _P],
     "xdfm_dense_bwd_workspace_floats": [_I64, _I32, _I32, _PSZ],
     "xdfm_dense_bwd": [_P, _P, _P, _P, _I64, _I32, _I32, _I32, _P, _I32, _P, _P, _P, _P],
+    "xdfm_dense_bwd_dw_multi_workspace_floats": [_P, _I32, _I64, _PSZ],
+    "xdfm_dense_bwd_dw_multi": [_P, _I32, _I64, _P, _P],
+    "xdfm_tower_fwd": [_P, _P, _I64, _P, _P],
+    "xdfm_tower_bwd_dx": [_P, _P, _I64, _P, _I32, _P],
     "xdfm_cin_act_fwd": [_P, _I64, _I32, _I32, _I32, _I32, _P, _P, _I32, _I32, _P],
     "xdfm_cin_act_bwd": [_P, _P, _P, _I32, _I32, _I64, _I32, _I32, _I32, _I32, _P, _P],
     "xdfm_fast_cin_fwd": [_P, _P, _P, _P, _I64, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _P, _P, _I32, _I32, _P],

@@ -626,28 +626,44 @@ __global__ __launch_bounds__(256) void cin_bwd_dx_mfma_kernel(
 // h tiles run from the last to the first: once tile ht is done its rows of the X tile in LDS
 // are dead (also as x0 rows of the masked layer, which needs ft <= ht), so dXk replaces them
 // in place and the kernel needs no LDS beyond the X tiles.
+// The image keeps every h tile's row of f tiles padded to a multiple of kDxRing (zero tiles that are loaded,
+// never multiplied): a tile's slot in the kernel's ring of registers is then its position in the row modulo
+// kDxRing, a compile-time number in the unrolled row, while the stream of loads runs on across rows.
+constexpr int kDxRing = 4;
+__host__ __device__ inline int dx_row_tiles(int ht, int nft, int masked) {
+  return masked ? (ht + 1 < nft ? ht + 1 : nft) : nft;
+}
+__host__ __device__ inline int dx_tiles_padded(int nft, int nht, int masked) {
+  int n = 0;
+  for (int ht = 0; ht < nht; ++ht) n += (dx_row_tiles(ht, nft, masked) + kDxRing - 1) & ~(kDxRing - 1);
+  return n;
+}
+
 template <int S>
 __device__ __forceinline__ void pack_dx_body(const CinDims& c, const float* __restrict__ w, int nft, int nht,
                                              int ntiles, float* __restrict__ wdx, int64_t idx) {
   constexpr int Sp = (S + 3) & ~3;
-  const int64_t total = (int64_t)ntiles * 64 * Sp;
+  const int64_t total = (int64_t)ntiles * 64 * Sp;  // ntiles = dx_tiles_padded()
   if (idx >= total) return;
   const int s = (int)(idx % Sp);
   const int lane = (int)((idx / Sp) & 63);
   int t = (int)(idx / (64 * Sp));
-  // tile order of the kernel: ht descending, ft ascending (masked: ft <= ht)
+  // tile order of the kernel: ht descending, ft ascending (masked: ft <= ht), rows padded
   int ht = nht - 1, ft = 0;
-  for (;; --ht) {
-    const int lim = c.masked ? (ht + 1 < nft ? ht + 1 : nft) : nft;
-    if (t < lim) {
+  bool real = false;
+  for (; ht >= 0; --ht) {
+    const int lim = dx_row_tiles(ht, nft, c.masked);
+    const int plim = (lim + kDxRing - 1) & ~(kDxRing - 1);
+    if (t < plim) {
       ft = t;
+      real = t < lim;
       break;
     }
-    t -= lim;
+    t -= plim;
   }
   const int i = lane & 15, k = lane >> 4;
   const int f = 4 * ft + (i >> 2), h = 4 * ht + (i & 3), n = 4 * s + k;
-  const bool ok = f < c.F && h < c.H && n < c.L && (!c.masked || h > f);
+  const bool ok = real && f < c.F && h < c.H && n < c.L && (!c.masked || h > f);
   wdx[idx] = ok ? w[(int64_t)(f * c.H + h) * cin_ldw(c) + n] : 0.f;
 }
 
@@ -789,17 +805,25 @@ __device__ __forceinline__ void dx2_body(const BwdIn& in, const Dx2Args& ax, int
 #pragma unroll
   for (int ft = 0; ft < NFT; ++ft) acc0[ft] = zero4;
 
+  // The filter image streams through a ring of kDxRing tiles of registers, requested kDxRing - 1 tiles
+  // (~2000 cycles of matrix work) ahead of their use: one tile ahead, every tile waited for the level-2
+  // cache (a third of a wave's cycles: profiles/r02_pmc_sq.txt).  Rows are padded in the image, so the slot
+  // of position ft is ft % kDxRing in every row.
   const f32x4* img = reinterpret_cast<const f32x4*>(wdx) + (size_t)lane * S4;
   const int tlast = ntiles - 1;
-  f32x4 a_cur[S4], a_nxt[S4];
+  constexpr int NPOS = (NFT + kDxRing - 1) & ~(kDxRing - 1);
+  f32x4 ring[kDxRing][S4];
 #pragma unroll
-  for (int q = 0; q < S4; ++q) a_cur[q] = img[q];
-  int t = 0;
+  for (int u = 0; u < kDxRing - 1; ++u)
+#pragma unroll
+    for (int q = 0; q < S4; ++q) ring[u][q] = img[(size_t)(u < tlast ? u : tlast) * 64 * S4 + q];
+  int tp = 0;  // padded index of the row's first tile
   const float* xlane = xs + m0;
   const float* alane = as + g * Tp + m0;
 
   for (int ht = nht - 1; ht >= 0; --ht) {
-    const int lim = c.masked ? (ht + 1 < nft ? ht + 1 : nft) : nft;
+    const int lim = dx_row_tiles(ht, nft, c.masked);
+    const int plim = (lim + kDxRing - 1) & ~(kDxRing - 1);
     f32x4 xkv[4];  // [r], component rt: xk[m0+rt][4ht+r]
 #pragma unroll
     for (int r = 0; r < 4; ++r) xkv[r] = *reinterpret_cast<const f32x4*>(xlane + (4 * ht + r) * Tp);
@@ -818,11 +842,14 @@ __device__ __forceinline__ void dx2_body(const BwdIn& in, const Dx2Args& ax, int
         }
     };
 #pragma unroll
-    for (int ft = 0; ft < NFT; ++ft) {
-      if (ft < lim) {
-        const int tn = t + 1 < tlast ? t + 1 : tlast;  // next tile's image (clamped reload at the end)
+    for (int ft = 0; ft < NPOS; ++ft) {
+      if (ft < plim) {
+        const int tn = tp + ft + kDxRing - 1 < tlast ? tp + ft + kDxRing - 1 : tlast;  // (clamped at the end)
 #pragma unroll
-        for (int q = 0; q < S4; ++q) a_nxt[q] = img[(size_t)tn * 64 * S4 + q];
+        for (int q = 0; q < S4; ++q) ring[(ft + kDxRing - 1) % kDxRing][q] = img[(size_t)tn * 64 * S4 + q];
+      }
+      if (ft < NFT && ft < lim) {
+        const f32x4(&a_cur)[S4] = ring[ft % kDxRing];
         x0v[ft & 1] = *reinterpret_cast<const f32x4*>(alane + 4 * ft * Tp);
         if constexpr (CUT) {
           f32x4 up = zero4;
@@ -840,14 +867,12 @@ __device__ __forceinline__ void dx2_body(const BwdIn& in, const Dx2Args& ax, int
             for (int rt = 0; rt < RT; ++rt)
               U[ft & 1][rt] = mfma(a_cur[s >> 2][s & 3], dc[s][rt], s == 0 ? zero4 : U[ft & 1][rt]);
         }
-#pragma unroll
-        for (int q = 0; q < S4; ++q) a_cur[q] = a_nxt[q];
-        ++t;
       }
       // the previous tile is folded in while this one multiplies
-      if (ft >= 1 && ft - 1 < lim) fold(ft - 1, U[(ft - 1) & 1], x0v[(ft - 1) & 1]);
+      if (ft >= 1 && ft - 1 < NFT && ft - 1 < lim) fold(ft - 1, U[(ft - 1) & 1], x0v[(ft - 1) & 1]);
     }
-    if (NFT - 1 < lim) fold(NFT - 1, U[(NFT - 1) & 1], x0v[(NFT - 1) & 1]);
+    if (NPOS == NFT && NFT - 1 < lim) fold(NFT - 1, U[(NFT - 1) & 1], x0v[(NFT - 1) & 1]);
+    tp += plim;
     // add the 4 fi groups: after the two swaps lane group g holds the total of r = g
     f32x4 tot;
 #pragma unroll
@@ -1372,7 +1397,7 @@ int fwd_mfma(const CinDims& c, const float* x0, const float* xk, const float* w,
 static size_t wpk_region_floats(int F, int H, int L) {
   const int nft = (F + 3) / 4, nht = (H + 3) / 4, Hp = (H + 3) & ~3, S = (L + 3) / 4;
   const size_t old_img = (size_t)nft * 4 * Hp * (4 * smax_for(S) + 1);
-  const size_t new_img = (size_t)nft * nht * 64 * (S <= 3 ? 4 : 8);  // S <= 5 only
+  const size_t new_img = (size_t)dx_tiles_padded(nft, nht, 0) * 64 * (S <= 3 ? 4 : 8);  // S <= 5 only
   return ((old_img > new_img ? old_img : new_img) + 3) & ~(size_t)3;
 }
 
@@ -1439,7 +1464,7 @@ int bwd_mfma(const CinDims& c, const float* x0, const float* xk, const float* w,
     // filter gradient only
   } else if (nft <= 10 && S <= 5 && dx2_lds <= kLdsLimit) {
     const int SPB = 256 / c.D;
-    const int ntiles = n_tiles(nft, nht, c.masked);
+    const int ntiles = dx_tiles_padded(nft, nht, c.masked);
     const int n_dx = (int)((c.B + SPB - 1) / SPB);
     const Dx2Args ax{w ? wpk : packed_dx, d_xk, d_x0, SPB, ntiles, add0, add1};
     const int SS = S <= 3 ? 3 : 5;
@@ -1593,7 +1618,7 @@ void pack_floats(int64_t B, int F, int H, int D, int L, int masked, size_t* fwd_
   // one image serves both roles of the layer's inputs: shared_x only makes the LDS need smaller
   if (dx2_applies(F, H, L, false)) {
     const int nft = (F + 3) / 4, nht = (H + 3) / 4, S = (L + 3) / 4;
-    *bwd_floats = (size_t)n_tiles(nft, nht, masked) * 64 * (S <= 3 ? 4 : 8);
+    *bwd_floats = (size_t)dx_tiles_padded(nft, nht, masked) * 64 * (S <= 3 ? 4 : 8);
   }
 }
 
@@ -1628,7 +1653,7 @@ int pack_all(const xdfm_cin_pack_job* jobs, int n_jobs, int64_t B, int D, hipStr
     if (in.bwd_image) {
       J.nft = (in.F + 3) / 4;
       J.nht = (in.H + 3) / 4;
-      J.ntiles = n_tiles(J.nft, J.nht, in.masked);
+      J.ntiles = dx_tiles_padded(J.nft, J.nht, in.masked);
       J.SS = (in.L + 3) / 4 <= 3 ? 3 : 5;
       J.dx_blocks = (unsigned)(((int64_t)J.ntiles * 64 * ((J.SS + 3) & ~3) + 255) / 256);
     }

@@ -325,6 +325,8 @@ class XDeepFMEngine(object):
         self._late_event = None
         self._late_event2 = None
         self._late_work = None
+        self._late_multi = None
+        self.dw_multi_tail = os.environ.get("XDFM_DW_MULTI_TAIL", "1") != "0"
         self._fold_dx = False
         self.overlap_dnn = self.overlap_dnn_wanted(hp) and not self.bf16
         if self.bf16:
@@ -681,6 +683,10 @@ class XDeepFMEngine(object):
             _lib.check(self.lib.xdfm_dense_bwd_workspace_floats(B, ws["pooled"].shape[1], 1, ctypes.byref(sz)))
             dnn_part_floats = max(dnn_part_floats, sz.value)
         buf("part_dnn", dnn_part_floats)
+        if self._tower_fused():
+            jobs = self._dw_jobs(ws, B, sizes_only=True)
+            _lib.check(self.lib.xdfm_dense_bwd_dw_multi_workspace_floats(jobs, len(jobs), B, ctypes.byref(sz)))
+            buf("part_multi", max(sz.value, 1))
         buf("pieces", 2 * (nnz // 64 + 1) * (D + 2))
         if self.overlap_dnn:
             # the DNN tower's gradient w.r.t. emb_out, written beside the CIN backward and added to
@@ -1123,6 +1129,11 @@ class XDeepFMEngine(object):
         """DNN tower (xDeepFM.py:473-533) on the current stream."""
         hp, lib, ws, st = self.hp, self.lib, self.ws, self._stream()
         ev = self._mark("dnn_fwd")
+        if self._tower_fused():
+            _lib.check(lib.xdfm_tower_fwd(ctypes.byref(self._tower_desc()), _ptr(ws["emb_out"]), B,
+                                          _ptr(ws["dnn_out"]), st))
+            self._done(ev)
+            return
         x, K = ws["emb_out"], self.F * self.D
         for k, size in enumerate(hp.layer_sizes):
             act = _ACT[hp.activation[k]]
@@ -1161,6 +1172,67 @@ class XDeepFMEngine(object):
         )
         self._done(ev)
 
+    def _tower_fused(self):
+        """The tower runs as one launch per pass (xdfm_tower_fwd / xdfm_tower_bwd_dx) and the step's small
+        weight gradients as one multi-job launch: fp32, no batch norm / dropout / softmax, 1..4 hidden layers,
+        the first at most 32 wide, the others at most 64."""
+        hp = self.hp
+        if not hp.use_DNN_part or self.bf16 or os.environ.get("XDFM_TOWER_FUSED", "1") == "0":
+            return False
+        sizes = [int(v) for v in hp.layer_sizes]
+        return bool(1 <= len(sizes) <= 4 and sizes[0] <= 32 and max(sizes) <= 64 and not self.use_dropout
+                    and not self.use_bn and all(_ACT[a] != _SOFTMAX for a in hp.activation[:len(sizes)]))
+
+    def _tower_desc(self):
+        """struct xdfm_tower_desc over the current workspace (cached until it is re-allocated)."""
+        hit = getattr(self, "_tower_cache", None)
+        if hit is not None and hit[0] == self._ws_token:
+            return hit[1]
+        hp, ws = self.hp, self.ws
+        d = _lib.TowerDesc()
+        d.n_hidden, d.in_dim = len(hp.layer_sizes), self.F * self.D
+        for k, size in enumerate(hp.layer_sizes):
+            d.size[k], d.act[k] = int(size), _ACT[hp.activation[k]]
+            d.w[k], d.b[k] = self.views["dnn_w_%d" % k].data_ptr(), self.views["dnn_b_%d" % k].data_ptr()
+            d.h[k], d.d_h[k] = ws["h_%d" % k].data_ptr(), ws["d_h_%d" % k].data_ptr()
+        d.w_out, d.b_out = self.views["dnn_w_out"].data_ptr(), self.views["dnn_b_out"].data_ptr()
+        self._tower_cache = (self._ws_token, d)
+        return d
+
+    def _dw_jobs(self, ws, B, sizes_only=False, head=True):
+        """xdfm_dw_job array: the tower's layers, then (head) the linear bias and the CIN head."""
+        hp = self.hp
+        sizes = [self.F * self.D] + [int(v) for v in hp.layer_sizes]
+        n_layers = len(hp.layer_sizes)
+        head = bool(head and hp.use_Linear_part and hp.use_CIN_part)
+        n = n_layers + 1 + (2 if head else 0)
+        jobs = (_lib.DwJob * n)()
+        final_len = ws["pooled"].shape[1] if hp.use_CIN_part else 1
+        dims = [(sizes[k], sizes[k + 1], _ACT[hp.activation[k]]) for k in range(n_layers)] + [(sizes[-1], 1, 0)]
+        if head:
+            dims += [(1, 1, 0), (final_len, 1, 0)]
+        for q, (K, Nout, act) in enumerate(dims):
+            jobs[q].K, jobs[q].Nout, jobs[q].act = K, Nout, act
+        if sizes_only:
+            return jobs
+        gv, g = self.grad_views, ws["g_logit"]
+        acts = [ws["emb_out"]] + [ws["h_%d" % k] for k in range(n_layers)]
+        for k in range(n_layers):
+            J = jobs[k]
+            J.x, J.y, J.dy = acts[k].data_ptr(), acts[k + 1].data_ptr(), ws["d_h_%d" % k].data_ptr()
+            J.dw, J.db = gv["dnn_w_%d" % k].data_ptr(), gv["dnn_b_%d" % k].data_ptr()
+        J = jobs[n_layers]
+        J.x, J.y, J.dy = acts[-1].data_ptr(), ws["dnn_out"].data_ptr(), g.data_ptr()
+        J.dw, J.db = gv["dnn_w_out"].data_ptr(), gv["dnn_b_out"].data_ptr()
+        if head:
+            J = jobs[n_layers + 1]  # d lin_b = sum_b g: the bias row of a [1] -> [1] identity layer
+            J.x = J.y = J.dy = g.data_ptr()
+            J.dw, J.db = ws["dummy"].data_ptr(), gv["lin_b"].data_ptr()
+            J = jobs[n_layers + 2]  # the CIN head as [n] -> [1] with dy = g
+            J.x, J.y, J.dy = ws["pooled"].data_ptr(), g.data_ptr(), g.data_ptr()
+            J.dw, J.db = gv["cin_w_out"].data_ptr(), gv["cin_b_out"].data_ptr()
+        return jobs
+
     def _dnn_plain(self):
         """No dropout, batch norm or softmax in the tower: its backward splits into an input-gradient
         chain and the weight gradients."""
@@ -1168,11 +1240,13 @@ class XDeepFMEngine(object):
         return not (self._dropout_live or self.use_bn or any(_ACT[hp.activation[k]] == _SOFTMAX
                                                               for k in range(len(hp.layer_sizes))))
 
-    def _dnn_backward(self, B, first_layer_dx, phase="all"):
+    def _dnn_backward(self, B, first_layer_dx, phase="all", head_jobs=False):
         """Backward of the DNN tower on the current stream.  first_layer_dx: (buffer, accumulate)
         for the gradient w.r.t. emb_out, None to skip it.  phase (plain towers only): "dx" = the
         chain of input gradients down to emb_out alone, "dw" = the weight / bias gradients alone
-        (after "dx": they read the d_h the chain left)."""
+        (after "dx": they read the d_h the chain left).  head_jobs: the linear bias and the CIN head's
+        weight gradients ride in the same multi-job launch (fused towers; sets self._head_jobs_done)."""
+        self._head_jobs_done = False
         hp, lib, ws, st = self.hp, self.lib, self.ws, self._stream()
         g, gv = ws["g_logit"], self.grad_views
         ev = self._mark("dnn_bwd")
@@ -1181,6 +1255,16 @@ class XDeepFMEngine(object):
         acts = [ws["emb_out"]] + [ws["h_%d" % k] for k in range(n_layers)]
         d_acts = [None] + [ws["d_h_%d" % k] for k in range(n_layers)]
         want_dx, want_dw = phase != "dw", phase != "dx"
+        if self._tower_fused() and (first_layer_dx is not None or phase == "dw"):
+            if want_dx:
+                dx, acc = first_layer_dx
+                _lib.check(lib.xdfm_tower_bwd_dx(ctypes.byref(self._tower_desc()), _ptr(g), B, _ptr(dx), int(acc), st))
+            if want_dw:
+                jobs = self._dw_jobs(ws, B, head=head_jobs)
+                _lib.check(lib.xdfm_dense_bwd_dw_multi(jobs, len(jobs), B, _ptr(ws["part_multi"]), st))
+                self._head_jobs_done = len(jobs) > len(hp.layer_sizes) + 1
+            self._done(ev)
+            return
         if phase != "all":
             x_in, K_in = acts[-1], sizes[-1]
             layers = [(x_in, self.views["dnn_w_out"], ws["dnn_out"], g, K_in, 1, 0, d_acts[-1], 0,
@@ -1295,6 +1379,11 @@ class XDeepFMEngine(object):
                 if fused_head:
                     small_grads(ws["part_dnn"], self._stream())
 
+            def multi_dw():
+                self._dnn_backward(B, None, phase="dw", head_jobs=True)
+                if not self._head_jobs_done:
+                    small_grads(ws["part_dnn"], self._stream())
+
             def fork_side():
                 # (with main_first this runs behind the first CIN kernel of the backward pass: see forward())
                 if side_state["forked"]:
@@ -1325,8 +1414,19 @@ class XDeepFMEngine(object):
                     side2 = self._dnn_stream2
                     side2.wait_event(side_state["dx_done"])  # (the weight gradients read the d_h the chain left)
                     with torch.cuda.stream(side2):
-                        head_work()
-                        self._dnn_backward(B, None, phase="dw")
+                        if fused_head and self._tower_fused():
+                            if getattr(self, "_loss_deferred", False):
+                                self._finish_loss(B, self._stream())
+                                self._loss_deferred = False
+                            if self.dw_multi_tail and defer_late:
+                                # the small weight gradients as one launch on the chain's own stream behind
+                                # the table gradient, where that stream has slack (run_late_work())
+                                self._late_multi = multi_dw
+                            else:
+                                multi_dw()
+                        else:
+                            head_work()
+                            self._dnn_backward(B, None, phase="dw")
                         self._late_event2 = torch.cuda.Event()
                         self._late_event2.record(side2)
 
@@ -1524,6 +1624,9 @@ class XDeepFMEngine(object):
         """Issue what backward(defer_late=True) held back (the first layer's filter gradient on the side
         stream)."""
         work, self._late_work = self._late_work, None
+        if work is not None:
+            work()
+        work, self._late_multi = self._late_multi, None
         if work is not None:
             work()
 
