@@ -211,6 +211,8 @@ struct Staging {
   int64_t lo = 0, hi = 0; // the samples of the batch this piece holds
   // per-sample scratch: running count per field (reference: dnn_feat_dic, :178-185)
   std::vector<int64_t> cnt, stamp;                        // fields inside [0, F)
+  std::vector<int64_t> f_feat, f_row, f_col;              // one line's tokens (parse_line_fast)
+  std::vector<float> f_val;
   std::vector<std::pair<int64_t, int64_t>> field_count;   // any other field index
   int err_code = 0;
   std::string err;
@@ -330,6 +332,15 @@ struct xdfm_ffm_reader {
   std::vector<xdfm::Span> lines;
   int threads = 1;
   std::unique_ptr<Pool> pool;
+  // Line index: positions of the '\n's of the stretch [.., idx_pos) that no batch has consumed yet, found by
+  // all threads at once, a stretch of the file at a time (finding 8192 line ends with one thread took as long
+  // as parsing them with sixteen).  Only for files without any '\r' (checked once when the file is opened):
+  // universal newlines also end a line at a bare '\r', which the one-thread scan below still serves.
+  bool plain_newlines = false;
+  std::vector<uint64_t> nl;                   // ascending
+  size_t nl_head = 0;                         // first not yet consumed
+  size_t idx_pos = 0;                         // first byte not yet indexed
+  std::vector<std::vector<uint64_t>> nl_part;  // per thread
 };
 
 extern "C" int xdfm_ffm_open(const char* path, int64_t field_count, int64_t feature_count,
@@ -370,6 +381,18 @@ extern "C" int xdfm_ffm_open(const char* path, int64_t field_count, int64_t feat
     r->threads = t < 1 ? 1 : (t > 16 ? 16 : t);
   }
   r->pool.reset(new Pool(r->threads));
+  if (r->size > 0) {
+    // any '\r' at all?  (each thread looks through its part of the file)
+    const int T = r->threads;
+    std::vector<uint8_t> found((size_t)T, 0);
+    const size_t per = (r->size + (size_t)T - 1) / (size_t)T;
+    r->pool->run(T, [r, per, &found](int t) {
+      const size_t lo = std::min(r->size, (size_t)t * per), hi = std::min(r->size, lo + per);
+      if (hi > lo && memchr(r->data + lo, '\r', hi - lo)) found[(size_t)t] = 1;
+    });
+    r->plain_newlines = true;
+    for (uint8_t f : found) r->plain_newlines = r->plain_newlines && !f;
+  }
   *out = r;
   return XDFM_OK;
 }
@@ -385,10 +408,126 @@ extern "C" int xdfm_ffm_close(xdfm_ffm_reader* r) {
 
 namespace {
 
+// The canonical line -- `label f:i:v f:i:v ...` with single separators, no impression id, plain decimal
+// literals ([+-]digits[.digits], at most 15 significant digits: the case in which mantissa / 10^k is the
+// correctly rounded double, as in parse_py_float) and every field inside [1, FIELD_COUNT] -- in ONE pass over
+// its bytes: no per-token memchr, no spans, the tokens collected in the piece's scratch and appended in bulk.
+// Returns false BEFORE anything is appended when the line is anything else; parse_line then takes it through
+// the general path (same results, same messages).
+inline bool fast_number(const char*& p, const char* e, char stop, double* out) {
+  static const double kPow10[] = {1e0,  1e1,  1e2,  1e3,  1e4,  1e5,  1e6,  1e7,  1e8,  1e9,  1e10, 1e11,
+                                  1e12, 1e13, 1e14, 1e15, 1e16, 1e17, 1e18, 1e19, 1e20, 1e21, 1e22};
+  const char* q = p;
+  bool neg = false;
+  if (q < e && (*q == '+' || *q == '-')) neg = (*q++ == '-');
+  unsigned long long mant = 0;
+  int nd = 0, frac = 0;
+  bool any = false;
+  while (q < e && (unsigned)(*q - '0') <= 9u) {
+    mant = mant * 10 + (unsigned)(*q - '0');
+    if (mant != 0) ++nd;
+    any = true;
+    ++q;
+  }
+  if (q < e && *q == '.') {
+    ++q;
+    while (q < e && (unsigned)(*q - '0') <= 9u) {
+      mant = mant * 10 + (unsigned)(*q - '0');
+      if (mant != 0) ++nd;
+      any = true;
+      ++frac;
+      ++q;
+    }
+  }
+  if (!any || nd > 15 || frac > 22 || (q < e && *q != stop)) return false;
+  const double v = (double)mant / kPow10[frac];
+  *out = neg ? -v : v;
+  p = q;
+  return true;
+}
+
+inline bool fast_index(const char*& p, const char* e, int64_t* out) {
+  const char* q = p;
+  unsigned long long acc = 0;
+  while (q < e && (unsigned)(*q - '0') <= 9u) {
+    acc = acc * 10 + (unsigned)(*q - '0');
+    ++q;
+  }
+  if (q == p || q - p > 18 || q >= e || *q != ':') return false;
+  *out = (int64_t)acc;
+  p = q + 1;
+  return true;
+}
+
+bool parse_line_fast(const xdfm_ffm_reader* r, Staging& st, Span line, int64_t sample, int64_t ln) {
+  using namespace xdfm;
+  if (line.empty() || r->col_sep == ':' || (unsigned)(r->col_sep - '0') <= 9u || r->col_sep == '.' ||
+      r->col_sep == '+' || r->col_sep == '-')
+    return false;
+  if (memchr(line.b, r->id_sep, (size_t)(line.e - line.b))) return false;
+  const char* p = line.b;
+  const char* const e = line.e;
+  double label;
+  if (!fast_number(p, e, r->col_sep, &label)) return false;
+  if ((int64_t)st.cnt.size() != r->F) {
+    st.cnt.assign((size_t)r->F, 0);
+    st.stamp.assign((size_t)r->F, -1);
+  }
+  st.f_feat.clear();
+  st.f_row.clear();
+  st.f_col.clear();
+  st.f_val.clear();
+  const int64_t epoch = ln;
+  int64_t prev_row = st.dnn_row.empty() ? -1 : st.dnn_row.back();
+  int64_t prev_col = st.dnn_col.empty() ? -1 : st.dnn_col.back();
+  bool in_order = true;
+  int64_t width = 0;
+  while (p < e) {
+    ++p;  // the separator fast_number stopped at
+    int64_t field, feat;
+    double val;
+    if (!fast_index(p, e, &field) || !fast_index(p, e, &feat) || !fast_number(p, e, r->col_sep, &val)) return false;
+    field -= 1;
+    if (field < 0 || field >= r->F) return false;
+    int64_t col = 0;
+    if (st.stamp[(size_t)field] == epoch) {
+      col = ++st.cnt[(size_t)field];
+    } else {
+      st.stamp[(size_t)field] = epoch;
+      st.cnt[(size_t)field] = 0;
+    }
+    const int64_t row = sample * r->F + field;
+    if (row < prev_row || (row == prev_row && col < prev_col)) in_order = false;
+    prev_row = row;
+    prev_col = col;
+    st.f_feat.push_back(feat - 1);
+    st.f_row.push_back(row);
+    st.f_col.push_back(col);
+    st.f_val.push_back((float)val);
+    if (col + 1 > width) width = col + 1;
+  }
+  // the line is canonical: commit
+  st.imp_off.push_back((int64_t)st.imp_chars.size());
+  st.imp_present.push_back(0);
+  st.labels.push_back((float)label);
+  const size_t k = st.f_feat.size();
+  st.tok_sample.insert(st.tok_sample.end(), k, sample);
+  st.tok_feat.insert(st.tok_feat.end(), st.f_feat.begin(), st.f_feat.end());
+  st.tok_val.insert(st.tok_val.end(), st.f_val.begin(), st.f_val.end());
+  st.dnn_row.insert(st.dnn_row.end(), st.f_row.begin(), st.f_row.end());
+  st.dnn_col.insert(st.dnn_col.end(), st.f_col.begin(), st.f_col.end());
+  if (!in_order) st.in_order = false;
+  if (width > st.dnn_width) st.dnn_width = width;
+  return true;
+}
+
 // one sample (1-based line number ln, index `sample` in the batch); appends to st
 int parse_line(const xdfm_ffm_reader* r, Staging& st, Span line, int64_t sample, int64_t ln) {
   using namespace xdfm;
   line = strip(line);
+  if (parse_line_fast(r, st, line, sample, ln)) return XDFM_OK;
+  // (a failed fast attempt may have stamped fields with this line's epoch: start the counts afresh)
+  std::fill(st.stamp.begin(), st.stamp.end(), -1);
   // words = line.split(ID_spliter); impression id only when len(words) == 2
   const char* first_sep = line.empty() ? nullptr : (const char*)memchr(line.b, r->id_sep, (size_t)(line.e - line.b));
   int seps = first_sep ? 1 : 0;
@@ -520,6 +659,49 @@ extern "C" int xdfm_ffm_next(xdfm_ffm_reader* r, int64_t batch_size, xdfm_ffm_ba
   // 1. the next batch_size lines (universal newlines)
   r->lines.clear();
   const char* end = r->data + r->size;
+  if (r->plain_newlines) {
+    while ((int64_t)r->lines.size() < batch_size && r->pos < r->size) {
+      if (r->nl_head == r->nl.size() && r->idx_pos < r->size) {
+        // index the next stretch: what the lines still wanted should weigh (by the lines read so far, 512
+        // bytes each before there are any) and a quarter more, 4 MiB per thread at most
+        r->nl.clear();
+        r->nl_head = 0;
+        const int T = r->threads;
+        const size_t want = (size_t)(batch_size - (int64_t)r->lines.size());
+        const size_t avg = r->line_no > 0 ? r->pos / (size_t)r->line_no + 16 : 512;
+        size_t len = std::max<size_t>(want * avg + want * avg / 4, (size_t)1 << 16);
+        len = std::min(len, (size_t)T << 22);
+        const size_t lo0 = r->idx_pos, hi0 = std::min(r->size, lo0 + len);
+        if ((int)r->nl_part.size() < T) r->nl_part.resize((size_t)T);
+        const size_t per = (hi0 - lo0 + (size_t)T - 1) / (size_t)T;
+        r->pool->run(T, [r, lo0, hi0, per](int t) {
+          std::vector<uint64_t>& out = r->nl_part[(size_t)t];
+          out.clear();
+          const size_t lo = std::min(hi0, lo0 + (size_t)t * per), hi = std::min(hi0, lo + per);
+          const char* q = r->data + lo;
+          const char* const qe = r->data + hi;
+          while (q < qe) {
+            const char* e = (const char*)memchr(q, '\n', (size_t)(qe - q));
+            if (!e) break;
+            out.push_back((uint64_t)(e - r->data));
+            q = e + 1;
+          }
+        });
+        for (int t = 0; t < T; ++t) r->nl.insert(r->nl.end(), r->nl_part[(size_t)t].begin(), r->nl_part[(size_t)t].end());
+        r->idx_pos = hi0;
+      }
+      const char* b = r->data + r->pos;
+      if (r->nl_head < r->nl.size()) {
+        const char* e = r->data + r->nl[r->nl_head++];
+        r->pos = (size_t)(e - r->data) + 1;
+        r->lines.push_back(Span{b, e});
+      } else if (r->idx_pos >= r->size) {
+        r->pos = r->size;  // the last line has no newline
+        r->lines.push_back(Span{b, end});
+      }
+      // (else: a stretch without a newline was indexed; the loop indexes the next one)
+    }
+  } else
   while ((int64_t)r->lines.size() < batch_size && r->pos < r->size) {
     const char* b = r->data + r->pos;
     // the line ends at the first '\n' or '\r': two library scans instead of a byte loop (this
