@@ -281,3 +281,60 @@ def test_parsed_batches_on_disk_serve_a_second_run_without_parsing(tmp_path, mon
     before = set(os.listdir(cache))
     list(other.load_data_from_file(path))
     assert len(set(os.listdir(cache)) - before) == 1
+
+
+@pytest.mark.parametrize("newline", ["\n", "\r\n", "\r"])
+@pytest.mark.parametrize("threads", ["1", "4"])
+def test_one_pass_lines_and_their_fallbacks_equal_the_oracle(tmp_path, monkeypatch, newline, threads):
+    """The reader takes a canonical line (single separators, plain decimals of at most 15 digits, fields in
+    range, no impression id) in one pass over its bytes and everything else through the general path; line
+    ends come from an index built by all threads unless the file holds a '\\r'.  Every kind of line that must
+    fall back, between canonical ones, in files of each newline convention, the last line without one."""
+    monkeypatch.setenv("XDFM_PARSE_THREADS", threads)
+    monkeypatch.setenv("XDFM_FFM_CACHE_MB", "0")
+    rng = np.random.default_rng(11)
+    F, N, B = 6, 1000, 700
+    odd = [
+        "1 1:2:3  4:5:6",                      # two separators in a row (an empty word)
+        "0 1:7:1.5 %imp42",                    # an impression id
+        "1 +1:8:2 2:9:-0.25",                  # a signed index
+        "0 1:1_0:1 2:3:1e-2",                  # underscore, exponent
+        "1 2:4:0.1234567890123456 3:5:1",      # 16 significant digits: not the short form
+        "0 3:6:.5 4:7:5. 5:8:00012.50",        # bare fractions, leading zeros
+        "1 6:9:1:extra 1:2:3",                 # a fourth component (ignored)
+        "  0 1:2:3 ",                          # spaces around the line
+        "1 2:2:1 2:3:1 2:4:1 1:9:1",           # multi-hot field, fields out of order
+        "0 1:999999999999999999:0",            # an 18-digit feature id
+        "1.0 1:2:3\t",                         # a tab at the end (stripped like any whitespace)
+        "-0 1:2:-0",                           # negative zeros
+        "1",                                   # no tokens at all
+    ]
+    lines = []
+    for i in range(2 * B + 123):
+        if i % 7 == 3:
+            lines.append(odd[(i // 7) % len(odd)])
+        else:
+            toks = ["%d:%d:%s" % (f + 1, rng.integers(1, N + 1), "1" if f > 2 else "%.4f" % rng.random())
+                    for f in range(F) if rng.random() > 0.15]
+            lines.append("%d %s" % (i & 1, " ".join(toks)))
+    path = str(tmp_path / "mix.txt")
+    with open(path, "w", newline="") as f:
+        f.write(newline.join(lines))  # (no newline after the last line)
+    hp = make_hp(FEATURE_COUNT=N, FIELD_COUNT=F, batch_size=B)
+    it = FFMTextIterator(hp, None)
+    got = list(it.load_data_from_file(path))
+    exp = list(O.batches(path, B, F, N))
+    assert len(got) == len(exp) == 3 and sum(g[2] for g in got) == len(lines)
+    for (feed, imps, n), (arrays, eimps, en) in zip(got, exp):
+        assert n == en and list(imps) == eimps
+        for k in KEYS:
+            g, e = feed[getattr(it, k)], arrays[k]
+            assert g.dtype == e.dtype and g.shape == e.shape and np.array_equal(g, e), k
+    # a field outside [1, FIELD_COUNT] inside an otherwise canonical line aliases like the reference
+    with open(path, "a", newline="") as f:
+        f.write(newline + "1 1:2:3 %d:4:5 0:6:7" % (F + 2))
+    it2 = FFMTextIterator(hp, None)
+    got = list(it2.load_data_from_file(path))
+    exp = list(O.batches(path, B, F, N))
+    for k in KEYS:
+        assert np.array_equal(got[-1][0][getattr(it2, k)], exp[-1][0][k]), k
