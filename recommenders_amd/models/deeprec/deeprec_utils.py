@@ -88,79 +88,6 @@ def check_type(config):
                 raise TypeError("Parameters {0} must be {1}".format(key, label))
 
 
-# model_type aliases -> keys that must be present (sequential models only: see the
-# quirk note in check_nn_config).
-_SEQ_COMMON = [
-    "item_embedding_dim",
-    "cate_embedding_dim",
-    "max_seq_length",
-    "loss",
-    "method",
-    "user_vocab",
-    "item_vocab",
-    "cate_vocab",
-]
-# the reference tests these in a second if/elif chain (:187-262), so a match
-# here REPLACES whatever the first chain selected.
-_REQUIRED_SEQ = [
-    (
-        ("gru4rec", "GRU4REC", "GRU4Rec"),
-        [
-            "item_embedding_dim",
-            "cate_embedding_dim",
-            "max_seq_length",
-            "loss",
-            "method",
-            "user_vocab",
-            "item_vocab",
-            "cate_vocab",
-            "hidden_size",
-        ],
-    ),
-    (
-        ("caser", "CASER", "Caser"),
-        [
-            "item_embedding_dim",
-            "cate_embedding_dim",
-            "user_embedding_dim",
-            "max_seq_length",
-            "loss",
-            "method",
-            "user_vocab",
-            "item_vocab",
-            "cate_vocab",
-            "T",
-            "L",
-            "n_v",
-            "n_h",
-            "min_seq_length",
-        ],
-    ),
-    (("asvd", "ASVD", "a2svd", "A2SVD"), list(_SEQ_COMMON)),
-    (
-        ("slirec", "sli_rec", "SLI_REC", "Sli_rec"),
-        _SEQ_COMMON + ["attention_size", "hidden_size", "att_fcn_layer_sizes"],
-    ),
-    (
-        ("nextitnet", "next_it_net", "NextItNet", "NEXT_IT_NET"),
-        [
-            "item_embedding_dim",
-            "cate_embedding_dim",
-            "user_embedding_dim",
-            "max_seq_length",
-            "loss",
-            "method",
-            "user_vocab",
-            "item_vocab",
-            "cate_vocab",
-            "dilations",
-            "kernel_size",
-            "min_seq_length",
-        ],
-    ),
-]
-
-
 def check_nn_config(f_config):
     """Validate a flat config: required keys, data format, value types.
 
@@ -169,32 +96,15 @@ def check_nn_config(f_config):
     A config without ``model_type`` raises ``KeyError`` like the reference.
     """
     model_type = f_config["model_type"]
-    # Reference quirk, kept on purpose: the FM/LR/DKN/xDeepFM lists are selected by a
-    # first if/elif chain (:143-186) and then overwritten by a second, independent
-    # chain (:187-262) whose final ``else`` resets the list to [].  Net effect: only
-    # the sequential models have required keys; for xDeepFM a missing key surfaces
-    # later (``KeyError`` on ``data_format`` below, ``AttributeError`` in the model).
-    required = []
-    for aliases, keys in _REQUIRED_SEQ:
-        if model_type in aliases:
-            required = keys
-            break
-
-    for key in required:
-        if key not in f_config:
-            raise ValueError("Parameters {0} must be set".format(key))
-
+    # Reference quirk, kept: the FM / LR / DKN / xDeepFM required-key lists are selected by a first if/elif
+    # chain (:143-186) and then overwritten by a second, independent chain over the sequential models
+    # (:187-262) whose final ``else`` resets the list to [].  Net effect on this path: xDeepFM has NO required
+    # keys; a missing one surfaces later (``KeyError`` on ``data_format`` below, ``AttributeError`` in the
+    # model).  The sequential models' own lists are not restated here: those models are out of scope.
     if model_type in ("exDeepFM", "xDeepFM"):
         if f_config["data_format"] != "ffm":
             raise ValueError(
                 "For xDeepFM model, data format must be 'ffm', but your set is {0}".format(
-                    f_config["data_format"]
-                )
-            )
-    elif model_type in ("dkn", "DKN"):
-        if f_config["data_format"] != "dkn":
-            raise ValueError(
-                "For dkn model, data format must be 'dkn', but your set is {0}".format(
                     f_config["data_format"]
                 )
             )
