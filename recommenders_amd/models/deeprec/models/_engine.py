@@ -321,6 +321,7 @@ class XDeepFMEngine(object):
         self._dnn_stream2 = None
         self.main_first = os.environ.get("XDFM_MAIN_FIRST", "1") != "0"
         self.defer_dw = os.environ.get("XDFM_DEFER_DW", "1") != "0"
+        self.tower_serial = os.environ.get("XDFM_TOWER_SERIAL", "1") != "0"
         self.serial_plan = False  # bench.py's per-kernel timing: the id sort on the main stream
         self._late_event = None
         self._late_event2 = None
@@ -880,10 +881,17 @@ class XDeepFMEngine(object):
                                          or k in self._fused_pool
                                          for k, (_, _, nh) in enumerate(cin_shapes(hp)))
                                  and self._dnn_plain() and os.environ.get("XDFM_FOLD_DX", "1") != "0")
+            serial_tower = bool(self.tower_serial and self._tower_fused())
+            if serial_tower:
+                # the one-launch tower on the chain's own stream, ahead of the CIN (13 us alone; beside the CIN
+                # kernel it finishes 12-25 us AFTER it)
+                self._dnn_forward(B)
+
             def fork_tower():
                 side.wait_event(emb_ready)
                 with torch.cuda.stream(side):
-                    self._dnn_forward(B)
+                    if not serial_tower:
+                        self._dnn_forward(B)
                     if with_grad and not self._fold_dx:
                         ws["d_emb"][:B].zero_()  # the CIN backward accumulates into it
                     done = torch.cuda.Event()
