@@ -612,7 +612,7 @@ __device__ __forceinline__ Pieces pieces_of(const BwdArgs& a, int64_t nchunks) {
 
 template <int VEC, int MODE, bool AGE>
 __global__ __launch_bounds__(256) void embed_bwd_kernel(BwdArgs a) {
-  xdfm::Stamp stamp_(xdfm::kStampEmbedBwd);
+  xdfm::Stamp stamp_(MODE == 0 ? xdfm::kStampEmbedBwd : xdfm::kStampEmbedScatter);
   __shared__ float4 cur_s[AGE ? xdfm::kDriftG : 1];
   int done = 0;
   if (AGE) {
@@ -1005,6 +1005,7 @@ struct GatherArgs {
 
 template <int VEC, bool AGE>
 __global__ __launch_bounds__(256) void gather_rows_kernel(GatherArgs a) {
+  xdfm::Stamp stamp_(xdfm::kStampGatherRows);
   __shared__ float4 cur_s[AGE ? xdfm::kDriftG : 1];
   int done = 0;
   if (AGE) {

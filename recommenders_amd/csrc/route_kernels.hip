@@ -12,11 +12,13 @@
 #include <hip/hip_runtime.h>
 
 #include "xdfm_common.h"
+#include "stamp.h"
 
 namespace {
 
 __global__ void route_keys_kernel(const int64_t* __restrict__ ids, int64_t n, int64_t N, int32_t G, int64_t rpr,
                                   int64_t* __restrict__ keys) {
+  xdfm::Stamp stamp_(xdfm::kStampRoute);
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   int64_t id = ids[i];
@@ -34,6 +36,7 @@ __device__ __forceinline__ bool is_head(const int32_t* __restrict__ sk, int64_t 
 
 __global__ __launch_bounds__(kUT) void route_count_kernel(const int32_t* __restrict__ sk, int64_t n,
                                                           int32_t* __restrict__ block_heads) {
+  xdfm::Stamp stamp_(xdfm::kStampRoute);
   __shared__ int wsum[kUT / 64];
   const int64_t base = (int64_t)blockIdx.x * kUTile;
   int c = 0;
@@ -58,6 +61,7 @@ __global__ __launch_bounds__(kUT) void route_write_kernel(const int32_t* __restr
                                                           const int32_t* __restrict__ block_heads,
                                                           int32_t* __restrict__ slot_sorted, int64_t* __restrict__ inverse,
                                                           int64_t* __restrict__ uniq_rows, int32_t* __restrict__ first_slot) {
+  xdfm::Stamp stamp_(xdfm::kStampRoute);
   __shared__ int red[kUT];
   __shared__ int wtot[kUT / 64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -123,6 +127,7 @@ __global__ __launch_bounds__(256) void route_pad_kernel(const int32_t* __restric
                                                         int64_t cap, int64_t pad_row, int64_t* __restrict__ rows_padded,
                                                         int32_t* __restrict__ slot_sorted_p,
                                                         int64_t* __restrict__ inverse_p, int32_t* __restrict__ counts) {
+  xdfm::Stamp stamp_(xdfm::kStampRoute);
   __shared__ int start[65];
   __shared__ int mx_s;
   if (threadIdx.x == 0) {
@@ -174,6 +179,7 @@ __global__ __launch_bounds__(256) void route_pad_kernel(const int32_t* __restric
 // source's largest per-owner count
 __global__ void route_decode_kernel(const int64_t* __restrict__ raw, int32_t G, int64_t cap,
                                     int64_t* __restrict__ rows, int32_t* __restrict__ src_max) {
+  xdfm::Stamp stamp_(xdfm::kStampRoute);
   const int64_t S = cap + 1;
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= (int64_t)G * S) return;
@@ -250,3 +256,5 @@ extern "C" int xdfm_route_scratch_ints(int64_t n, size_t* ints) {
   *ints = (size_t)((n + kUTile - 1) / kUTile) + 1;
   return XDFM_OK;
 }
+
+XDFM_STAMP_UNIT(stamp_unit_route)

@@ -77,12 +77,14 @@ int stamp_unit_pooled(unsigned long long*);
 int stamp_unit_dnn(unsigned long long*);
 int stamp_unit_optim(unsigned long long*);
 int stamp_unit_sort(unsigned long long*);
+int stamp_unit_route(unsigned long long*);
 }  // namespace xdfm
 
 extern "C" int xdfm_debug_stamps(uint64_t* device_buf) {
   unsigned long long* b = reinterpret_cast<unsigned long long*>(device_buf);
   int (*const units[])(unsigned long long*) = {xdfm::stamp_unit_embed, xdfm::stamp_unit_cin,  xdfm::stamp_unit_pooled,
-                                               xdfm::stamp_unit_dnn,   xdfm::stamp_unit_optim, xdfm::stamp_unit_sort};
+                                               xdfm::stamp_unit_dnn,   xdfm::stamp_unit_optim, xdfm::stamp_unit_sort,
+                                               xdfm::stamp_unit_route};
   for (auto u : units) {
     const int e = u(b);
     if (e) return xdfm::fail(XDFM_E_HIP, "xdfm_debug_stamps: %s", hipGetErrorString((hipError_t)e));

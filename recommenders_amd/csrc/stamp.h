@@ -34,6 +34,9 @@ enum StampId {
   kStampCinDwUnpack,
   kStampLossPair,
   kStampPooledDwReduce,
+  kStampRoute,          // route_keys / count / write / pad / decode
+  kStampGatherRows,     // the owner-side row gather of the sharded table
+  kStampEmbedScatter,   // embed_bwd in a scatter mode (per-slot gradient records, dense gradient image)
   kStampCount
 };
 

@@ -155,3 +155,43 @@ def test_tower_refuses_what_it_does_not_serve():
     assert b"32" in lib.xdfm_last_error()
     d.n_hidden = 5
     assert lib.xdfm_tower_fwd(ctypes.byref(d), None, 4, None, None) != 0
+
+
+def test_device_time_stamps_of_a_training_step():
+    """xdfm_debug_stamps: with a buffer installed every kernel family of a step leaves start <= end stamps of the
+    100 MHz clock, the gather starts before the table gradient ends, and nothing is written once the buffer is
+    taken away again (measurement hook of tools/stamp_timeline.py)."""
+    from recommenders_amd.models.deeprec.models._engine import XDeepFMEngine
+    from tests.util import make_hp, random_batch
+
+    lib = _lib.lib
+    dev = torch.device("cuda:0")
+    hp = make_hp(FEATURE_COUNT=5000, FIELD_COUNT=8, dim=8, batch_size=256, layer_sizes=[16, 16],
+                 activation=["relu", "relu"], dropout=[0.0, 0.0], cross_layer_sizes=[8, 4])
+    eng = XDeepFMEngine(hp, device=dev, seed=3, embedding_update="sparse_rows")
+    b = random_batch(np.random.default_rng(0), hp, 256)
+    db = eng.upload(b["labels"], b["dnn_feat_indices"], b["dnn_feat_values"], b["dnn_feat_weights"])
+    eng.train_step(db)
+    torch.cuda.synchronize()
+    init = torch.empty(64, dtype=torch.int64)
+    init[0::2] = np.iinfo(np.int64).max
+    init[1::2] = 0
+    buf = init.to(dev)
+    _lib.check(lib.xdfm_debug_stamps(ctypes.c_void_p(buf.data_ptr())))
+    try:
+        db.planned = db.planned_gather = False
+        eng.train_step(db)
+        torch.cuda.synchronize()
+    finally:
+        _lib.check(lib.xdfm_debug_stamps(None))
+    t = buf.cpu().numpy().reshape(32, 2)
+    seen = [i for i in range(32) if t[i, 1] > 0]
+    assert 0 in seen and 6 in seen and 8 in seen  # gather, table gradient, dense update (csrc/stamp.h)
+    for i in seen:
+        assert t[i, 0] <= t[i, 1] and t[i, 1] - t[i, 0] < 100_000_000  # under a second of the 100 MHz clock
+    assert t[0, 0] < t[6, 1] <= t[8, 1]
+    before = buf.clone()
+    db.planned = db.planned_gather = False
+    eng.train_step(db)
+    torch.cuda.synchronize()
+    assert torch.equal(buf, before)

@@ -26,7 +26,8 @@ from recommenders_amd.models.deeprec.models._engine import XDeepFMEngine  # noqa
 NAMES = ["embed_fwd", "cin_fwd (layer 0)", "cin_pooled_fwd + head", "cin_pooled_bwd", "cin_bwd_dx2", "cin_bwd_dw",
          "embed_bwd", "embed_bwd_long", "dense_update", "dense_fwd x3", "dense_bwd_dx x3", "dense_bwd_dw + reduce",
          "sort hist/scatter x6", "plan_gather", "cin_pack_all", "loss_finish", "opt_advance", "dense_stats x2",
-         "cin_dw_unpack", "loss_pair", "cin_pooled_dw_reduce"]
+         "cin_dw_unpack", "loss_pair", "cin_pooled_dw_reduce", "route_* (next batch)", "gather_rows (owner)",
+         "embed_bwd scatter (records)"]
 SLOTS = 32
 
 ap = argparse.ArgumentParser()
@@ -35,20 +36,40 @@ ap.add_argument("--batch", type=int, default=8192)
 ap.add_argument("--dim", type=int, default=16)
 ap.add_argument("--features", type=int, default=1 << 25)
 ap.add_argument("--batches", type=int, default=16)
+ap.add_argument("--sharded", action="store_true", help="the row-sharded engine's step (eager exchanges + local graph)")
+ap.add_argument("--force-collectives", action="store_true")
 args = ap.parse_args()
 args.workload, args.dtype = "criteo", "fp32"
 
 hp = bench.workload_hparams(args)
 dev = torch.device("cuda:0")
 torch.cuda.set_device(0)
-eng = XDeepFMEngine(hp, device=dev, seed=7, embedding_update="sparse_rows")
 host = bench.synth_batches(hp, args.batches, seed=1234)
 resident = [tuple(torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in (
     hb["labels"].reshape(-1), hb["dnn_feat_indices"], hb["dnn_feat_values"], hb["dnn_feat_weights"])) for hb in host]
-graphed = eng.capture_step(*resident[0])
-packed = [graphed.pack(*r) for r in resident]
+if args.sharded:
+    from recommenders_amd.models.deeprec.models._sharded import ShardedXDeepFMEngine
+
+    if args.force_collectives:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29534")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    eng = ShardedXDeepFMEngine(hp, device=dev, seed=7, force_collectives=args.force_collectives)
+    made = [eng.make_batch(*r) for r in resident]
+
+    def run_step(i):
+        eng.train_step(made[i % len(made)], next_batch=made[(i + 1) % len(made)])
+else:
+    eng = XDeepFMEngine(hp, device=dev, seed=7, embedding_update="sparse_rows")
+    graphed = eng.capture_step(*resident[0])
+    packed = [graphed.pack(*r) for r in resident]
+
+    def run_step(i):
+        graphed.run_packed(packed[i % len(packed)])
 for i in range(40):
-    graphed.run_packed(packed[i % len(packed)])
+    run_step(i)
 torch.cuda.synchronize()
 eng.check_errors()
 
@@ -63,9 +84,9 @@ for r in range(args.repeat):
     # 30 replays ahead of the measured one, no host synchronisation in between: clocks are up and the host is
     # a step ahead when the stamps are cleared (a 512-byte copy in stream order) and the measured replay starts
     for i in range(30):
-        graphed.run_packed(packed[(40 + 31 * r + i) % len(packed)])
+        run_step(40 + 31 * r + i)
     buf.copy_(init_dev, non_blocking=True)
-    graphed.run_packed(packed[(40 + 31 * r + 30) % len(packed)])
+    run_step(40 + 31 * r + 30)
     torch.cuda.synchronize()
     t = buf.cpu().numpy().astype(np.float64).reshape(SLOTS, 2) / 100.0  # us
     rows = [(t[i, 0], t[i, 1], NAMES[i]) for i in range(len(NAMES)) if t[i, 1] > 0]
