@@ -1402,13 +1402,15 @@ class XDeepFMEngine(object):
                     if third:
                         if advance:
                             self._advance_step()
-                    else:
+                    elif not self._fold_dx:
                         head_work()
                     if self._fold_dx:
+                        # (one side stream: still the chain the CIN waits for first, the rest behind it)
                         self._dnn_backward(B, (ws["d_emb_dnn"], 0), phase="dx")
                         side_state["dx_done"] = torch.cuda.Event()
                         side_state["dx_done"].record(side)
                         if not third:
+                            head_work()
                             self._dnn_backward(B, None, phase="dw")
                     else:
                         self._dnn_backward(B, (ws["d_emb_dnn"], 0))

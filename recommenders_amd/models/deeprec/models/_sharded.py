@@ -475,11 +475,12 @@ class ShardedXDeepFMEngine(XDeepFMEngine):
         self.fixed = os.environ.get("XDFM_SHARD_FIXED", "1") != "0" and self.exchange.virtual_world == 1
         self.cap_factor = float(os.environ.get("XDFM_SHARD_CAP_FACTOR", "1.25"))
         self.fixed_steps = self.sized_steps = 0
-        # the second side stream of the backward pass pays when the exchanges are collectives (their streams
-        # and the step's share four hardware queues either way; bench.py --sharded on one GPU: 0.53 against
-        # 0.60 ms with it, 0.57 against 0.48 ms without collectives)
+        # one side stream for the backward pass here (the chain the CIN waits for first, the rest behind it):
+        # the routing, owner-side and exchange streams already share the four hardware queues with the step's,
+        # and a second side stream costs more than it hides (bench.py --sharded on one GPU: 0.46 against
+        # 0.57 ms; with every exchange through RCCL 0.51 against 0.51-0.55)
         if "XDFM_SIDE_SPLIT" not in os.environ:
-            self.side_split = bool(self.exchange.collective)
+            self.side_split = False
         # dense_exact: the regularisation loss of this rank's rows (summed over the ranks by the caller)
         self.reg_table = torch.zeros((1,), dtype=torch.float32, device=self.device)
         if self.world > 1:
