@@ -366,12 +366,14 @@ def main():
     if in_situ:
         _lib.check(_lib.lib.xdfm_prof_enable(1))
     fence()
+    graph_steps_before = getattr(eng, "graph_steps", 0)
     t0 = time.perf_counter()
     for i in range(args.steps):
         loss, _ = step(args.warmup + i)
     host_enqueue = time.perf_counter() - t0  # the host's share: below the step time, the device is the limit
     fence()
     elapsed = time.perf_counter() - t0
+    graph_steps_timed = getattr(eng, "graph_steps", 0) - graph_steps_before
     prof_steps = args.steps
     if not in_situ:
         # same kernels, same batches, launched eagerly with the library's HIP events around
@@ -473,7 +475,9 @@ def main():
             "kernel_time_ms_per_step": round(total_ms / prof_steps, 4),
             "launch": (("hip graph replay" + (" (folded onto one stream: GPU_MAX_HW_QUEUES < 4)"
                                               if getattr(eng, "folded", False) else "")) if graphed is not None else
-                       "exchanges eager, local forward/backward as a hip graph" if not in_situ else "eager"),
+                       ("whole step as one hip graph per routing generation (%d of %d timed steps)"
+                        % (graph_steps_timed, args.steps) if graph_steps_timed else
+                        "exchanges eager, local forward/backward as a hip graph") if not in_situ else "eager"),
             "kernel_timing": "HIP events around every launch, %s" % (
                 "in the timed region" if in_situ else "%d eager steps right after the timed graph replays" % prof_steps),
             "kernels": kernels,

@@ -20,6 +20,7 @@ GPUs.  ``ShardedXDeepFMEngine`` composes it with the kernels of libxdfm.so.
 
 import ctypes
 import os
+import time
 
 import numpy as np
 import torch
@@ -54,12 +55,14 @@ class RoutePlan(object):
 
     __slots__ = ("n_tok", "order", "slot_sorted", "inverse", "uniq_rows", "send_counts", "recv_counts",
                  "recv_rows", "n_send", "n_recv", "owner_sorted_ids", "owner_sorted_tok", "gen",
-                 "fixed", "cap", "gmax", "fit_host", "fit_event")
+                 "fixed", "cap", "gmax", "fit_host", "fit_event", "fit_tagged")
 
     def __init__(self):
         # fixed: the request has G x cap slots whatever the batch holds (route_fixed): the exchanges
         # need no sizes; send_counts / recv_counts are then None (equal splits)
         self.fixed, self.cap, self.gmax, self.fit_host, self.fit_event = False, 0, None, None, None
+        # (a plan routed inside a captured step: the key of the tagged answer fits() polls, see route_fixed)
+        self.fit_tagged = None
 
 
 class _Bufs(object):
@@ -88,6 +91,9 @@ class _Captured(object):
         self.failed = False
 
     def run(self, key, fn, device):
+        if torch.cuda.is_current_stream_capturing():
+            fn()  # part of a larger capture (the whole step): recorded in place
+            return
         g = self.graphs.get(key)
         if g is not None:
             g.replay()
@@ -107,6 +113,26 @@ class _Captured(object):
 
             warnings.warn("HIP graph capture of a routing sequence failed (%s); it stays eager" % (exc,))
             self.failed = True
+
+
+_hip_rt = None
+
+
+def _hip_copy_to_host(pinned, src):
+    """hipMemcpyAsync device -> pinned host on the current stream (inside a capture: a copy node; torch's own
+    non_blocking copy also records an event for its host allocator, which a capture does not want)."""
+    global _hip_rt
+    if _hip_rt is None:
+        _hip_rt = ctypes.CDLL("libamdhip64.so")
+        _hip_rt.hipMemcpyAsync.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int,
+                                           ctypes.c_void_p]
+        _hip_rt.hipMemcpyAsync.restype = ctypes.c_int
+    nbytes = src.numel() * src.element_size()
+    assert pinned.numel() * pinned.element_size() == nbytes and src.is_contiguous() and pinned.is_contiguous()
+    st = torch._C._cuda_getCurrentRawStream(src.device.index)
+    err = _hip_rt.hipMemcpyAsync(pinned.data_ptr(), src.data_ptr(), nbytes, 2, st)  # 2: device to host
+    if err != 0:
+        raise RuntimeError("hipMemcpyAsync to pinned memory failed (%d)" % err)
 
 
 class RowShardExchange(object):
@@ -131,6 +157,9 @@ class RowShardExchange(object):
         self.cap = 0
         self._route_graphs = _Captured()
         self._pinned = {}
+        self.watchdog_quiet_s = float(os.environ.get("XDFM_SHARD_WATCHDOG_QUIET_S", "0.5"))
+        self._fit_bufs = {}    # (generation, G) -> tagged-answer buffers of routings that run inside a step graph
+        self._fit_expect = {}  # (generation, G) -> how often that routing has been replayed
 
     def _a2a(self, out, x, out_splits=None, in_splits=None):
         if self.host_staged and x.is_cuda:
@@ -296,12 +325,17 @@ class RowShardExchange(object):
         n = int(ids.numel())
         plan.n_tok = n
         plan.fixed, plan.cap = True, self.cap
+        in_capture = bool(ids.is_cuda and torch.cuda.is_current_stream_capturing())
         if ids.is_cuda and n > 0:
             # partition + padding are a dozen launches over this generation's buffers: replayed as one graph
-            # (the ids are copied into a buffer of the generation's first)
+            # (the ids are copied into a buffer of the generation's first; inside a step graph `ids` IS a
+            # buffer that stays where it is and the launches are recorded in place)
             bufs = self._bufs.setdefault((ids.device, self._calls & 1), _Bufs(ids.device))
-            ids_in = bufs.get("ids_in", n, torch.int64)
-            ids_in.copy_(ids)
+            if in_capture:
+                ids_in = ids.reshape(-1)
+            else:
+                ids_in = bufs.get("ids_in", n, torch.int64)
+                ids_in.copy_(ids)
             res = {}
 
             def seq():
@@ -310,7 +344,10 @@ class RowShardExchange(object):
 
             seq_key = ("route", n, int(n_rows), G, self.cap, int(pad_row), self._calls & 1, ids_in.data_ptr())
             hit = self._route_out.get(seq_key) if hasattr(self, "_route_out") else None
-            if hit is None:
+            if in_capture:
+                seq()
+                hit = res["v"]
+            elif hit is None:
                 self._route_graphs.run(seq_key, seq, ids.device)
                 if not hasattr(self, "_route_out"):
                     self._route_out = {}
@@ -332,7 +369,18 @@ class RowShardExchange(object):
         # ids to their owners (equal splits); every block's header tells the owner its source's largest count
         raw = self.to_owner(plan, rows_p)
         plan.recv_rows, src_max = self._decode(raw, G, self.cap)
-        if src_max.is_cuda:
+        if src_max.is_cuda and in_capture:
+            # no event can tell the host that a part of a graph has run: the answer travels with a count of
+            # this routing's replays in the high half of every word, and fits() reads until the count is the
+            # one it expects (fit_buffers; 8-byte words of pinned memory, each written whole)
+            key = (self._calls & 1, G)
+            seq_hi, tagged, pin, _ = self.fit_buffers(key, src_max.device)
+            seq_hi.add_(1 << 32)
+            tagged.copy_(src_max)
+            tagged.add_(seq_hi)
+            _hip_copy_to_host(pin, tagged)
+            plan.fit_host, plan.fit_tagged = None, key
+        elif src_max.is_cuda:
             gen = self._calls & 1
             pin = self._pinned.get((gen, G))
             if pin is None:
@@ -361,9 +409,34 @@ class RowShardExchange(object):
         src_max = (raw.view(G, cap + 1)[:, cap] >> 32).to(torch.int32)
         return rows, src_max
 
+    def fit_buffers(self, key, device):
+        """(replay count << 32 on the device, tagged answer on the device, its pinned copy, numpy view of that)
+        of the routing of generation key[0] inside a step graph.  Made outside the capture."""
+        hit = self._fit_bufs.get(key)
+        if hit is None:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("fit_buffers must exist before the capture")
+            G = key[1]
+            pin = torch.zeros((G,), dtype=torch.int64).pin_memory()
+            hit = self._fit_bufs[key] = (torch.zeros((1,), dtype=torch.int64, device=device),
+                                         torch.zeros((G,), dtype=torch.int64, device=device), pin, pin.numpy())
+            self._fit_expect[key] = 0
+        return hit
+
     def fits(self, plan):
         """Whether a fixed-capacity plan holds its batch on every rank (plan.gmax = the largest number of
         distinct rows any rank asks of any owner)."""
+        if plan.fit_tagged is not None:
+            view, want = self._fit_bufs[plan.fit_tagged][3], self._fit_expect[plan.fit_tagged]
+            t0 = time.monotonic()
+            while True:
+                v = view.copy()
+                if bool(((v >> 32) == want).all()):
+                    break
+                if time.monotonic() - t0 > 120.0:
+                    raise RuntimeError("the routing inside the captured step did not report (replay %d)" % want)
+            plan.gmax = int((v & 0xFFFFFFFF).max())
+            return plan.gmax <= plan.cap
         if plan.fit_event is not None:
             plan.fit_event.synchronize()
         plan.gmax = int(plan.fit_host.max())
@@ -475,12 +548,6 @@ class ShardedXDeepFMEngine(XDeepFMEngine):
         self.fixed = os.environ.get("XDFM_SHARD_FIXED", "1") != "0" and self.exchange.virtual_world == 1
         self.cap_factor = float(os.environ.get("XDFM_SHARD_CAP_FACTOR", "1.25"))
         self.fixed_steps = self.sized_steps = 0
-        # one side stream for the backward pass here (the chain the CIN waits for first, the rest behind it):
-        # the routing, owner-side and exchange streams already share the four hardware queues with the step's,
-        # and a second side stream costs more than it hides (bench.py --sharded on one GPU: 0.46 against
-        # 0.57 ms; with every exchange through RCCL 0.51 against 0.51-0.55)
-        if "XDFM_SIDE_SPLIT" not in os.environ:
-            self.side_split = False
         # dense_exact: the regularisation loss of this rank's rows (summed over the ranks by the caller)
         self.reg_table = torch.zeros((1,), dtype=torch.float32, device=self.device)
         if self.world > 1:
@@ -507,6 +574,14 @@ class ShardedXDeepFMEngine(XDeepFMEngine):
         if self.use_bn and self.exchange.collective:
             self.graph_local = False
         self._local_graphs = {}
+        # with fixed-capacity requests and the next batch announced, the WHOLE step (exchanges, owner-side
+        # work and the next batch's routing included) replays as one HIP graph per routing generation
+        # (_StepGraph; XDFM_SHARD_STEP_GRAPH=0: the local part only, exchanges eager)
+        self.graph_step = os.environ.get("XDFM_SHARD_STEP_GRAPH", "1") != "0"
+        self.step_route_at = int(os.environ.get("XDFM_SHARD_ROUTE_AT", "0"))
+        self._step_graphs = {}
+        self._after_step_graph = False
+        self.graph_steps = 0
 
     # ------------------------------------------------------------------ scratch row
     _ROW_KEYS = ("embedding", "lin_w", "slot/table_m", "slot/table_v", "slot/lin_m", "slot/lin_v")
@@ -675,6 +750,10 @@ class ShardedXDeepFMEngine(XDeepFMEngine):
             self._route_stream = torch.cuda.Stream(device=self.device)
         rs = self._route_stream
         ready = getattr(next_batch, "ready_event", None)
+        if self._after_step_graph:
+            # the last step was one graph on the current stream (no per-generation events): wait for all of it
+            rs.wait_stream(torch.cuda.current_stream(self.device))
+            self._after_step_graph = False
         if ready is not None:
             rs.wait_event(ready)  # the copy / kernels that produced the batch's arrays
         else:
@@ -697,7 +776,8 @@ class ShardedXDeepFMEngine(XDeepFMEngine):
             # with its peers
             raise RuntimeError("train_step got a different batch than the one announced as next_batch")
         _, plan, done = pre
-        torch.cuda.current_stream(self.device).wait_event(done)
+        if done is not None:  # (None: routed inside the previous step's graph, on this stream)
+            torch.cuda.current_stream(self.device).wait_event(done)
         return plan
 
     def _token_grads(self, batch, seg_ids, order32, send_c):
@@ -833,6 +913,34 @@ class ShardedXDeepFMEngine(XDeepFMEngine):
             self._local_graphs[key] = g
         return g
 
+    def _step_graph(self, batch, next_batch, plan, g):
+        """The _StepGraph that serves this step, or None: it needs a fixed-capacity plan in its generation's
+        buffers, the next batch announced and of the same shape (with its arrays in one flat buffer:
+        make_batch), and both generations' local graphs already captured and replayed (so every buffer the
+        step touches exists)."""
+        if not (self.graph_step and plan.fixed and g.direct and g.graph is not None and next_batch is not None
+                and next_batch is not batch and next_batch.B == batch.B and next_batch.nnz == batch.nnz
+                and getattr(next_batch, "flat", None) is not None and next_batch.flat.numel() == g.flat.numel()
+                and getattr(batch, "flat", None) is not None and batch.flat.numel() == g.flat.numel()):
+            return None
+        other = None
+        for h in self._local_graphs.values():
+            if (h.direct and h.graph is not None and h.gen == 1 - g.gen and h.slots == g.slots
+                    and h.batch.B == batch.B and h.batch.nnz == batch.nnz and h.ws_token == self._ws_token):
+                other = h
+        if other is None:
+            return None
+        key = (id(g), id(other), self.exchange.cap)
+        sg = self._step_graphs.get(key)
+        if sg is not None and sg.ws_token != self._ws_token:
+            self._step_graphs.clear()
+            sg = None
+        if sg is None:
+            if len(self._step_graphs) >= 8:
+                return None
+            sg = self._step_graphs[key] = _StepGraph(self, g, other, plan)
+        return sg
+
     def make_batch(self, labels, dnn_idx, ids, weights):
         """XDeepFMEngine.make_batch with the arrays the local graph reads (labels, weights, CSR offsets, token
         rows) as views of ONE flat buffer: handing the batch to the graph is one copy."""
@@ -841,9 +949,13 @@ class ShardedXDeepFMEngine(XDeepFMEngine):
         B, nnz = int(labels.numel()), int(ids.numel())
         lay, flat = _flat_layout(B, nnz, self.F, self.device)
         b = DeviceBatch()
-        b.B, b.nnz, b.ids = B, nnz, ids
+        b.B, b.nnz = B, nnz
         b.flat = flat
         b.labels, b.weights, b.row_ptr, b.tok_row = (_flat_view(flat, lay, k) for k in ("labels", "weights", "row_ptr", "tok_row"))
+        # (the ids too: a step graph routes the NEXT batch from the flat buffer it was handed, see _StepGraph)
+        b.ids = _flat_view(flat, lay, "ids")[:nnz].view(ids.shape) if nnz and ids.dtype == torch.int64 else ids
+        if b.ids is not ids:
+            b.ids.copy_(ids)
         b.labels.copy_(labels.reshape(-1))
         if nnz:
             b.weights[:nnz].copy_(weights.reshape(-1))
@@ -875,6 +987,9 @@ class ShardedXDeepFMEngine(XDeepFMEngine):
         plan = self.resolve_plan(batch)
         if self.graph_local and self.kernel_events is None and batch.nnz > 0:
             g = self._local_graph(batch, plan)  # None: too many shapes seen, stay eager
+        sg = self._step_graph(batch, next_batch, plan, g) if g is not None else None
+        if sg is not None:
+            return sg.step(batch, next_batch)
         if g is not None:
             self.fetch_rows(batch, static=g, plan=plan)
             g.load(batch)
@@ -1046,15 +1161,128 @@ def _flat_layout(B, nnz, F, device):
     """(name -> (byte offset, dtype, elements), a new flat buffer) for the per-batch arrays of the local graph."""
     lay, off = {}, 0
     for name, dt, n in (("labels", torch.float32, B), ("weights", torch.float32, max(nnz, 1)),
-                        ("row_ptr", torch.int32, B * F + 1), ("tok_row", torch.int32, max(nnz, 1))):
+                        ("row_ptr", torch.int32, B * F + 1), ("tok_row", torch.int32, max(nnz, 1)),
+                        ("ids", torch.int64, max(nnz, 1))):
         lay[name] = (off, dt, n)
-        off += (n * 4 + 255) // 256 * 256
+        off += (n * (8 if dt == torch.int64 else 4) + 255) // 256 * 256
     return lay, torch.zeros((max(off, 256),), dtype=torch.uint8, device=device)
 
 
 def _flat_view(flat, lay, name):
     off, dt, n = lay[name]
-    return flat[off:off + n * 4].view(dt)
+    return flat[off:off + n * (8 if dt == torch.int64 else 4)].view(dt)
+
+
+class _StepGraph(object):
+    """One rank's WHOLE step under fixed-capacity requests as one HIP graph: rows gathered for the peers and
+    sent, the local forward / backward / gradient records (_LocalGraph._run), records to their owners, the
+    owners' update, the all-reduce and update of the replicated parameters, the loss -- and, on a branch of
+    its own, the routing of the batch that FOLLOWS (partition, request to the owners, owner-side sort) into the
+    other generation's buffers.  A step then costs the host one copy (the next batch's flat buffer into the
+    other generation's inputs), one graph launch and a look at a pinned word: whether the batch routed by the
+    previous graph fits its requests (RowShardExchange.fits, tagged answer).
+
+    There is one such graph per routing generation; each reads its own batch's arrays from its _LocalGraph's
+    inputs (loaded one step earlier, when the batch was announced as next_batch) and the next batch's ids from
+    the other one's.  Every rank captures the same sequence of collectives (RCCL orders them on the process
+    group's own stream, which joins the capture); ranks run the same software on the same shapes, so they
+    take or leave this path together."""
+
+    def __init__(self, eng, lg, lg_next, plan):
+        self.eng, self.lg, self.lg_next, self.plan = eng, lg, lg_next, plan
+        self.plan_next = None
+        self.graph = None
+        self.ws_token = eng._ws_token
+        self.tot = torch.zeros((2,), dtype=torch.float32, device=eng.device)
+        self.fit_key = (1 - plan.gen, eng.exchange.world)
+        eng.exchange.fit_buffers(self.fit_key, eng.device)
+        if eng._route_stream is None:
+            eng._route_stream = torch.cuda.Stream(device=eng.device)
+
+    def capture(self):
+        eng, ex = self.eng, self.eng.exchange
+        keep = (eng.step, eng.b1p, eng.b2p, ex._calls, eng._rows_stale, eng._route_pre)
+        if ex.collective and ex.watchdog_quiet_s > 0:
+            # The process group's watchdog thread polls the events of the eager collectives it still lists; asked
+            # about one while the group's stream is being captured, the runtime answers with an error that ends
+            # the process.  With the device idle and a few of its polling periods gone by, its list is empty.
+            torch.cuda.synchronize(eng.device)
+            time.sleep(ex.watchdog_quiet_s)
+        graph = torch.cuda.CUDAGraph()
+        try:
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+                self._run()
+        except Exception as exc:  # noqa: BLE001
+            # (a capture that failed leaves its streams capturing: there is no falling back inside this process)
+            raise RuntimeError("HIP graph capture of the whole sharded step failed (%s); XDFM_SHARD_STEP_GRAPH=0 "
+                               "keeps the exchanges eager" % (exc,))
+        finally:
+            eng.step, eng.b1p, eng.b2p, ex._calls, eng._rows_stale, eng._route_pre = keep
+        self.graph = graph
+
+    def _run(self):
+        eng, ex, lg = self.eng, self.eng.exchange, self.lg
+        cur = torch.cuda.current_stream(eng.device)
+        rs = eng._route_stream
+        at = eng.step_route_at
+
+        def route_next():
+            with torch.cuda.stream(rs):
+                self.plan_next = eng._prepare(self.lg_next.batch)
+
+        def fork_here(where):
+            if at == where:
+                rs.wait_stream(cur)
+                route_next()
+
+        eng.fetch_rows(lg.batch, static=lg, plan=self.plan)
+        fork_here(0)  # (behind the rows' exchange: the request's collective is issued after it)
+        if lg.fixed:
+            lg.send_c.zero_()
+        eng.forward(lg.batch, with_loss=True, with_grad=True)
+        fork_here(1)
+        # as in XDeepFMEngine.train_step: the step scalars move on beside the backward pass, and the weight
+        # gradients nothing of the table's path reads are issued behind the gradient records
+        if not eng.backward(lg.batch, advance=True, defer_late=True):
+            eng._advance_step()
+        eng._token_grads(lg.batch, lg.seg_ids, lg.order32, lg.send_c)
+        eng.run_late_work()
+        fork_here(2)
+        eng._owner_update(lg.batch, lg.send_c)
+        eng.join_late()
+        if ex.collective:
+            ex.all_reduce(eng.dense_grad)
+        eng._update_dense(True)
+        fork_here(3)
+        cur.wait_stream(rs)
+        if eng.rank != 0:
+            eng.reg_loss.zero_()
+        if not eng.sparse:
+            eng.reg_loss.add_(eng.reg_table)
+        _lib.check(eng.lib.xdfm_loss_total(_ptr(eng._loss2), _ptr(self.tot), eng._stream()))
+
+    def step(self, batch, next_batch):
+        eng, ex, lg = self.eng, self.eng.exchange, self.lg
+        if lg.loaded is not batch:
+            lg.load(batch)
+        self.lg_next.load(next_batch)
+        if self.graph is None:
+            self.capture()
+        self.graph.replay()
+        # what the eager step's calls leave on the host
+        eng.step += 1
+        if eng.opt_kind == 1 or eng.use_dropout or eng.catchup_on:
+            eng.b1p = np.float32(eng.b1p * np.float32(0.9))
+            eng.b2p = np.float32(eng.b2p * np.float32(0.999))
+        if eng.sparse and eng.catchup_on:
+            eng._rows_stale = True
+        ex._calls += 1
+        ex._fit_expect[self.fit_key] += 1
+        eng._route_pre = (next_batch, self.plan_next, None)
+        eng._after_step_graph = True
+        eng.graph_steps += 1
+        batch.route = self.plan
+        return self.tot[1], self.tot[0]
 
 
 class _LocalGraph(object):
@@ -1087,13 +1315,17 @@ class _LocalGraph(object):
             # launch keeps the address it was recorded with)
             self.seg_ids = torch.zeros((nnz,), dtype=torch.int32, device=dev)
         self.ws_token = eng._ws_token
+        self.gen = plan.gen if plan is not None else None
+        self.loaded = None  # the batch whose arrays the inputs hold
         self.send_c = torch.zeros((slots, D + 4 if use_lin else D), dtype=f32, device=dev)
         sb = DeviceBatch()
         sb.B, sb.nnz = B, nnz
         self.lay, self.flat = _flat_layout(B, nnz, eng.F, dev)
         sb.labels, sb.weights, sb.row_ptr, sb.tok_row = (_flat_view(self.flat, self.lay, k)
                                                           for k in ("labels", "weights", "row_ptr", "tok_row"))
-        sb.ids = None  # never read: the embeddings come from src_table
+        # (not read by the local pass, whose embeddings come from src_table: a step graph routes the batch that
+        # follows from here)
+        sb.ids = _flat_view(self.flat, self.lay, "ids")[:nnz] if nnz else None
         sb.src_table, sb.src_lin, sb.src_ids, sb.src_N = self.src_table, self.src_lin, self.src_ids, max(slots, 1)
         sb.sorted_ids = sb.sorted_tok = None
         sb.planned = True
@@ -1134,6 +1366,7 @@ class _LocalGraph(object):
     def load(self, batch):
         """Copy the per-batch arrays (and the partition order) into the graph's inputs."""
         sb, plan = self.batch, batch.route
+        self.loaded = batch
         flat = getattr(batch, "flat", None)
         if flat is not None and flat.numel() == self.flat.numel():
             self.flat.copy_(flat)  # labels, weights, CSR offsets, token rows in one copy

@@ -1,6 +1,7 @@
 #!/usr/bin/env python
 """Timeline of one replayed step from a rocprofv3 --kernel-trace CSV, anchored at the gather kernel:
-start / end / duration in us, queue, kernel.   python tools/trace_step.py trace.csv [k-th last step]"""
+start / end / duration in us, queue, kernel.   python tools/trace_step.py trace.csv [k-th last step] [anchor]
+(anchor: the kernel that starts a step; gather_rows for the row-sharded engine)"""
 import csv
 import re
 import sys
@@ -8,7 +9,8 @@ import sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 back = int(sys.argv[2]) if len(sys.argv) > 2 else 8
-idx = [i for i, r in enumerate(rows) if "embed_fwd_kernel" in r["Kernel_Name"]]
+anchor = sys.argv[3] if len(sys.argv) > 3 else "embed_fwd_kernel"
+idx = [i for i, r in enumerate(rows) if anchor in r["Kernel_Name"]]
 a, b = idx[-back], idx[-back + 1]
 t0 = int(rows[a]["Start_Timestamp"])
 
