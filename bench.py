@@ -306,7 +306,9 @@ def main():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29533")
             dist1.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
-        eng = ShardedXDeepFMEngine(hp, device=dev, seed=7, force_collectives=bool(world == 1 and args.force_collectives))
+        # (every rank's synthetic batches have one shape: the whole step may replay as one graph on all ranks)
+        eng = ShardedXDeepFMEngine(hp, device=dev, seed=7, force_collectives=bool(world == 1 and args.force_collectives),
+                                   uniform_batches=True)
 
     resident = []
     for hb in host_batches:
@@ -488,6 +490,8 @@ def main():
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(line) + "\n").encode())
     if dist is not None:
+        if hasattr(eng, "close"):
+            eng.close()  # graphs that hold captured collectives go before the group does
         dist.barrier()
         dist.destroy_process_group()
 

@@ -528,7 +528,11 @@ class ShardedXDeepFMEngine(XDeepFMEngine):
     rank's part of the global batch; all ranks must call it with equally sized batches."""
 
     def __init__(self, hp, device=None, seed=None, group=None, virtual_world=1, embedding_update="sparse_rows",
-                 force_collectives=False, compute_dtype=None):
+                 force_collectives=False, compute_dtype=None, uniform_batches=False):
+        """uniform_batches: the caller's promise that every batch on every rank has the same number of samples
+        and tokens (synthetic or padded data).  With more than one rank the whole-step graph (_StepGraph) needs
+        it: a rank replays that graph when its own consecutive batches agree in shape, the graph issues the
+        step's collectives in another order than the eager step does, and all ranks must take the same path."""
         self.exchange = RowShardExchange(group, virtual_world=virtual_world, force_collectives=force_collectives)
         self.world, self.rank = self.exchange.world, self.exchange.rank
         if embedding_update == "dense_exact" and hp.is_clip_norm:
@@ -577,7 +581,11 @@ class ShardedXDeepFMEngine(XDeepFMEngine):
         # with fixed-capacity requests and the next batch announced, the WHOLE step (exchanges, owner-side
         # work and the next batch's routing included) replays as one HIP graph per routing generation
         # (_StepGraph; XDFM_SHARD_STEP_GRAPH=0: the local part only, exchanges eager)
-        self.graph_step = os.environ.get("XDFM_SHARD_STEP_GRAPH", "1") != "0"
+        # More than one rank: opt-in (XDFM_SHARD_STEP_GRAPH=1 AND uniform_batches).  The captured collectives
+        # have run at world size 1 only (a one-GPU box; RCCL refuses two ranks on one device), and a path that
+        # could leave N ranks waiting for each other is not made the default on that evidence.
+        want = os.environ.get("XDFM_SHARD_STEP_GRAPH", "1" if self.world == 1 else "0") != "0"
+        self.graph_step = want and (self.world == 1 or bool(uniform_batches))
         self.step_route_at = int(os.environ.get("XDFM_SHARD_ROUTE_AT", "0"))
         self._step_graphs = {}
         self._after_step_graph = False
@@ -918,7 +926,8 @@ class ShardedXDeepFMEngine(XDeepFMEngine):
         buffers, the next batch announced and of the same shape (with its arrays in one flat buffer:
         make_batch), and both generations' local graphs already captured and replayed (so every buffer the
         step touches exists)."""
-        if not (self.graph_step and plan.fixed and g.direct and g.graph is not None and next_batch is not None
+        if not (self.graph_step and not self.exchange.host_staged and plan.fixed and g.direct
+                and g.graph is not None and next_batch is not None
                 and next_batch is not batch and next_batch.B == batch.B and next_batch.nnz == batch.nnz
                 and getattr(next_batch, "flat", None) is not None and next_batch.flat.numel() == g.flat.numel()
                 and getattr(batch, "flat", None) is not None and batch.flat.numel() == g.flat.numel()):
@@ -940,6 +949,19 @@ class ShardedXDeepFMEngine(XDeepFMEngine):
                 return None
             sg = self._step_graphs[key] = _StepGraph(self, g, other, plan)
         return sg
+
+    def close(self):
+        """Drop the captured steps.  Call it before torch.distributed.destroy_process_group(): graphs that hold
+        captured collectives keep the communicator busy, and destroying the group then waits for ever."""
+        import gc
+
+        torch.cuda.synchronize(self.device)
+        for sg in self._step_graphs.values():
+            sg.graph = None
+        self._step_graphs.clear()
+        self._route_pre = None
+        gc.collect()
+        torch.cuda.synchronize(self.device)
 
     def make_batch(self, labels, dnn_idx, ids, weights):
         """XDeepFMEngine.make_batch with the arrays the local graph reads (labels, weights, CSR offsets, token

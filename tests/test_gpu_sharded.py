@@ -76,6 +76,54 @@ def test_sharded_step_equals_plain_engine_and_oracle(optimizer, virtual_world):
     assert np.abs(plain.state_dict()["embedding"].cpu().numpy() - table.cpu().numpy()).max() <= 1e-6
 
 
+@pytest.mark.parametrize("embedding_update", ["sparse_rows", "dense_exact"])
+def test_whole_step_graph_equals_eager_exchanges(embedding_update):
+    """Batches of one shape, each announcing its successor: once both routing generations have replayed their
+    local graphs the whole step -- exchanges, owner-side update, the next batch's routing -- is one graph per
+    generation (_StepGraph).  Bit for bit the engine whose exchanges stay eager, through a batch that does not
+    fit its request (found out from the tagged answer of the routing inside the previous graph; that batch
+    goes with sized requests) and a step without an announced successor."""
+    extra = dict(embed_l2=0.01, layer_l2=0.01) if embedding_update == "dense_exact" else {}
+    hp = make_hp(optimizer="adam", learning_rate=0.01, FEATURE_COUNT=300, cross_l2=0.01, **extra)
+    rng = np.random.default_rng(15)
+    p32 = X.init_params(hp, seed=9)
+    whole = ShardedXDeepFMEngine(hp, seed=3, embedding_update=embedding_update)
+    eager = ShardedXDeepFMEngine(hp, seed=3, embedding_update=embedding_update)
+    eager.graph_step = False
+    assert whole.graph_step
+    for e in (whole, eager):
+        e.load_global_state({k: v.clone() for k, v in p32.items()})
+    # (one token per field: every batch has the same number of tokens, as the graph asks)
+    batches = [random_batch(rng, hp, 64, multi_p=0.0, missing_p=0.0) for _ in range(14)]
+    dev_w = [_upload(whole, b) for b in batches]
+    dev_e = [_upload(eager, b) for b in batches]
+    used = []
+    for k in range(len(batches)):
+        last = k + 1 == len(batches) or k == 9  # step 9 announces nothing: step 10 routes its own batch
+        forced = k == 7 and whole._route_pre is not None and whole._route_pre[1].fit_tagged is not None
+        if forced:
+            plan = whole._route_pre[1]
+            keep, plan.cap = plan.cap, 1  # "does not fit"
+        before = whole.graph_steps
+        lw = whole.train_step(dev_w[k], next_batch=None if last else dev_w[k + 1])
+        le = eager.train_step(dev_e[k], next_batch=None if last else dev_e[k + 1])
+        if forced:
+            plan.cap = keep
+            assert whole.graph_steps == before  # that batch went with sized requests
+        used.append(whole.graph_steps - before)
+        assert float(lw[0]) == float(le[0]) and float(lw[1]) == float(le[1]), (k, used)
+    torch.cuda.synchronize()
+    whole.check_errors()
+    assert sum(used) >= 5 and eager.graph_steps == 0, used
+    assert used[7] == 0 and used[9] == 0 and used[13] == 0
+    assert whole.sized_steps == 2  # the first batch and the forced miss
+    a, b = whole.state_dict(), eager.state_dict()
+    for key in a:
+        if torch.is_tensor(a[key]):
+            assert torch.equal(a[key], b[key]), key
+    assert whole.step == eager.step == len(batches)
+
+
 def test_sharded_batch_norm_without_peers_equals_plain_engine():
     """enable_BN with nothing split: the plain normalisation kernels, inside the captured local graph."""
     hp = make_hp(optimizer="adam", learning_rate=0.01, FEATURE_COUNT=300, enable_BN=True, loss="cross_entropy_loss")
@@ -261,10 +309,13 @@ def test_two_ranks_sharing_the_gpu_match_the_oracle_on_the_global_batch(optimize
 def _rccl_worker(port, bn, out):
     """One rank over the nccl (= RCCL) backend with every collective of the N-GPU step issued for
     real (an exchange with oneself): the calls, dtypes and split lists of the multi-GPU path."""
+    import faulthandler
     import os
+    import sys
 
     import torch.distributed as dist
 
+    faulthandler.dump_traceback_later(90, exit=True, file=sys.stderr)  # a rank that hangs names its line and ends
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     torch.cuda.set_device(0)
@@ -280,7 +331,7 @@ def _rccl_worker(port, bn, out):
         p64 = {k: v.double() for k, v in p32.items()}
         st = X.new_opt_state(p64, hp)
         rng = np.random.default_rng(31)
-        batches = [random_batch(rng, hp, 64) for _ in range(4)]
+        batches = [random_batch(rng, hp, 64, multi_p=0.0, missing_p=0.0) for _ in range(4 if bn else 10)]
         dev = [_upload(eng, b) for b in batches]
         for k, b in enumerate(batches):
             if k == 2 and not bn:
@@ -290,10 +341,14 @@ def _rccl_worker(port, bn, out):
             assert abs(float(dloss) - o_dl) <= 2e-5 * abs(o_dl), (k, float(dloss), o_dl)
         torch.cuda.synchronize()
         eng.check_errors()
-        assert (eng.sized_steps, eng.fixed_steps) == ((1, 3) if bn else (2, 2))
+        assert (eng.sized_steps, eng.fixed_steps) == ((1, 3) if bn else (2, 8))
+        # the later steps ran as one graph each, the all-to-alls and the all-reduce captured with the kernels
+        # (and eager collectives -- gather_global_table below -- still work behind them)
+        assert eng.graph_steps >= (0 if bn else 3), eng.graph_steps
         table, _ = eng.gather_global_table()
         err = np.abs(table.cpu().numpy() - p64["embedding"].numpy()).max()
         assert err <= (5e-4 if bn else 2e-4) * np.abs(p64["embedding"].numpy()).max(), err
+        eng.close()  # (captured collectives are released before the group is destroyed)
         out.put("ok")
     except Exception:  # noqa: BLE001
         import traceback
@@ -301,6 +356,7 @@ def _rccl_worker(port, bn, out):
         out.put(traceback.format_exc())
     finally:
         dist.destroy_process_group()
+        faulthandler.cancel_dump_traceback_later()
 
 
 @pytest.mark.parametrize("bn", [False, True])
@@ -315,3 +371,4 @@ def test_collectives_of_the_sharded_step_run_over_rccl(bn):
     res = out.get(timeout=110)
     p.join(timeout=30)
     assert res == "ok", res
+    assert p.exitcode == 0, "the rank did not end (exit code %r)" % (p.exitcode,)
