@@ -266,3 +266,39 @@ def check(code):
         msg = lib.xdfm_last_error()
         raise XdfmError(code, msg.decode("utf-8", "replace") if msg else "")
     return code
+
+
+_hip_runtime = None
+
+
+def hip_runtime():
+    """The HIP runtime this process has loaded already (torch's; libxdfm.so resolves to the same one), for the few
+    runtime calls torch does not expose: a copy node inside a capture, its node handle, its source per replay.
+    Opened by the path /proc/self/maps shows, so that no second copy of the runtime is ever loaded."""
+    global _hip_runtime
+    if _hip_runtime is None:
+        path = "libamdhip64.so"
+        try:
+            with open("/proc/self/maps") as f:
+                for line in f:
+                    if "libamdhip64" in line:
+                        path = line.split()[-1]
+                        break
+        except OSError:
+            pass
+        rt = ctypes.CDLL(path)
+        vp, sz = ctypes.c_void_p, ctypes.c_size_t
+        rt.hipMemcpyAsync.argtypes = [vp, vp, sz, ctypes.c_int, vp]
+        rt.hipMemcpyAsync.restype = ctypes.c_int
+        rt.hipStreamGetCaptureInfo_v2.argtypes = [vp, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_ulonglong),
+                                                  ctypes.POINTER(vp), ctypes.POINTER(ctypes.POINTER(vp)),
+                                                  ctypes.POINTER(sz)]
+        rt.hipStreamGetCaptureInfo_v2.restype = ctypes.c_int
+        rt.hipGraphExecMemcpyNodeSetParams1D.argtypes = [vp, vp, vp, vp, sz, ctypes.c_int]
+        rt.hipGraphExecMemcpyNodeSetParams1D.restype = ctypes.c_int
+        _hip_runtime = rt
+    return _hip_runtime
+
+
+HIP_MEMCPY_DEVICE_TO_HOST = 2
+HIP_MEMCPY_DEVICE_TO_DEVICE = 3

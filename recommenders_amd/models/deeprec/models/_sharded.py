@@ -115,22 +115,13 @@ class _Captured(object):
             self.failed = True
 
 
-_hip_rt = None
-
-
 def _hip_copy_to_host(pinned, src):
     """hipMemcpyAsync device -> pinned host on the current stream (inside a capture: a copy node; torch's own
     non_blocking copy also records an event for its host allocator, which a capture does not want)."""
-    global _hip_rt
-    if _hip_rt is None:
-        _hip_rt = ctypes.CDLL("libamdhip64.so")
-        _hip_rt.hipMemcpyAsync.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int,
-                                           ctypes.c_void_p]
-        _hip_rt.hipMemcpyAsync.restype = ctypes.c_int
     nbytes = src.numel() * src.element_size()
     assert pinned.numel() * pinned.element_size() == nbytes and src.is_contiguous() and pinned.is_contiguous()
     st = torch._C._cuda_getCurrentRawStream(src.device.index)
-    err = _hip_rt.hipMemcpyAsync(pinned.data_ptr(), src.data_ptr(), nbytes, 2, st)  # 2: device to host
+    err = _lib.hip_runtime().hipMemcpyAsync(pinned.data_ptr(), src.data_ptr(), nbytes, _lib.HIP_MEMCPY_DEVICE_TO_HOST, st)
     if err != 0:
         raise RuntimeError("hipMemcpyAsync to pinned memory failed (%d)" % err)
 
