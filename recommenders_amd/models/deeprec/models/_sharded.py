@@ -581,6 +581,20 @@ class ShardedXDeepFMEngine(XDeepFMEngine):
         self._step_graphs = {}
         self._after_step_graph = False
         self.graph_steps = 0
+        if self.graph_step and self.exchange.collective:
+            # a process that ends with captured collectives alive hangs in the process group's destructor
+            # (seen with an engine held by a module global): drop the graphs before the interpreter goes
+            import atexit
+            import weakref
+
+            ref = weakref.ref(self)
+
+            def _close_at_exit():
+                eng = ref()
+                if eng is not None and eng._step_graphs:
+                    eng.close()
+
+            atexit.register(_close_at_exit)
 
     # ------------------------------------------------------------------ scratch row
     _ROW_KEYS = ("embedding", "lin_w", "slot/table_m", "slot/table_v", "slot/lin_m", "slot/lin_v")

@@ -110,3 +110,5 @@ for r in range(args.repeat):
     print("  span %.1f us; gaps on the chain: %s" % (end - t0, "; ".join(gaps)))
 _lib.check(_lib.lib.xdfm_debug_stamps(None))
 print("spans: " + " ".join("%.1f" % s for s in spans))
+if args.sharded:
+    eng.close()  # (captured collectives go before the process group does)
