@@ -15,6 +15,7 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <chrono>
 #include <condition_variable>
 #include <functional>
 #include <memory>
@@ -341,7 +342,15 @@ struct xdfm_ffm_reader {
   size_t nl_head = 0;                         // first not yet consumed
   size_t idx_pos = 0;                         // first byte not yet indexed
   std::vector<std::vector<uint64_t>> nl_part;  // per thread
+  // XDFM_FFM_TIMING=1: seconds spent finding lines / parsing / filling, printed when the reader is closed
+  bool timing = false;
+  double t_lines = 0, t_parse = 0, t_fill = 0;
+  int64_t batches = 0;
 };
+
+static inline double now_s() {
+  return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
 
 extern "C" int xdfm_ffm_open(const char* path, int64_t field_count, int64_t feature_count,
                              char col_sep, char id_sep, xdfm_ffm_reader** out) {
@@ -381,6 +390,7 @@ extern "C" int xdfm_ffm_open(const char* path, int64_t field_count, int64_t feat
     r->threads = t < 1 ? 1 : (t > 16 ? 16 : t);
   }
   r->pool.reset(new Pool(r->threads));
+  r->timing = getenv("XDFM_FFM_TIMING") != nullptr;
   if (r->size > 0) {
     // any '\r' at all?  (each thread looks through its part of the file)
     const int T = r->threads;
@@ -399,6 +409,10 @@ extern "C" int xdfm_ffm_open(const char* path, int64_t field_count, int64_t feat
 
 extern "C" int xdfm_ffm_close(xdfm_ffm_reader* r) {
   if (!r) return XDFM_OK;
+  if (r->timing && r->batches > 0)
+    fprintf(stderr, "xdfm_ffm: %lld batches on %d threads: lines %.3f ms, parse %.3f ms, fill %.3f ms per batch\n",
+            (long long)r->batches, r->threads, 1e3 * r->t_lines / r->batches, 1e3 * r->t_parse / r->batches,
+            1e3 * r->t_fill / r->batches);
   r->pool.reset();
   if (r->data) munmap((void*)r->data, r->size);
   if (r->fd >= 0) close(r->fd);
@@ -657,6 +671,7 @@ extern "C" int xdfm_ffm_next(xdfm_ffm_reader* r, int64_t batch_size, xdfm_ffm_ba
   r->first_line = r->line_no + 1;
 
   // 1. the next batch_size lines (universal newlines)
+  const double t0 = r->timing ? now_s() : 0;
   r->lines.clear();
   const char* end = r->data + r->size;
   if (r->plain_newlines) {
@@ -718,6 +733,7 @@ extern "C" int xdfm_ffm_next(xdfm_ffm_reader* r, int64_t batch_size, xdfm_ffm_ba
   if (n == 0) return xdfm::fail(XDFM_E_EOF, "end of file");
 
   // 2. parse: contiguous runs of lines on up to r->threads threads, each into its own staging
+  const double t1 = r->timing ? now_s() : 0;
   int T = r->threads;
   if (T > n / 256) T = (int)(n / 256);
   if (T < 1) T = 1;
@@ -734,6 +750,11 @@ extern "C" int xdfm_ffm_next(xdfm_ffm_reader* r, int64_t batch_size, xdfm_ffm_ba
   });
   r->line_no += n;
   r->pieces = T;
+  if (r->timing) {
+    r->t_lines += t1 - t0;
+    r->t_parse += now_s() - t1;
+    r->batches += 1;
+  }
 
   // 3. the pieces stay where they are; the first failing one (file order) decides the error
   r->tok_base.assign((size_t)T + 1, 0);
@@ -785,6 +806,7 @@ extern "C" int xdfm_ffm_fill(xdfm_ffm_reader* r, float* labels, int64_t* fm_feat
   // every piece writes its own stretch of the arrays (tens of megabytes per batch: one core's
   // store bandwidth would be the bound)
   const bool sorted = r->in_order;
+  const double tf = r->timing ? now_s() : 0;
   r->pool->run(r->pieces, [=](int t) {
     const Staging& w = r->workers[(size_t)t];
     const size_t base = (size_t)r->tok_base[(size_t)t], cnt = w.dnn_row.size();
@@ -837,5 +859,6 @@ extern "C" int xdfm_ffm_fill(xdfm_ffm_reader* r, float* labels, int64_t* fm_feat
     if (imp_present && w.hi > w.lo) memcpy(imp_present + w.lo, w.imp_present.data(), (size_t)(w.hi - w.lo));
   });
   if (imp_offsets) imp_offsets[n] = r->imp_base[(size_t)r->pieces];
+  if (r->timing) r->t_fill += now_s() - tf;
   return XDFM_OK;
 }

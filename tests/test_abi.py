@@ -75,3 +75,11 @@ def test_fewer_hardware_queues_than_branches_are_read_from_the_runtimes_own_sett
         monkeypatch.setenv("GPU_MAX_HW_QUEUES", q)
         assert hw_queue_limit() == limit, q
         assert graph_replay_refusal() is None
+
+
+def test_graft_entry_build_runs():
+    """__graft_entry__.build() (what the driver calls first): make is a no-op on a built tree, the package
+    imports and the library's ABI number is the header's."""
+    import __graft_entry__ as entry
+
+    entry.build()
