@@ -183,6 +183,8 @@ SIGNATURES = {
     "xdfm_cin_pair_count": [_I32, _I32, _I32, ctypes.POINTER(ctypes.c_int64)],
     "xdfm_cin_pair_sum": [_P, _P, _I64, _I32, _I32, _I32, _I32, _P, _P],
     "xdfm_cin_pair_bwd": [_P, _P, _P, _I64, _I32, _I32, _I32, _I32, _P, _I32, _P, _I32, _P],
+    "xdfm_cin_pair_sum_bf16": [_P, _P, _I64, _I32, _I32, _I32, _I32, _P, _P],
+    "xdfm_cin_pair_bwd_bf16": [_P, _P, _P, _I64, _I32, _I32, _I32, _I32, _P, _I32, _P, _I32, _P],
     "xdfm_cin_bf16_image_bytes": [_I32, _I32, _I32, _PSZ, _PSZ],
     "xdfm_cin_bf16_pack": [_P, _I32, _I32, _I32, _I32, _I32, _P, _P, _P],
     "xdfm_cin_bf16_fwd": [_P, _P, _P, _I64, _I32, _I32, _I32, _I32, _I32, _P, _P],

@@ -325,6 +325,8 @@ class XDeepFMEngine(object):
         self.defer_dw = os.environ.get("XDFM_DEFER_DW", "1") != "0"
         self.tower_serial = os.environ.get("XDFM_TOWER_SERIAL", "1") != "0"
         self._plan_pending = None
+        # bf16 path: the pooled channels' pair sums on the bf16 matrix cores too (0: the exact fp32 forms)
+        self.pair_bf16 = os.environ.get("XDFM_PAIR_BF16", "1") != "0"
         self._plan_at = int(os.environ.get("XDFM_PLAN_AT", "1"))  # 0: ahead of the step, 1: behind the filter images, 2: behind the gather
         self.serial_plan = False  # bench.py's per-kernel timing: the id sort on the main stream
         self._late_event = None
@@ -939,7 +941,8 @@ class XDeepFMEngine(object):
                                                          masked, _ptr(xnext), st))
                     if k in self._split:
                         P, Lp = self._split[k]
-                        _lib.check(lib.xdfm_cin_pair_sum(_ptr(x0), _ptr(xk), B, F, H, D, masked, _ptr(ws["S_%d" % k]), st))
+                        pair_sum = lib.xdfm_cin_pair_sum_bf16 if self.pair_bf16 else lib.xdfm_cin_pair_sum
+                        _lib.check(pair_sum(_ptr(x0), _ptr(xk), B, F, H, D, masked, _ptr(ws["S_%d" % k]), st))
                         _lib.check(lib.xdfm_dense_bf16_fwd(_ptr(ws["S_%d" % k]), _ptr(ws["wp_%d" % k]), _ptr(ws["zeros"]),
                                                            B, P, Lp, 0, _ptr(ws["pool_%d" % k]), _ptr(ws["bf16_ws"]), st))
                         ws["pooled"][:B, off:off + Lp].copy_(ws["pool_%d" % k][:B])
@@ -1543,8 +1546,9 @@ class XDeepFMEngine(object):
                         _lib.check(lib.xdfm_cin_bf16_bwd_dw(_ptr(x0), _ptr(xk), _ptr(d_xnext), B, F, H, D, nh, masked,
                                                             _ptr(gv["cin_f_%d" % k]), L, _ptr(ws["bf16_ws"]), st))
                     if k in self._split:
-                        _lib.check(lib.xdfm_cin_pair_bwd(_ptr(x0), _ptr(xk), _ptr(ws["dS"]), B, F, H, D, masked,
-                                                         _ptr(d_emb), 1, _ptr(d_xk), 1 if nh > 0 else 0, st))
+                        pair_bwd = lib.xdfm_cin_pair_bwd_bf16 if self.pair_bf16 else lib.xdfm_cin_pair_bwd
+                        _lib.check(pair_bwd(_ptr(x0), _ptr(xk), _ptr(ws["dS"]), B, F, H, D, masked,
+                                            _ptr(d_emb), 1, _ptr(d_xk), 1 if nh > 0 else 0, st))
                     continue
                 fold = self.overlap_dnn and self._fold_dx
                 first_writer = fold and k == len(shapes) - 1  # nothing has been put into d_emb yet

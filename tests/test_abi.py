@@ -35,7 +35,7 @@ def test_every_declared_symbol_is_exported_and_bound():
 
 
 def test_abi_version_and_error_channel():
-    assert _lib.lib.xdfm_abi_version() == 3
+    assert _lib.lib.xdfm_abi_version() == 4
     # argument validation happens on the host before any device work
     sz = ctypes.c_size_t()
     rc = _lib.lib.xdfm_dense_bwd_workspace_floats(-1, 0, 0, ctypes.byref(sz))

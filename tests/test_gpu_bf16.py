@@ -305,3 +305,51 @@ def test_bf16_cin_layer_kernels_against_fp64(B, F, H, D, L, Lfull, masked):
     got = dw.view(F, H, Lfull)
     close(got[:, :, :L].cpu().numpy(), W.grad.cpu().numpy(), "d_w")        # zero where the mask is
     assert bool((got[:, :, L:] == 5.0).all())                               # the other columns untouched
+
+
+@pytest.mark.parametrize("B,F,H,D", [
+    (33, 39, 128, 64),   # configs[4]'s layers 1 and 2
+    (5, 7, 40, 32),      # one ragged tile of f, H no multiple of 32
+    (130, 64, 8, 64),    # F at its limit, one partial tile of h
+    (9, 33, 72, 16),     # D = 16: the sum is served (one step over d), the backward falls back to the fp32 form
+    (6, 39, 39, 64),     # masked below: handed to the fp32 kernels
+])
+def test_bf16_pair_sums_against_fp64(B, F, H, D):
+    """xdfm_cin_pair_sum_bf16 / xdfm_cin_pair_bwd_bf16 (the pooled channels' S = X0 Xk^T and its backward on the
+    bf16 matrix cores, one wave per sample) against float64, written and accumulated; shapes they do not serve
+    go to the exact fp32 kernels and must give THEIR numbers (1e-5)."""
+    lib = _lib.lib
+    masked = 1 if (F == H and B == 6) else 0
+    g = torch.Generator(device="cuda").manual_seed(B * 7 + H)
+    x0 = torch.randn(B, F, D, device="cuda", generator=g)
+    xk = x0 if masked else torch.randn(B, H, D, device="cuda", generator=g)
+    cnt = ctypes.c_int64()
+    _lib.check(lib.xdfm_cin_pair_count(F, H, masked, ctypes.byref(cnt)))
+    P = cnt.value
+    S = torch.full((B, P), float("nan"), device="cuda")
+    _lib.check(lib.xdfm_cin_pair_sum_bf16(_p(x0), _p(xk), B, F, H, D, masked, _p(S), None))
+    dS = torch.randn(B, P, device="cuda", generator=g)
+    base0 = torch.randn(B, F, D, device="cuda", generator=g)
+    basek = torch.randn(B, H, D, device="cuda", generator=g)
+    served_bwd = (not masked) and D % 32 == 0
+    rtol = BF16_RTOL if not masked else 1e-5
+    a = x0.double().requires_grad_(True)
+    bq = a if masked else xk.double().requires_grad_(True)
+    full = torch.einsum("bfd,bhd->bfh", a, bq)
+    if masked:
+        iu = torch.triu_indices(F, H, 1, device="cuda")
+        ref = full[:, iu[0], iu[1]]
+    else:
+        ref = full.reshape(B, P)
+    ref.backward(dS.double())
+    close(S.cpu().numpy(), ref.detach().cpu().numpy(), "S", rtol)
+    for acc in (0, 1):
+        dx0 = base0.clone() if acc else torch.full((B, F, D), float("nan"), device="cuda")
+        dxk = None if masked else (basek.clone() if acc else torch.full((B, H, D), float("nan"), device="cuda"))
+        _lib.check(lib.xdfm_cin_pair_bwd_bf16(_p(x0), _p(xk), _p(dS), B, F, H, D, masked, _p(dx0), acc, _p(dxk), acc, None))
+        torch.cuda.synchronize()
+        tol = rtol if served_bwd or masked else 1e-5
+        close(dx0.cpu().numpy(), (a.grad + (base0.double() if acc else 0)).cpu().numpy(), "d_x0 (accumulate=%d)" % acc, tol)
+        if not masked:
+            close(dxk.cpu().numpy(), (bq.grad + (basek.double() if acc else 0)).cpu().numpy(),
+                  "d_xk (accumulate=%d)" % acc, tol)
