@@ -465,10 +465,10 @@ int xdfm_cin_pair_bwd(const float* x0, const float* xk, const float* dS, int64_t
                       int32_t D, int32_t masked, float* d_x0, int32_t accumulate_x0, float* d_xk,
                       int32_t accumulate_xk, void* stream);
 /* The same two products with their operands rounded to bf16 on the bf16 matrix cores (fp32 sums), for the bf16
- * path's wide layers (north_star's bf16 bar, 2e-2): one wave per sample, no staging through LDS.  Served: the
- * unmasked layers (xk != x0) with F <= 64 and D a multiple of 16 (pair_sum) / 32 (pair_bwd, which also wants H a
- * multiple of 8) up to 64; x0, xk, dS 16-byte aligned.  Every other shape is handed to the exact fp32 forms
- * above, so the calls can replace them anywhere.  (Same reference lines: xDeepFM.py:253-270.) */
+ * path's wide layers (north_star's bf16 bar, 2e-2): one wave per sample, no staging through LDS.  Served: F <= 64
+ * and D a multiple of 16 (pair_sum) / 32 (pair_bwd) up to 64, the masked layer (xk == x0) and the unmasked ones
+ * (xk != x0; pair_bwd then also wants H a multiple of 8); x0, xk, dS 16-byte aligned.  Every other shape is handed
+ * to the exact fp32 forms above, so the calls can replace them anywhere.  (Same reference lines: xDeepFM.py:253-270.) */
 int xdfm_cin_pair_sum_bf16(const float* x0, const float* xk, int64_t B, int32_t F, int32_t H, int32_t D,
                            int32_t masked, float* S, void* stream);
 int xdfm_cin_pair_bwd_bf16(const float* x0, const float* xk, const float* dS, int64_t B, int32_t F, int32_t H,

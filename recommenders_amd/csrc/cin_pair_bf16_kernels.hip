@@ -12,8 +12,12 @@
 // 0.5 - 1.2 GB per launch at configs[4]'s sizes and the fp32 forms reached 0.26 - 0.34 of the HBM rate (one
 // sample's rows staged through 46 - 79 KB of LDS per block, a barrier, 16 times the matrix instructions).
 //
-// Served: the unmasked layers with D a multiple of 16 up to 64 and F <= 64; the entry points hand every other
-// shape to the exact fp32 kernels.
+// The masked first layer (xk == x0, pairs f < h in the row-major strict upper triangle): S is the full square's
+// product of which the triangle is stored; its backward is ONE product, d_X0 = (G + G^T) X0, with the symmetric
+// matrix read element by element out of the compact triangle.
+//
+// Served: D a multiple of 16 (sums) / 32 (backward) up to 64 and F <= 64; the unmasked backward also wants H a
+// multiple of 8.  The entry points hand every other shape to the exact fp32 kernels.
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
@@ -27,6 +31,9 @@ using namespace xdfm_bf16;
 namespace {
 
 typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+// first pair index of row f in the strict upper triangle of an F x F matrix (cin_pool_kernels.hip)
+__host__ __device__ inline int tri_start(int f, int F) { return f * (2 * F - f - 1) / 2; }
 
 __device__ __forceinline__ bf16x8 frag_of(const float (&v)[8]) {
   uint4 p;
@@ -66,7 +73,7 @@ __device__ __forceinline__ f32x16 zero16() {
 // NFT 32-row tiles of f, NKS = D / 16 steps over d.  The X0 fragments stay in registers for the sample; per
 // 32 rows of Xk: NKS fragment loads, NFT * NKS matrix instructions, the NFT result tiles stored (a register
 // holds 32 consecutive h of one f: 128-byte stores).
-template <int NFT, int NKS>
+template <int NFT, int NKS, bool MASKED>
 __global__ __launch_bounds__(256) void cin_pair_sum_bf16_kernel(int64_t B, int F, int H, const float* __restrict__ x0,
                                                                 const float* __restrict__ xk, float* __restrict__ S) {
   xdfm::Stamp stamp_(xdfm::kStampCinFwd);
@@ -77,7 +84,7 @@ __global__ __launch_bounds__(256) void cin_pair_sum_bf16_kernel(int64_t B, int F
   if (b >= B) return;  // (wave-uniform; no barrier in this kernel)
   const float* xa = x0 + b * F * D;
   const float* xb = xk + b * H * D;
-  float* out = S + b * F * H;
+  float* out = S + b * (MASKED ? F * (F - 1) / 2 : F * H);
   bf16x8 A[NFT][NKS];
 #pragma unroll
   for (int ft = 0; ft < NFT; ++ft) {
@@ -103,7 +110,11 @@ __global__ __launch_bounds__(256) void cin_pair_sum_bf16_kernel(int64_t B, int F
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
           const int f = 32 * ft + tile_row(i, half);
-          if (f < F) out[f * H + h] = acc[ft][i];
+          if (MASKED) {
+            if (f < F && h > f) out[tri_start(f, F) + h - f - 1] = acc[ft][i];
+          } else if (f < F) {
+            out[f * H + h] = acc[ft][i];
+          }
         }
     }
   }
@@ -114,7 +125,7 @@ __global__ __launch_bounds__(256) void cin_pair_sum_bf16_kernel(int64_t B, int F
 // 16-byte loads each) and the Xk fragments of the NDT column tiles (eight 4-byte loads each), NFT * NDT
 // matrix instructions; the NFT * NDT result tiles leave at the end.  Then d_Xk, 32 rows of h at a time: the X0
 // fragments (K = f, ceil(F / 16) steps) stay in registers, the G^T fragments are eight 4-byte loads.
-template <int NFT, int NDT>
+template <int NFT, int NDT, bool MASKED>
 __global__ __launch_bounds__(256) void cin_pair_bwd_bf16_kernel(int64_t B, int F, int H, const float* __restrict__ x0,
                                                                 const float* __restrict__ xk,
                                                                 const float* __restrict__ dS, float* __restrict__ d_x0,
@@ -128,7 +139,7 @@ __global__ __launch_bounds__(256) void cin_pair_bwd_bf16_kernel(int64_t B, int F
   if (b >= B) return;
   const float* xa = x0 + b * F * D;
   const float* xb = xk + b * H * D;
-  const float* g = dS + b * F * H;
+  const float* g = dS + b * (MASKED ? F * (F - 1) / 2 : F * H);
   {
     f32x16 acc[NFT][NDT];
 #pragma unroll
@@ -141,8 +152,20 @@ __global__ __launch_bounds__(256) void cin_pair_bwd_bf16_kernel(int64_t B, int F
 #pragma unroll
       for (int ft = 0; ft < NFT; ++ft) {
         const int f = 32 * ft + lr;
-        // (H is a multiple of 8 here: a fragment lies inside [0, H) or outside it)
-        Ga[ft] = frag_rows(g + f * H + hk, f < F && hk < H);
+        if (MASKED) {
+          // G + G^T out of the triangle: (f, h) and (h, f) are one pair, the diagonal is empty
+          float v[8];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const int h = hk + i;
+            const int lo = f < h ? f : h, hi = f < h ? h : f;
+            v[i] = (f < F && h < H && f != h) ? g[tri_start(lo, F) + hi - lo - 1] : 0.f;
+          }
+          Ga[ft] = frag_of(v);
+        } else {
+          // (H is a multiple of 8 here: a fragment lies inside [0, H) or outside it)
+          Ga[ft] = frag_rows(g + f * H + hk, f < F && hk < H);
+        }
       }
 #pragma unroll
       for (int dt = 0; dt < NDT; ++dt) Xb[dt] = frag_strided(xb + (int64_t)hk * D + 32 * dt + lr, D, H - hk, true);
@@ -165,7 +188,7 @@ __global__ __launch_bounds__(256) void cin_pair_bwd_bf16_kernel(int64_t B, int F
           }
         }
   }
-  if (d_xk == nullptr) return;
+  if (MASKED || d_xk == nullptr) return;
   bf16x8 Xa[NKF][NDT];
 #pragma unroll
   for (int ks = 0; ks < NKF; ++ks) {
@@ -202,9 +225,9 @@ __global__ __launch_bounds__(256) void cin_pair_bwd_bf16_kernel(int64_t B, int F
 }
 
 bool served(int64_t B, int F, int H, int D, int masked, const float* x0, const float* xk, bool bwd) {
-  if (masked || xk == x0 || B <= 0) return false;
+  if (B <= 0 || (masked ? (xk != x0 || F != H) : xk == x0)) return false;
   if (F > 64 || D > 64 || D % (bwd ? 32 : 16) != 0) return false;
-  if (bwd && H % 8 != 0) return false;  // a G fragment is 8 consecutive h of one row, 16-byte aligned
+  if (bwd && !masked && H % 8 != 0) return false;  // a G fragment is 8 consecutive h of one row, 16-byte aligned
   return true;
 }
 
@@ -219,9 +242,14 @@ extern "C" int xdfm_cin_pair_sum_bf16(const float* x0, const float* xk, int64_t 
   const dim3 grid((unsigned)((B + 3) / 4)), block(256);
   const int nft = (F + 31) / 32, nks = D / 16;
 #define SUM_CASE(NFT_, NKS_)                                                                                  \
-  if (nft == NFT_ && nks == NKS_)                                                                             \
-  XDFM_LAUNCH("cin_pair_sum_bf16_kernel<" #NFT_ ", " #NKS_ ">", stream, (cin_pair_sum_bf16_kernel<NFT_, NKS_>), grid, \
-              block, 0, B, F, H, x0, xk, S)
+  if (nft == NFT_ && nks == NKS_) {                                                                           \
+    if (masked)                                                                                               \
+      XDFM_LAUNCH("cin_pair_sum_bf16_kernel<" #NFT_ ", " #NKS_ ", masked>", stream,                           \
+                  (cin_pair_sum_bf16_kernel<NFT_, NKS_, true>), grid, block, 0, B, F, H, x0, xk, S);          \
+    else                                                                                                      \
+      XDFM_LAUNCH("cin_pair_sum_bf16_kernel<" #NFT_ ", " #NKS_ ">", stream,                                   \
+                  (cin_pair_sum_bf16_kernel<NFT_, NKS_, false>), grid, block, 0, B, F, H, x0, xk, S);         \
+  }
   SUM_CASE(1, 1);
   SUM_CASE(1, 2);
   SUM_CASE(1, 3);
@@ -240,14 +268,22 @@ extern "C" int xdfm_cin_pair_bwd_bf16(const float* x0, const float* xk, const fl
                                       float* d_xk, int32_t accumulate_xk, void* stream) {
   if (!served(B, F, H, D, masked, x0, xk, true))
     return xdfm_cin_pair_bwd(x0, xk, dS, B, F, H, D, masked, d_x0, accumulate_x0, d_xk, accumulate_xk, stream);
-  XDFM_REQUIRE(x0 && xk && dS && d_x0 && d_xk && F > 0 && H > 0, "xdfm_cin_pair_bwd_bf16: bad argument");
+  XDFM_REQUIRE(x0 && xk && dS && d_x0 && F > 0 && H > 0, "xdfm_cin_pair_bwd_bf16: bad argument");
+  XDFM_REQUIRE((xk == x0) == (d_xk == nullptr), "xdfm_cin_pair_bwd_bf16: d_xk must be NULL exactly when xk == x0");
   XDFM_REQUIRE((reinterpret_cast<uintptr_t>(dS) & 15) == 0, "xdfm_cin_pair_bwd_bf16: dS must be 16-byte aligned");
   const dim3 grid((unsigned)((B + 3) / 4)), block(256);
   const int nft = (F + 31) / 32, ndt = D / 32;
 #define BWD_CASE(NFT_, NDT_)                                                                                  \
-  if (nft == NFT_ && ndt == NDT_)                                                                             \
-  XDFM_LAUNCH("cin_pair_bwd_bf16_kernel<" #NFT_ ", " #NDT_ ">", stream, (cin_pair_bwd_bf16_kernel<NFT_, NDT_>), grid, \
-              block, 0, B, F, H, x0, xk, dS, d_x0, accumulate_x0 ? 1 : 0, d_xk, accumulate_xk ? 1 : 0)
+  if (nft == NFT_ && ndt == NDT_) {                                                                           \
+    if (masked)                                                                                               \
+      XDFM_LAUNCH("cin_pair_bwd_bf16_kernel<" #NFT_ ", " #NDT_ ", masked>", stream,                           \
+                  (cin_pair_bwd_bf16_kernel<NFT_, NDT_, true>), grid, block, 0, B, F, H, x0, xk, dS, d_x0,    \
+                  accumulate_x0 ? 1 : 0, d_xk, accumulate_xk ? 1 : 0);                                        \
+    else                                                                                                      \
+      XDFM_LAUNCH("cin_pair_bwd_bf16_kernel<" #NFT_ ", " #NDT_ ">", stream,                                   \
+                  (cin_pair_bwd_bf16_kernel<NFT_, NDT_, false>), grid, block, 0, B, F, H, x0, xk, dS, d_x0,   \
+                  accumulate_x0 ? 1 : 0, d_xk, accumulate_xk ? 1 : 0);                                        \
+  }
   BWD_CASE(1, 1);
   BWD_CASE(1, 2);
   BWD_CASE(2, 1);

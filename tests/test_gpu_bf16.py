@@ -312,14 +312,15 @@ def test_bf16_cin_layer_kernels_against_fp64(B, F, H, D, L, Lfull, masked):
     (5, 7, 40, 32),      # one ragged tile of f, H no multiple of 32
     (130, 64, 8, 64),    # F at its limit, one partial tile of h
     (9, 33, 72, 16),     # D = 16: the sum is served (one step over d), the backward falls back to the fp32 form
-    (6, 39, 39, 64),     # masked below: handed to the fp32 kernels
+    (6, 39, 39, 64),     # masked below (the first layer: xk is x0, pairs f < h)
+    (70, 20, 20, 48),    # masked; D = 48: the sum is served, the backward falls back
 ])
 def test_bf16_pair_sums_against_fp64(B, F, H, D):
     """xdfm_cin_pair_sum_bf16 / xdfm_cin_pair_bwd_bf16 (the pooled channels' S = X0 Xk^T and its backward on the
-    bf16 matrix cores, one wave per sample) against float64, written and accumulated; shapes they do not serve
-    go to the exact fp32 kernels and must give THEIR numbers (1e-5)."""
+    bf16 matrix cores, one wave per sample) against float64, written and accumulated, unmasked and masked (the
+    triangle of pairs); shapes they do not serve go to the exact fp32 kernels and must give THEIR numbers (1e-5)."""
     lib = _lib.lib
-    masked = 1 if (F == H and B == 6) else 0
+    masked = 1 if F == H else 0
     g = torch.Generator(device="cuda").manual_seed(B * 7 + H)
     x0 = torch.randn(B, F, D, device="cuda", generator=g)
     xk = x0 if masked else torch.randn(B, H, D, device="cuda", generator=g)
@@ -331,8 +332,8 @@ def test_bf16_pair_sums_against_fp64(B, F, H, D):
     dS = torch.randn(B, P, device="cuda", generator=g)
     base0 = torch.randn(B, F, D, device="cuda", generator=g)
     basek = torch.randn(B, H, D, device="cuda", generator=g)
-    served_bwd = (not masked) and D % 32 == 0
-    rtol = BF16_RTOL if not masked else 1e-5
+    served_bwd = D % 32 == 0
+    rtol = BF16_RTOL
     a = x0.double().requires_grad_(True)
     bq = a if masked else xk.double().requires_grad_(True)
     full = torch.einsum("bfd,bhd->bfh", a, bq)
@@ -348,7 +349,7 @@ def test_bf16_pair_sums_against_fp64(B, F, H, D):
         dxk = None if masked else (basek.clone() if acc else torch.full((B, H, D), float("nan"), device="cuda"))
         _lib.check(lib.xdfm_cin_pair_bwd_bf16(_p(x0), _p(xk), _p(dS), B, F, H, D, masked, _p(dx0), acc, _p(dxk), acc, None))
         torch.cuda.synchronize()
-        tol = rtol if served_bwd or masked else 1e-5
+        tol = rtol if served_bwd else 1e-5
         close(dx0.cpu().numpy(), (a.grad + (base0.double() if acc else 0)).cpu().numpy(), "d_x0 (accumulate=%d)" % acc, tol)
         if not masked:
             close(dxk.cpu().numpy(), (bq.grad + (basek.double() if acc else 0)).cpu().numpy(),
