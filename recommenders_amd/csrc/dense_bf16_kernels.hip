@@ -16,6 +16,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <cstdlib>
 
 #include "act.h"
 #include "cin_bf16.h"
@@ -288,6 +289,250 @@ __global__ __launch_bounds__(256, 2) void dense_bf16_kernel(GemmArgs g, float* _
       }
 }
 
+// ---------------------------------------------------------------- the same product with 16-byte loads
+// The kernel above brings its operands in with 4- and 8-byte loads: 24 load instructions per thread and k step,
+// and a CU's address unit spends as long on a 256-byte wave load as on a 1 KB one -- the products of configs[4]
+// ran at the rate those instructions issue (7 % matrix-core busy).  Here (K and Nout multiples of 4, operands
+// 16-byte aligned, the reduction a multiple of 32 per split) every load is 16 bytes:
+//   * an operand whose k index is the fast one in memory (x in the forward product, dz and w in the input
+//     gradient): a thread takes 4 consecutive k of 4 rows; LDS keeps [row][pairs of k] as above;
+//   * an operand whose ROW index is the fast one (w in the forward product, x and dz in the weight gradient): a
+//     thread takes 4 consecutive rows of 2 x 2 consecutive k and stores the 4 packed pairs side by side; LDS keeps
+//     [pair of k][row] (pitch 136 words: the two halves of a wave read banks 32 apart), and a lane's fragment is 4
+//     words from 4 rows of that image instead of one 16-byte read.
+constexpr int kPitchT = 136;
+
+template <int MODE>
+__global__ __launch_bounds__(256, 2) void dense_bf16_v4_kernel(GemmArgs g, float* __restrict__ part) {
+  __shared__ __align__(16) uint32_t as[2][kBM * kPitch];
+  __shared__ __align__(16) uint32_t bs[2][kBN * kPitch];
+  constexpr bool A_KFAST = MODE != kDw, B_KFAST = MODE == kDx;
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, r = lane & 31;
+  const int m0 = blockIdx.y * kBM, n0 = blockIdx.x * kBN;
+  const int split = blockIdx.z;
+  const int k_lo = split * g.r_per_split;
+  int k_hi = k_lo + g.r_per_split;
+  if (k_hi > g.R) k_hi = g.R;
+  const int steps = k_hi > k_lo ? (k_hi - k_lo) / kBK : 0;
+  const bool with_act = g.act != XDFM_ACT_IDENTITY;
+  const int lda = MODE == kDx ? g.Nout : g.K, ldb = g.Nout;
+  const int limA = MODE == kDw ? g.K : g.M;  // rows of A that exist in memory (kDw: row K is the row of ones)
+  const int limB = g.N;
+
+  // per-thread sources: k-fast: 4 rows (i), one quad of k; row-fast: 2 pairs of k (i), one quad of rows
+  const float* pa[4];
+  const float* pa2[4];
+  const float* pb[4];
+  const float* pb2[4];
+  bool ka[4], kb[4];
+  bool onesA = false;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    pa[i] = pa2[i] = pb[i] = pb2[i] = nullptr;
+    ka[i] = kb[i] = false;
+  }
+  if (A_KFAST) {
+    const float* base = MODE == kDx ? g.dy : g.x;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = m0 + (tid >> 3) + 32 * i;
+      ka[i] = row < limA;
+      const int64_t off = (int64_t)(ka[i] ? row : limA - 1) * lda + k_lo + 4 * (tid & 7);
+      pa[i] = base + off;
+      if (MODE == kDx) pa2[i] = g.y + off;
+    }
+  } else {  // kDw: A(m,k) = x[k][m]
+    const int rq = m0 + 4 * (tid & 31);
+    ka[0] = ka[1] = rq < limA;
+    onesA = rq == limA;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int kk = k_lo + 2 * ((tid >> 5) + 8 * i);
+      pa[i] = g.x + (int64_t)kk * lda + (ka[0] ? rq : limA - 4);
+    }
+  }
+  if (B_KFAST) {  // kDx: B(k,n) = w[n][k]
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = n0 + (tid >> 3) + 32 * i;
+      kb[i] = row < limB;
+      pb[i] = g.w + (int64_t)(kb[i] ? row : limB - 1) * ldb + k_lo + 4 * (tid & 7);
+    }
+  } else {  // kFwd: w[k][n]; kDw: dz[k][n]
+    const int rq = n0 + 4 * (tid & 31);
+    kb[0] = kb[1] = rq < limB;
+    const float* base = MODE == kDw ? g.dy : g.w;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int kk = k_lo + 2 * ((tid >> 5) + 8 * i);
+      const int64_t off = (int64_t)kk * ldb + (kb[0] ? rq : limB - 4);
+      pb[i] = base + off;
+      if (MODE == kDw) pb2[i] = g.y + off;
+    }
+  }
+  const int64_t stepa = A_KFAST ? kBK : (int64_t)kBK * lda;
+  const int64_t stepb = B_KFAST ? kBK : (int64_t)kBK * ldb;
+
+  // (loads two k steps ahead through a second register set were tried: 236 - 256 registers with spills, the
+  // forward product no faster, the backward ones 40 % slower)
+  f4 av[4], ay[4], bv[4], by4[4];
+  auto issue = [&]() {
+    if (A_KFAST) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        av[i] = *reinterpret_cast<const f4*>(pa[i]);
+        if (MODE == kDx && with_act) ay[i] = *reinterpret_cast<const f4*>(pa2[i]);
+        pa[i] += stepa;
+        if (MODE == kDx) pa2[i] += stepa;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        av[2 * i] = *reinterpret_cast<const f4*>(pa[i]);
+        av[2 * i + 1] = *reinterpret_cast<const f4*>(pa[i] + lda);
+        pa[i] += stepa;
+      }
+    }
+    if (B_KFAST) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        bv[i] = *reinterpret_cast<const f4*>(pb[i]);
+        pb[i] += stepb;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        bv[2 * i] = *reinterpret_cast<const f4*>(pb[i]);
+        bv[2 * i + 1] = *reinterpret_cast<const f4*>(pb[i] + ldb);
+        if (MODE == kDw && with_act) {
+          by4[2 * i] = *reinterpret_cast<const f4*>(pb2[i]);
+          by4[2 * i + 1] = *reinterpret_cast<const f4*>(pb2[i] + ldb);
+        }
+        pb[i] += stepb;
+        if (MODE == kDw) pb2[i] += stepb;
+      }
+    }
+  };
+  auto stash = [&](int buf) {
+    if (A_KFAST) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        f4 v = av[i];
+        if (MODE == kDx && with_act) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] *= act_grad(ay[i][e], g.act);
+        }
+        if (!ka[i]) v = f4{0.f, 0.f, 0.f, 0.f};
+        const int row = (tid >> 3) + 32 * i;
+        *reinterpret_cast<uint2*>(&as[buf][row * kPitch + 2 * (tid & 7)]) =
+            make_uint2(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]));
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        f4 v0 = av[2 * i], v1 = av[2 * i + 1];
+        if (!ka[0]) {
+          const float one = onesA ? 1.f : 0.f;
+          v0 = f4{one, 0.f, 0.f, 0.f};
+          v1 = v0;
+        }
+        const int kp = (tid >> 5) + 8 * i;
+        *reinterpret_cast<uint4*>(&as[buf][kp * kPitchT + 4 * (tid & 31)]) =
+            make_uint4(pack_bf16(v0[0], v1[0]), pack_bf16(v0[1], v1[1]), pack_bf16(v0[2], v1[2]), pack_bf16(v0[3], v1[3]));
+      }
+    }
+    if (B_KFAST) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        f4 v = bv[i];
+        if (!kb[i]) v = f4{0.f, 0.f, 0.f, 0.f};
+        const int row = (tid >> 3) + 32 * i;
+        *reinterpret_cast<uint2*>(&bs[buf][row * kPitch + 2 * (tid & 7)]) =
+            make_uint2(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]));
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        f4 v0 = bv[2 * i], v1 = bv[2 * i + 1];
+        if (MODE == kDw && with_act) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            v0[e] *= act_grad(by4[2 * i][e], g.act);
+            v1[e] *= act_grad(by4[2 * i + 1][e], g.act);
+          }
+        }
+        if (!kb[0]) {
+          v0 = f4{0.f, 0.f, 0.f, 0.f};
+          v1 = v0;
+        }
+        const int kp = (tid >> 5) + 8 * i;
+        *reinterpret_cast<uint4*>(&bs[buf][kp * kPitchT + 4 * (tid & 31)]) =
+            make_uint4(pack_bf16(v0[0], v1[0]), pack_bf16(v0[1], v1[1]), pack_bf16(v0[2], v1[2]), pack_bf16(v0[3], v1[3]));
+      }
+    }
+  };
+  auto frag = [&](const uint32_t* T, bool kfast, int row, int col) {
+    if (kfast) return as_frag(*reinterpret_cast<const uint4*>(T + row * kPitch + col));
+    uint4 q;
+    q.x = T[(col + 0) * kPitchT + row];
+    q.y = T[(col + 1) * kPitchT + row];
+    q.z = T[(col + 2) * kPitchT + row];
+    q.w = T[(col + 3) * kPitchT + row];
+    return as_frag(q);
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+
+  auto products = [&](int buf) {
+    const uint32_t* A = as[buf];
+    const uint32_t* Bt = bs[buf];
+#pragma unroll
+    for (int ks = 0; ks < kBK / 16; ++ks) {
+      const int col = 8 * ks + 4 * half;
+      bf16x8 a[2], b[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) a[i] = frag(A, A_KFAST, wm + 32 * i + r, col);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) b[j] = frag(Bt, B_KFAST, wn + 32 * j + r, col);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = mfma(a[i], b[j], acc[i][j]);
+    }
+  };
+  if (steps > 0) {
+    issue();
+    stash(0);
+  }
+  __syncthreads();
+  for (int s = 0; s < steps; ++s) {
+    if (s + 1 < steps) issue();
+    products(s & 1);
+    if (s + 1 < steps) stash((s + 1) & 1);
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int m = m0 + wm + 32 * i + tile_row(e, half), n = n0 + wn + 32 * j + r;
+        if (g.splits == 1)
+          emit<MODE>(g, m, n, acc[i][j][e]);
+        else if (m < g.M && n < g.N)
+          part[((int64_t)split * g.M + m) * g.N + n] = acc[i][j][e];
+      }
+}
+
 template <int MODE>
 __global__ void dense_bf16_reduce_kernel(GemmArgs g, const float* __restrict__ part) {
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -318,7 +563,14 @@ int launch(GemmArgs g, float* workspace, hipStream_t st) {
   // even leading dimensions where pairs of k are loaded as 8 bytes; R a multiple of 32 (so is every split)
   const bool fast = g.R % kBK == 0 && g.B * (int64_t)g.K < lim && g.B * (int64_t)g.Nout < lim &&
                     (MODE == kFwd ? g.K % 2 == 0 : (MODE == kDx ? g.Nout % 2 == 0 : true));
-  if (fast)
+  static const bool v4_on = !(getenv("XDFM_DENSE_V4") && getenv("XDFM_DENSE_V4")[0] == '0');
+  const auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  const bool v4 = v4_on && fast && g.K % 4 == 0 && g.Nout % 4 == 0 && g.K >= 4 && g.Nout >= 4 && al16(g.x) &&
+                  al16(g.w) && (MODE == kFwd || (al16(g.y) && al16(g.dy)));
+  if (v4)
+    XDFM_LAUNCH(MODE == kFwd ? "dense_bf16_v4_kernel<fwd>" : (MODE == kDx ? "dense_bf16_v4_kernel<dx>" : "dense_bf16_v4_kernel<dw>"),
+                st, (dense_bf16_v4_kernel<MODE>), grid, dim3(256), 0, g, workspace);
+  else if (fast)
     XDFM_LAUNCH(name, st, (dense_bf16_kernel<MODE, true>), grid, dim3(256), 0, g, workspace);
   else
     XDFM_LAUNCH(name, st, (dense_bf16_kernel<MODE, false>), grid, dim3(256), 0, g, workspace);

@@ -242,17 +242,24 @@ class XDeepFMEngine(object):
             if self.catchup_on:
                 self.row_step = torch.zeros((self.N,), dtype=torch.int32, device=dev)
         self.dense_shapes = dense_param_shapes(hp)
+        # one flat buffer; segment i = [offs[i], offs[i + 1]).  bf16 path: every parameter starts on a 16-byte
+        # boundary (the matrix products load their operands 16 bytes at a time); the filler at a segment's end
+        # holds zeros, takes zero gradients and stays zero under every optimizer, and adds nothing to a norm
+        align = 4 if self.bf16 else 1
         offs = [0]
+        sizes = []
         for shape in self.dense_shapes.values():
-            offs.append(offs[-1] + int(np.prod(shape)))
+            sizes.append(int(np.prod(shape)))
+            offs.append((offs[-1] + sizes[-1] + align - 1) // align * align)
         self.dense_off = offs
+        self._dense_sizes = sizes
         n_dense = max(offs[-1], 1)
         self.dense = torch.zeros((n_dense,), dtype=f32, device=dev)
         self.dense_grad = torch.zeros((n_dense,), dtype=f32, device=dev)
         self.views, self.grad_views = {}, {}
         for i, (name, shape) in enumerate(self.dense_shapes.items()):
-            self.views[name] = self.dense[offs[i] : offs[i + 1]].view(shape)
-            self.grad_views[name] = self.dense_grad[offs[i] : offs[i + 1]].view(shape)
+            self.views[name] = self.dense[offs[i] : offs[i] + sizes[i]].view(shape)
+            self.grad_views[name] = self.dense_grad[offs[i] : offs[i] + sizes[i]].view(shape)
         self.bn_state = {name: torch.zeros(shape, dtype=f32, device=dev)
                          for name, shape in bn_state_shapes(hp).items()}
         # ---- optimizer slots
@@ -409,8 +416,27 @@ class XDeepFMEngine(object):
                        ("slot/lin_m", self.lin_m), ("slot/lin_v", self.lin_v),
                        ("slot/dense_m", self.dense_m), ("slot/dense_v", self.dense_v)):
             if t is not None:
-                sd[key] = t
+                # (the dense slots without the alignment filler of the bf16 path: one layout for every engine)
+                sd[key] = self._dense_compact(t) if key.startswith("slot/dense_") else t
         return sd
+
+    def _dense_compact(self, flat):
+        offs, sizes = self.dense_off, self._dense_sizes
+        if offs[-1] == sum(sizes):
+            return flat
+        return torch.cat([flat[offs[i]:offs[i] + sizes[i]] for i in range(len(sizes))]) if sizes else flat[:0]
+
+    def _dense_expand(self, flat, compact):
+        """compact (parameters back to back) into the flat buffer's segments."""
+        offs, sizes = self.dense_off, self._dense_sizes
+        compact = torch.as_tensor(compact).reshape(-1)
+        if offs[-1] == sum(sizes):
+            flat[:compact.numel()].copy_(compact.to(flat.device))
+            return
+        at = 0
+        for i in range(len(sizes)):
+            flat[offs[i]:offs[i] + sizes[i]].copy_(compact[at:at + sizes[i]].to(flat.device))
+            at += sizes[i]
 
     def load_state(self, sd, strict=True):
         """Load parameters (and, when present, optimizer slots) from a dict of tensors /
@@ -438,7 +464,10 @@ class XDeepFMEngine(object):
                        ("slot/lin_m", self.lin_m), ("slot/lin_v", self.lin_v),
                        ("slot/dense_m", self.dense_m), ("slot/dense_v", self.dense_v)):
             if t is not None and key in sd:
-                put(t, sd[key])
+                if key.startswith("slot/dense_"):
+                    self._dense_expand(t, sd[key])
+                else:
+                    put(t, sd[key])
         if "step" in sd:
             self.step = int(sd["step"])
             self.b1p = np.float32(sd.get("b1p", 0.9 ** self.step))
