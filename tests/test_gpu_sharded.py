@@ -76,19 +76,26 @@ def test_sharded_step_equals_plain_engine_and_oracle(optimizer, virtual_world):
     assert np.abs(plain.state_dict()["embedding"].cpu().numpy() - table.cpu().numpy()).max() <= 1e-6
 
 
-@pytest.mark.parametrize("embedding_update", ["sparse_rows", "dense_exact"])
+@pytest.mark.parametrize("embedding_update", ["sparse_rows", "dense_exact", "sparse_rows+bn", "sparse_rows+dropout",
+                                              "sparse_rows+bf16"])
 def test_whole_step_graph_equals_eager_exchanges(embedding_update):
     """Batches of one shape, each announcing its successor: once both routing generations have replayed their
     local graphs the whole step -- exchanges, owner-side update, the next batch's routing -- is one graph per
     generation (_StepGraph).  Bit for bit the engine whose exchanges stay eager, through a batch that does not
     fit its request (found out from the tagged answer of the routing inside the previous graph; that batch
     goes with sized requests) and a step without an announced successor."""
+    embedding_update, _, variant = embedding_update.partition("+")
     extra = dict(embed_l2=0.01, layer_l2=0.01) if embedding_update == "dense_exact" else {}
+    if variant == "bn":  # moving statistics move once per step, captured or not
+        extra.update(enable_BN=True, loss="cross_entropy_loss")
+    if variant == "dropout":  # masks are drawn from the device-side step count
+        extra.update(user_dropout=True, dropout=[0.3, 0.2])
+    dtype = "bf16" if variant == "bf16" else None
     hp = make_hp(optimizer="adam", learning_rate=0.01, FEATURE_COUNT=300, cross_l2=0.01, **extra)
     rng = np.random.default_rng(15)
     p32 = X.init_params(hp, seed=9)
-    whole = ShardedXDeepFMEngine(hp, seed=3, embedding_update=embedding_update)
-    eager = ShardedXDeepFMEngine(hp, seed=3, embedding_update=embedding_update)
+    whole = ShardedXDeepFMEngine(hp, seed=3, embedding_update=embedding_update, compute_dtype=dtype)
+    eager = ShardedXDeepFMEngine(hp, seed=3, embedding_update=embedding_update, compute_dtype=dtype)
     eager.graph_step = False
     assert whole.graph_step
     for e in (whole, eager):
