@@ -234,8 +234,10 @@ def run_cpu_baseline(hp, batches, budget_s=20.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=10)
+    # (400 timed steps = 0.15 s on one GPU: the launch queue is in its steady state for most of them; at 100 the
+    # line read 1 % lower)
+    ap.add_argument("--steps", type=int, default=400)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=8192)
     ap.add_argument("--dim", type=int, default=16)
     ap.add_argument("--features", type=int, default=1 << 25)

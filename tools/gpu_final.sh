@@ -10,5 +10,5 @@ out=gpurun_out/final_$tag
 mkdir -p $out
 timeout -k 10 400 python3 bench.py > $out/bench.json 2> $out/bench.err || { tail -5 $out/bench.err; exit 1; }
 timeout -s KILL 200 rocprofv3 --kernel-trace --stats --output-format csv -d $out/eager -o t -- python3 bench.py --steps 30 --no-cpu-baseline --no-graph --profile-steps 0 > $out/eager.json 2> $out/eager.err || { tail -5 $out/eager.err; exit 1; }
-timeout -s KILL 200 rocprofv3 --kernel-trace --stats --output-format csv -d $out/graph -o t -- python3 bench.py --steps 100 --no-cpu-baseline --profile-steps 2 > $out/graph.json 2> $out/graph.err || { tail -5 $out/graph.err; exit 1; }
+timeout -s KILL 200 rocprofv3 --kernel-trace --stats --output-format csv -d $out/graph -o t -- python3 bench.py --steps 400 --no-cpu-baseline --profile-steps 2 > $out/graph.json 2> $out/graph.err || { tail -5 $out/graph.err; exit 1; }
 tools/gpu_pmc_traffic.sh final_$tag && echo final done
