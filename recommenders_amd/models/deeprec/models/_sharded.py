@@ -420,12 +420,16 @@ class RowShardExchange(object):
         if plan.fit_tagged is not None:
             view, want = self._fit_bufs[plan.fit_tagged][3], self._fit_expect[plan.fit_tagged]
             t0 = time.monotonic()
+            spins = 0
             while True:
                 v = view.copy()
                 if bool(((v >> 32) == want).all()):
                     break
-                if time.monotonic() - t0 > 120.0:
-                    raise RuntimeError("the routing inside the captured step did not report (replay %d)" % want)
+                spins += 1
+                if spins % 256 == 0:
+                    time.sleep(0)  # (let a reader thread of the caller's have the interpreter)
+                    if time.monotonic() - t0 > 120.0:
+                        raise RuntimeError("the routing inside the captured step did not report (replay %d)" % want)
             plan.gmax = int((v & 0xFFFFFFFF).max())
             return plan.gmax <= plan.cap
         if plan.fit_event is not None:
