@@ -354,3 +354,41 @@ def test_bf16_pair_sums_against_fp64(B, F, H, D):
         if not masked:
             close(dxk.cpu().numpy(), (bq.grad + (basek.double() if acc else 0)).cpu().numpy(),
                   "d_xk (accumulate=%d)" % acc, tol)
+
+
+def test_bf16_engine_checkpoints_in_the_layout_every_engine_reads():
+    """The bf16 engine starts every parameter of its flat buffer on a 16-byte boundary (filler between them); its
+    state_dict hands the dense optimizer slots out without the filler, so an fp32 engine -- and another bf16 one --
+    loads them, and a step after the round trip equals the step without it."""
+    hp = make_hp(optimizer="adam", learning_rate=0.01, **SHAPES["odd"])
+    rng = np.random.default_rng(4)
+    p32 = X.init_params(hp, seed=2)
+    a = XDeepFMEngine(hp, compute_dtype="bf16")
+    assert a.dense_off[-1] > sum(a._dense_sizes)  # odd sizes: there IS filler
+    a.load_state({k: v.clone() for k, v in p32.items()})
+    batches = [random_batch(rng, hp, 40) for _ in range(3)]
+    up = lambda e, b: e.upload(b["labels"], b["dnn_feat_indices"], b["dnn_feat_values"], b["dnn_feat_weights"])
+    for b in batches[:2]:
+        a.train_step(up(a, b))
+    a.flush_rows()
+    sd = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in a.state_dict().items()}
+    n_params = sum(a._dense_sizes)
+    assert sd["slot/dense_m"].numel() == n_params and sd["slot/dense_v"].numel() == n_params
+    b2 = XDeepFMEngine(hp, compute_dtype="bf16")
+    b2.load_state(sd)
+    f32 = XDeepFMEngine(hp)  # no filler in this one
+    f32.load_state(sd)
+    assert f32.dense_off[-1] == n_params
+    for name in a.dense_shapes:
+        assert torch.equal(a.views[name], b2.views[name]) and torch.equal(a.views[name], f32.views[name]), name
+    assert torch.equal(a.dense_m, b2.dense_m) and torch.equal(a.dense_v, b2.dense_v)
+    assert torch.equal(f32.dense_m, sd["slot/dense_m"].to(f32.dense_m.device))
+    # the filler stayed zero through two optimizer steps
+    keep = torch.zeros_like(a.dense, dtype=torch.bool)
+    for i, n in enumerate(a._dense_sizes):
+        keep[a.dense_off[i]:a.dense_off[i] + n] = True
+    assert not a.dense[~keep].any() and not a.dense_m[~keep].any() and not a.dense_v[~keep].any()
+    la = a.train_step(up(a, batches[2]))
+    lb = b2.train_step(up(b2, batches[2]))
+    torch.cuda.synchronize()
+    assert float(la[0]) == float(lb[0]) and float(la[1]) == float(lb[1])
