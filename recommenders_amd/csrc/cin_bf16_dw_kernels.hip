@@ -24,9 +24,11 @@ constexpr int kDwKM = 64;     // m per staged chunk (4 k steps)
 constexpr int kDwPitch = 36;  // uint32 per LDS row of dcurr: 64 bf16 + 16 bytes, so 32 rows spread over all banks
 constexpr int kDwXPitch = 68; // floats per LDS row of xk (kept fp32: the product with x0 needs no unpacking)
 
-// FAST: D even and B*D a multiple of 64 -- every staged m exists, so the staging is plain 8-byte loads
-// at a per-chunk base + per-thread row offsets computed once (the general form spends more
-// instructions on masks and addresses than on everything else together).
+// FAST: D even, B*D a multiple of 64, H and L filling their tiles -- every staged element exists, so
+// the staging is plain 8-byte loads at a per-chunk scalar base + one 32-bit offset per lane (the
+// general form spends more instructions on masks and addresses than on everything else together),
+// and the main loop fixes the order of what a wave issues (below).  Tiles not filled (rows past H or
+// L, read again and stored as zeros) measured slower in this form than in the general one.
 template <int HT, int NT, bool FAST>
 __global__ __launch_bounds__(256, 1) void cin_bf16_dw_kernel(Dims c, const float* __restrict__ x0,
                                                               const float* __restrict__ xk,
@@ -52,46 +54,66 @@ __global__ __launch_bounds__(256, 1) void cin_bf16_dw_kernel(Dims c, const float
   const int pc = tid & 31, r0 = tid >> 5;
   float xv[HT * 4][2], dv[NT * 4][2], x0v;
   bool livef = false;
-  // Loads without branches: rows past the end are clamped to the last row and zeroed by a select,
-  // addresses are one 32-bit multiply and one 64-bit add away from the chunk's base pointer.
-  // FAST: offsets of this thread's rows from a sample's base (rows past the end read the last row and
-  // are zeroed when stored), computed once
-  int offx[HT * 4], offd[NT * 4];
-  uint32_t keepx = 0, keepd = 0;
-#pragma unroll
-  for (int i = 0; i < HT * 4; ++i) {
-    const int row = r0 + 8 * i;
-    offx[i] = (row < c.H ? row : c.H - 1) * c.D;
-    keepx |= (row < c.H ? 1u : 0u) << i;
-  }
-#pragma unroll
-  for (int i = 0; i < NT * 4; ++i) {
-    const int row = r0 + 8 * i;
-    offd[i] = (row < c.L ? row : c.L - 1) * c.D;
-    keepd |= (row < c.L ? 1u : 0u) << i;
-  }
-  auto issue = [&](int64_t ch) {
-    if (FAST) {
-      const uint32_t m = (uint32_t)(ch * kDwKM) + 2 * pc;  // host checked: B*D < 2^31
-      const uint32_t b0 = m / (uint32_t)c.D, d0 = m - b0 * (uint32_t)c.D;
-      const float* px = xk + (int64_t)b0 * c.H * c.D + d0;
-      const float* pd = d_xnext + (int64_t)b0 * c.L * c.D + d0;
-#pragma unroll
-      for (int i = 0; i < HT * 4; ++i) {
-        const float2 v = *reinterpret_cast<const float2*>(px + offx[i]);
-        xv[i][0] = v.x;
-        xv[i][1] = v.y;
-      }
-#pragma unroll
-      for (int i = 0; i < NT * 4; ++i) {
-        const float2 v = *reinterpret_cast<const float2*>(pd + offd[i]);
-        dv[i][0] = v.x;
-        dv[i][1] = v.y;
-      }
+  // The blocks of a split stream the same bytes in step, so whoever asks first for a line takes the
+  // HBM miss and the others wait on the same fill: every chunk costs a miss latency, more than its
+  // products.  With D = 64 (a chunk is one sample: H and L rows of 256 B, each array contiguous)
+  // each block therefore also touches its 1 / OGn share of the 64-byte pieces of the chunk two
+  // ahead of the one being loaded; the value is never used (kept alive until the next chunk's
+  // stores, when it has long arrived: loads return in order, so it costs no wait).
+  const bool ahead = FAST && c.D == kDwKM;
+  const int64_t ch_end = ch0 + nch;
+  float pf_prev = 0.f, pf_cur = 0.f;
+  // FAST: the loads of a chunk as single steps, so that the main loop can issue them one at a time
+  // between matrix products (33 loads at once keep a wave in the issue queue of the CU's one
+  // memory pipeline for about as long as half of its products take)
+  const char *px = nullptr, *pd = nullptr;
+  uint32_t vx = 0, vd = 0, step = 0;
+  constexpr int kLoads = HT * 4 + NT * 4 + 1;
+  auto fast_prep = [&](int64_t ch) __attribute__((always_inline)) {
+    // the chunk's first sample gives a base every lane shares (a scalar pointer); what a lane adds
+    // to it is a 32-bit byte offset (host checked), one add per load
+    const uint32_t mbase = (uint32_t)(ch * kDwKM);  // host checked: B*D < 2^31
+    const uint32_t bfirst = mbase / (uint32_t)c.D;
+    const uint32_t m = mbase + 2 * pc;
+    const uint32_t b0 = m / (uint32_t)c.D, d0 = m - b0 * (uint32_t)c.D;
+    px = reinterpret_cast<const char*>(xk + (int64_t)bfirst * c.H * c.D);
+    pd = reinterpret_cast<const char*>(d_xnext + (int64_t)bfirst * c.L * c.D);
+    vx = ((b0 - bfirst) * (uint32_t)(c.H * c.D) + d0) * 4u;
+    vd = ((b0 - bfirst) * (uint32_t)(c.L * c.D) + d0) * 4u;
+    step = (uint32_t)c.D * 4u;  // bytes per row
+  };
+  auto fast_load = [&](int64_t ch, int i) __attribute__((always_inline)) {
+    if (i < HT * 4) {
+      const uint32_t row = (uint32_t)(r0 + 8 * i);
+      const float2 v = *reinterpret_cast<const float2*>(px + (vx + row * step));
+      xv[i][0] = v.x;
+      xv[i][1] = v.y;
+    } else if (i < HT * 4 + NT * 4) {
+      const int k = i - HT * 4;
+      const uint32_t row = (uint32_t)(r0 + 8 * k);
+      const float2 v = *reinterpret_cast<const float2*>(pd + (vd + row * step));
+      dv[k][0] = v.x;
+      dv[k][1] = v.y;
+    } else {
       const uint32_t mm = (uint32_t)(ch * kDwKM) + lane;
       const uint32_t bb = mm / (uint32_t)c.D;
       x0v = x0[((int64_t)bb * c.F + (f < c.F ? f : 0)) * c.D + (mm - bb * (uint32_t)c.D)];
       livef = f < c.F;
+      if (ahead && ch + 2 < ch_end) {
+        const uint32_t nx = (uint32_t)c.H * 4, nd = (uint32_t)c.L * 4;  // 64-byte pieces per sample
+        uint32_t j = (uint32_t)og + (uint32_t)OGn * (uint32_t)tid;
+        if (j >= nx + nd) j = (uint32_t)og;
+        const float* p = j < nx ? xk + (ch + 2) * (int64_t)c.H * kDwKM + 16 * j
+                                : d_xnext + (ch + 2) * (int64_t)c.L * kDwKM + 16 * (j - nx);
+        pf_cur = *p;
+      }
+    }
+  };
+  auto issue = [&](int64_t ch) __attribute__((always_inline)) {
+    if (FAST) {
+      fast_prep(ch);
+#pragma unroll
+      for (int i = 0; i < kLoads; ++i) fast_load(ch, i);
       return;
     }
     const int64_t m = ch * kDwKM + 2 * pc;
@@ -138,23 +160,27 @@ __global__ __launch_bounds__(256, 1) void cin_bf16_dw_kernel(Dims c, const float
       x0v = x0[(b * c.F + f) * c.D + (int)(mm - b * c.D)];
     }
   };
-  auto stash = [&](int buf) {
+  // FAST: what fast_load(., i) brought, into the LDS image (every staged row exists)
+  auto fast_store = [&](int buf, int i) __attribute__((always_inline)) {
+    uint32_t* xs = lds + buf * kBuf;
+    uint32_t* ds = xs + kXs;
+    if (i < HT * 4) {
+      *reinterpret_cast<float2*>(reinterpret_cast<float*>(xs) + (r0 + 8 * i) * kDwXPitch + 2 * pc) =
+          make_float2(xv[i][0], xv[i][1]);
+    } else if (i < HT * 4 + NT * 4) {
+      const int k = i - HT * 4;
+      ds[(r0 + 8 * k) * kDwPitch + pc] = pack_bf16(dv[k][0], dv[k][1]);
+    } else {
+      reinterpret_cast<float*>(ds + kDs)[wave * kDwKM + lane] = livef ? x0v : 0.f;
+    }
+  };
+  auto stash = [&](int buf) __attribute__((always_inline)) {
     uint32_t* xs = lds + buf * kBuf;
     uint32_t* ds = xs + kXs;
     float* xc = reinterpret_cast<float*>(ds + kDs);
     if (FAST) {
 #pragma unroll
-      for (int i = 0; i < HT * 4; ++i) {
-        const bool in = (keepx >> i) & 1;
-        *reinterpret_cast<float2*>(reinterpret_cast<float*>(xs) + (r0 + 8 * i) * kDwXPitch + 2 * pc) =
-            make_float2(in ? xv[i][0] : 0.f, in ? xv[i][1] : 0.f);
-      }
-#pragma unroll
-      for (int i = 0; i < NT * 4; ++i) {
-        const bool in = (keepd >> i) & 1;
-        ds[(r0 + 8 * i) * kDwPitch + pc] = pack_bf16(in ? dv[i][0] : 0.f, in ? dv[i][1] : 0.f);
-      }
-      xc[wave * kDwKM + lane] = livef ? x0v : 0.f;
+      for (int i = 0; i < kLoads; ++i) fast_store(buf, i);
       return;
     }
 #pragma unroll
@@ -174,6 +200,11 @@ __global__ __launch_bounds__(256, 1) void cin_bf16_dw_kernel(Dims c, const float
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[ht][nt][i] = 0.f;
 
+  // Chunk ch + 1 is loaded during the products of chunk ch and stored after them.  General form: all
+  // loads first.  FAST: one load at a time between the products of the first two k steps (a burst of
+  // 33 loads keeps the wave in the issue queue of the CU's one memory pipeline, matrix core idle,
+  // for about as long as half of the products take; stores spread the same way, or loads spread
+  // later than this, measured slower: the data is not there in time).
   if (nch > 0) {
     issue(ch0);
     stash(0);
@@ -181,37 +212,131 @@ __global__ __launch_bounds__(256, 1) void cin_bf16_dw_kernel(Dims c, const float
   __syncthreads();
   for (int ch = 0; ch < nch; ++ch) {
     const bool more = ch + 1 < nch;
-    if (more) issue(ch0 + ch + 1);
+    if (more) {
+      if (FAST)
+        fast_prep(ch0 + ch + 1);
+      else
+        issue(ch0 + ch + 1);
+    }
     const uint32_t* xs = lds + (ch & 1) * kBuf;
     const uint32_t* ds = xs + kXs;
     const float* xc = reinterpret_cast<const float*>(ds + kDs) + wave * kDwKM;
+    if (!FAST) {  // general form: the order is the compiler's (it spreads the loads' address work over the products)
 #pragma unroll
-    for (int ks = 0; ks < kDwKM / 16; ++ks) {
-      const int col = 8 * ks + 4 * half;  // uint32 column of this lane's 8 m in the bf16 image
-      typedef float f32x4v __attribute__((ext_vector_type(4)));
-      const f32x4v m0 = *reinterpret_cast<const f32x4v*>(xc + 16 * ks + 8 * half);
-      const f32x4v m1 = *reinterpret_cast<const f32x4v*>(xc + 16 * ks + 8 * half + 4);
-      bf16x8 a[HT];
+      for (int ks = 0; ks < kDwKM / 16; ++ks) {
+        typedef float f32x4g __attribute__((ext_vector_type(4)));
+        const f32x4g m0 = *reinterpret_cast<const f32x4g*>(xc + 16 * ks + 8 * half);
+        const f32x4g m1 = *reinterpret_cast<const f32x4g*>(xc + 16 * ks + 8 * half + 4);
+        bf16x8 ag[HT];
+#pragma unroll
+        for (int ht = 0; ht < HT; ++ht) {
+          const float* xr = reinterpret_cast<const float*>(xs) + (32 * ht + r) * kDwXPitch + 16 * ks + 8 * half;
+          const f32x4g p0 = *reinterpret_cast<const f32x4g*>(xr) * m0;  // packed fp32 multiplies
+          const f32x4g p1 = *reinterpret_cast<const f32x4g*>(xr + 4) * m1;
+          uint4 z;
+          z.x = pack_bf16(p0.x, p0.y);
+          z.y = pack_bf16(p0.z, p0.w);
+          z.z = pack_bf16(p1.x, p1.y);
+          z.w = pack_bf16(p1.z, p1.w);
+          ag[ht] = as_frag(z);
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          const bf16x8 bg = as_frag(*reinterpret_cast<const uint4*>(ds + (32 * nt + r) * kDwPitch + 8 * ks + 4 * half));
+#pragma unroll
+          for (int ht = 0; ht < HT; ++ht) acc[ht][nt] = mfma(ag[ht], bg, acc[ht][nt]);
+        }
+      }
+    } else {
+    // One wave per SIMD: nothing else hides an LDS read, so the operands of k step ks + 1 are read
+    // before the matrix products of step ks start, and its A fragments are formed between the two
+    // halves of those products (the matrix core works on while the VALU multiplies).
+    typedef float f32x4v __attribute__((ext_vector_type(4)));
+    struct OperandSet {
+      f32x4v m0, m1, x[HT][2];
+      uint4 b[NT];
+    };
+    auto read_set = [&](int ks, OperandSet& o) __attribute__((always_inline)) {
+      o.m0 = *reinterpret_cast<const f32x4v*>(xc + 16 * ks + 8 * half);
+      o.m1 = *reinterpret_cast<const f32x4v*>(xc + 16 * ks + 8 * half + 4);
 #pragma unroll
       for (int ht = 0; ht < HT; ++ht) {
         const float* xr = reinterpret_cast<const float*>(xs) + (32 * ht + r) * kDwXPitch + 16 * ks + 8 * half;
-        const f32x4v p0 = *reinterpret_cast<const f32x4v*>(xr) * m0;  // packed fp32 multiplies
-        const f32x4v p1 = *reinterpret_cast<const f32x4v*>(xr + 4) * m1;
-        uint4 z;
-        z.x = pack_bf16(p0.x, p0.y);
-        z.y = pack_bf16(p0.z, p0.w);
-        z.z = pack_bf16(p1.x, p1.y);
-        z.w = pack_bf16(p1.z, p1.w);
-        a[ht] = as_frag(z);
+        o.x[ht][0] = *reinterpret_cast<const f32x4v*>(xr);
+        o.x[ht][1] = *reinterpret_cast<const f32x4v*>(xr + 4);
       }
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-        const bf16x8 b = as_frag(*reinterpret_cast<const uint4*>(ds + (32 * nt + r) * kDwPitch + col));
+      for (int nt = 0; nt < NT; ++nt)  // 8 ks + 4 half: uint32 column of this lane's 8 m in the bf16 image
+        o.b[nt] = *reinterpret_cast<const uint4*>(ds + (32 * nt + r) * kDwPitch + 8 * ks + 4 * half);
+    };
+    typedef float f32x2v __attribute__((ext_vector_type(2)));
+    // a quarter of one A fragment: one packed multiply, one packed conversion
+    auto form_step = [&](const OperandSet& o, uint4 (&z)[HT], int j) {
+      const int ht = j >> 2, q = j & 3;
+      const f32x4v xv4 = o.x[ht][q >> 1], mv4 = (q >> 1) ? o.m1 : o.m0;
+      const f32x2v p = (q & 1) ? __builtin_shufflevector(xv4, xv4, 2, 3) * __builtin_shufflevector(mv4, mv4, 2, 3)
+                               : __builtin_shufflevector(xv4, xv4, 0, 1) * __builtin_shufflevector(mv4, mv4, 0, 1);
+      const uint32_t w = pack_bf16(p.x, p.y);
+      if (q == 0) z[ht].x = w;
+      if (q == 1) z[ht].y = w;
+      if (q == 2) z[ht].z = w;
+      if (q == 3) z[ht].w = w;
+    };
+    bf16x8 a[HT], b[NT];
+    {
+      OperandSet o;
+      uint4 z[HT];
+      read_set(0, o);
 #pragma unroll
-        for (int ht = 0; ht < HT; ++ht) acc[ht][nt] = mfma(a[ht], b, acc[ht][nt]);
+      for (int j = 0; j < HT * 4; ++j) form_step(o, z, j);
+#pragma unroll
+      for (int ht = 0; ht < HT; ++ht) a[ht] = as_frag(z[ht]);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) b[nt] = as_frag(o.b[nt]);
+    }
+    // The order below is the order issued (the scheduler may not move anything across a barrier):
+    // reads of step ks + 1, then each matrix product followed by its share of forming the next A
+    // fragments, which the VALU does while the matrix core is busy with that product.
+    constexpr int kStepsPerProduct = 4 / NT;  // HT * 4 quarter fragments over HT * NT products
+#pragma unroll
+    for (int ks = 0; ks < kDwKM / 16; ++ks) {
+      const bool next = ks + 1 < kDwKM / 16;
+      OperandSet o;
+      uint4 z[HT];
+      if (next) read_set(ks + 1, o);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int ht = 0; ht < HT; ++ht) {
+          acc[ht][nt] = mfma(a[ht], b[nt], acc[ht][nt]);
+          __builtin_amdgcn_sched_barrier(0);
+          if (FAST && more) {
+            constexpr int kHalf = 2 * HT * NT;  // products of two k steps
+            const int g = (ks * NT + nt) * HT + ht;
+            if (g < kHalf) {
+#pragma unroll
+              for (int i = g * kLoads / kHalf; i < (g + 1) * kLoads / kHalf; ++i) fast_load(ch0 + ch + 1, i);
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          }
+          if (next) {
+#pragma unroll
+            for (int k = 0; k < kStepsPerProduct; ++k) form_step(o, z, (nt * HT + ht) * kStepsPerProduct + k);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+      if (next) {
+#pragma unroll
+        for (int ht = 0; ht < HT; ++ht) a[ht] = as_frag(z[ht]);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) b[nt] = as_frag(o.b[nt]);
       }
     }
+    }
     if (more) stash((ch + 1) & 1);
+    asm volatile("" ::"v"(pf_prev));
+    pf_prev = pf_cur;
     __syncthreads();
   }
   if (f < c.F) {
@@ -286,23 +411,24 @@ extern "C" int xdfm_cin_bf16_bwd_dw(const float* x0, const float* xk, const floa
   if (B == 0) S = 0;
   const size_t lds = (size_t)2 * (HT * 32 * kDwXPitch + NT * 32 * kDwPitch + 4 * kDwKM) * 4;
   const dim3 grid((unsigned)(8 * ((S + 7) / 8) * OGn));
-  // rows past H / L would be loaded only to be zeroed: those shapes take the general form, which skips them
   const bool fast = (D & 1) == 0 && H == HT * 32 && L == NT * 32 && (c.cols % kDwKM) == 0 &&
-                    c.cols < ((int64_t)1 << 31) && (int64_t)(H > L ? H : L) * D < ((int64_t)1 << 31);
-#define DW(HTV, NTV)                                                                                                 \
+                    c.cols < ((int64_t)1 << 31) &&
+                    // a lane's byte offset from its chunk's first sample: at most 64 / D + 1 samples on
+                    (int64_t)(H > L ? H : L) * D * 4 * (kDwKM / D + 3) < ((int64_t)1 << 31);
+#define DW_M(HTV, NTV, FASTV)                                                                                        \
   do {                                                                                                               \
-    if (lds > 64 * 1024) {                                                                                           \
-      XDFM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(cin_bf16_dw_kernel<HTV, NTV, true>),                \
+    if (lds > 64 * 1024)                                                                                             \
+      XDFM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(cin_bf16_dw_kernel<HTV, NTV, FASTV>),               \
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                           \
-      XDFM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(cin_bf16_dw_kernel<HTV, NTV, false>),               \
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                           \
-    }                                                                                                                \
-    if (fast)                                                                                                        \
-      XDFM_LAUNCH("cin_bf16_dw_kernel<" #HTV ", " #NTV ">", stream, (cin_bf16_dw_kernel<HTV, NTV, true>), grid,      \
-                  dim3(256), lds, c, x0, xk, d_xnext, workspace, S, OGn, cps);                                       \
-    else                                                                                                             \
-      XDFM_LAUNCH("cin_bf16_dw_kernel<" #HTV ", " #NTV ">", stream, (cin_bf16_dw_kernel<HTV, NTV, false>), grid,     \
-                  dim3(256), lds, c, x0, xk, d_xnext, workspace, S, OGn, cps);                                       \
+    XDFM_LAUNCH("cin_bf16_dw_kernel<" #HTV ", " #NTV ">", stream, (cin_bf16_dw_kernel<HTV, NTV, FASTV>), grid,       \
+                dim3(256), lds, c, x0, xk, d_xnext, workspace, S, OGn, cps);                                         \
+  } while (0)
+#define DW(HTV, NTV)                 \
+  do {                               \
+    if (fast)                        \
+      DW_M(HTV, NTV, true);          \
+    else                             \
+      DW_M(HTV, NTV, false);         \
   } while (0)
 #define DW_N(HTV)            \
   do {                       \
@@ -323,6 +449,7 @@ extern "C" int xdfm_cin_bf16_bwd_dw(const float* x0, const float* xk, const floa
   }
 #undef DW_N
 #undef DW
+#undef DW_M
   const int64_t total = (int64_t)F * H * L;
   XDFM_LAUNCH("cin_bf16_dw_reduce_kernel", stream, cin_bf16_dw_reduce_kernel, dim3((unsigned)((total + 255) / 256)),
               dim3(256), 0, c, workspace, S, OGn, HT * 32, NT * 32, d_w, ldw);
