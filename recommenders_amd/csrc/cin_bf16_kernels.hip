@@ -147,23 +147,24 @@ __global__ __launch_bounds__(256, 2) void cin_bf16_fwd_kernel(Dims c, const floa
   const int NT = (c.L + 31) >> 5, OG = c.Fp / c.G;
   const int nchunks = NT * OG;
 
-  auto fetch = [&](int ci, uint4 (&r)[2]) {
+  constexpr int kFetch = NKS == 8 ? 4 : 2;  // uint4 per thread and chunk (make_dims: 16 KB chunks for NKS 8, else 8 KB)
+  auto fetch = [&](int ci, uint4 (&r)[kFetch]) {
     const uint4* src = img + (size_t)(ci < nchunks ? ci : nchunks - 1) * chunk;
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < kFetch; ++u) {
       const int i = threadIdx.x + u * 256;
       r[u] = i < chunk ? src[i] : make_uint4(0, 0, 0, 0);
     }
   };
-  auto stash = [&](int buf, const uint4 (&r)[2]) {
+  auto stash = [&](int buf, const uint4 (&r)[kFetch]) {
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < kFetch; ++u) {
       const int i = threadIdx.x + u * 256;
       if (i < chunk) wbuf[buf * chunk + i] = r[u];
     }
   };
 
-  uint4 pre[2];
+  uint4 pre[kFetch];
   fetch(0, pre);
   stage_x0(c, x0, m0, x0s);
   int64_t mb[kMT];
@@ -258,14 +259,14 @@ __global__ __launch_bounds__(256, 2) void cin_bf16_dx_kernel(Dims c, const float
 #pragma unroll
     for (int u = 0; u < (NKS + 3) / 4; ++u) {
       const int i = threadIdx.x + u * 256;
-      r[u] = i < chunk ? src[i] : make_uint4(0, 0, 0, 0);
+      r[u] = (NKS % 4 == 0 || i < chunk) ? src[i] : make_uint4(0, 0, 0, 0);  // whole rounds: no mask
     }
   };
   auto stash = [&](int buf, const uint4 (&r)[(NKS + 3) / 4]) {
 #pragma unroll
     for (int u = 0; u < (NKS + 3) / 4; ++u) {
       const int i = threadIdx.x + u * 256;
-      if (i < chunk) wbuf[buf * chunk + i] = r[u];
+      if (NKS % 4 == 0 || i < chunk) wbuf[buf * chunk + i] = r[u];
     }
   };
 
@@ -288,6 +289,9 @@ __global__ __launch_bounds__(256, 2) void cin_bf16_dx_kernel(Dims c, const float
   stash(0, pre);
   __syncthreads();
 
+  float* col_x0[kMT];  // d_x0[b][0][d] of this lane's column: row f is f * D further on
+#pragma unroll
+  for (int mt = 0; mt < kMT; ++mt) col_x0[mt] = d_x0 + mb[mt] * c.F * c.D + md[mt];
   const bool want_xk = d_xk != nullptr;
   const float pscale = c.masked ? 2.f : 1.f;
   f32x16 dxk[kMT], xkv[kMT];
@@ -314,7 +318,7 @@ __global__ __launch_bounds__(256, 2) void cin_bf16_dx_kernel(Dims c, const float
     float prev[kMT];
 #pragma unroll
     for (int mt = 0; mt < kMT; ++mt)
-      prev[mt] = (half == 0 && live[mt] && (accumulate_x0 || ht > 0)) ? d_x0[(mb[mt] * c.F + f) * c.D + md[mt]] : 0.f;
+      prev[mt] = (half == 0 && live[mt] && (accumulate_x0 || ht > 0)) ? col_x0[mt][(int64_t)f * c.D] : 0.f;
     f32x16 T[kMT];
 #pragma unroll
     for (int mt = 0; mt < kMT; ++mt)
@@ -328,16 +332,22 @@ __global__ __launch_bounds__(256, 2) void cin_bf16_dx_kernel(Dims c, const float
     }
 #pragma unroll
     for (int mt = 0; mt < kMT; ++mt) {
-      float p = 0.f;
+      // two running sums (packed multiply-adds), added at the end: a fixed order
+      typedef float f32x2 __attribute__((ext_vector_type(2)));
+      f32x2 pp = {0.f, 0.f};
 #pragma unroll
-      for (int i = 0; i < 16; ++i) p = fmaf(xkv[mt][i], T[mt][i], p);
+      for (int i = 0; i < 16; i += 2)
+        pp = __builtin_elementwise_fma(f32x2{xkv[mt][i], xkv[mt][i + 1]}, f32x2{T[mt][i], T[mt][i + 1]}, pp);
+      float p = pp.x + pp.y;
       if (want_xk) {
         const float xo = x0s[f * kMB + mloc[mt]];
 #pragma unroll
         for (int i = 0; i < 16; ++i) dxk[mt][i] = fmaf(xo, T[mt][i], dxk[mt][i]);
       }
-      p += __shfl_xor(p, 32);
-      if (half == 0 && live[mt]) d_x0[(mb[mt] * c.F + f) * c.D + md[mt]] = prev[mt] + pscale * p;
+      // the other half's sum by a register swap between the halves (no LDS round trip)
+      const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(p), __float_as_uint(p), false, false);
+      p += __uint_as_float(half == 0 ? sw[1] : sw[0]);
+      if (half == 0 && live[mt]) col_x0[mt][(int64_t)f * c.D] = prev[mt] + pscale * p;
     }
     if (f == c.F - 1 && want_xk) {
 #pragma unroll
