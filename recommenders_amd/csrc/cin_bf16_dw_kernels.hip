@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <cstdlib>
 
 #include "cin_bf16.h"
 #include "xdfm_common.h"
@@ -382,6 +383,256 @@ void dw_geometry(int64_t cols, int F, int* S, int* OGn, int* chunks_per_split) {
   *chunks_per_split = (int)((chunks + s - 1) / s);
 }
 
+
+// ---------------------------------------------------------------- filter gradient of the masked first layer
+// xk == x0 and only the pairs f < h are filter rows (xDeepFM.py:208-217), 741 of the 39 x 64 (f, h) slots the
+// kernel above computes for configs[4].  Here the PAIRS are the rows of the product: pair p = (f, h) in row-major
+// order of the triangle, 32 pairs per tile, kTriTT tiles per wave (a lane's A row is its pair: x0[f,m] * x0[h,m]
+// from two LDS rows), B = dcurr as above.  Two blocks instead of ten read each staged chunk, a third of the
+// matrix products remain.  Same loop as the FAST form above: operands a k step ahead, loads between products.
+constexpr int kTriTT = 3;  // 32-pair tiles per wave: 192 accumulators with NT = 4
+constexpr int kTriXR = 64; // staged x0 rows (host: F <= 64)
+
+__host__ __device__ inline int tri_pairs(int F) { return F * (F - 1) / 2; }
+
+template <int NT>
+__global__ __launch_bounds__(256, 1) void cin_bf16_dw_tri_kernel(Dims c, const float* __restrict__ x0,
+                                                                  const float* __restrict__ d_xnext,
+                                                                  float* __restrict__ part, int S, int OGT,
+                                                                  int chunks_per_split) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  constexpr int TT = kTriTT;
+  constexpr int kXs = kTriXR * kDwXPitch, kDs = NT * 32 * kDwPitch, kBuf = kXs + kDs;  // 4-byte units
+  uint32_t* lds = reinterpret_cast<uint32_t*>(smem);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, r = lane & 31;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int split = xcd + 8 * (slot / OGT), og = slot % OGT;
+  if (split >= S) return;
+  const int P = tri_pairs(c.F), Ppad = OGT * 4 * TT * 32;
+  const int64_t total_chunks = c.cols / kDwKM;  // host checked: a multiple of 64
+  const int64_t ch0 = (int64_t)split * chunks_per_split;
+  int nch = (int)(total_chunks - ch0 < chunks_per_split ? total_chunks - ch0 : chunks_per_split);
+  if (nch < 0) nch = 0;
+
+  // this lane's pairs: LDS word offsets of their two rows (a pair past the end repeats the last one; its
+  // results are not stored)
+  int offf[TT], offh[TT];
+#pragma unroll
+  for (int t = 0; t < TT; ++t) {
+    int p = ((og * 4 + wave) * TT + t) * 32 + r;
+    if (p >= P) p = P - 1;
+    int f = 0, rem = p;
+    while (rem >= c.F - 1 - f) {
+      rem -= c.F - 1 - f;
+      ++f;
+    }
+    offf[t] = f * kDwXPitch;
+    offh[t] = (f + 1 + rem) * kDwXPitch;
+  }
+
+  // staging as in the FAST form: a thread owns columns 2 pc, 2 pc + 1 of rows r0 + 8 i
+  const int pc = tid & 31, r0 = tid >> 5;
+  constexpr int XL = kTriXR / 8, kLoads = XL + NT * 4;
+  float xv[XL][2], dv[NT * 4][2];
+  const char *px = nullptr, *pd = nullptr;
+  uint32_t vx = 0, vd = 0, step = 0;
+  auto prep = [&](int64_t ch) __attribute__((always_inline)) {
+    const uint32_t mbase = (uint32_t)(ch * kDwKM);  // host checked: B*D < 2^31
+    const uint32_t bfirst = mbase / (uint32_t)c.D;
+    const uint32_t m = mbase + 2 * pc;
+    const uint32_t b0 = m / (uint32_t)c.D, d0 = m - b0 * (uint32_t)c.D;
+    px = reinterpret_cast<const char*>(x0 + (int64_t)bfirst * c.F * c.D);
+    pd = reinterpret_cast<const char*>(d_xnext + (int64_t)bfirst * c.L * c.D);
+    vx = ((b0 - bfirst) * (uint32_t)(c.F * c.D) + d0) * 4u;
+    vd = ((b0 - bfirst) * (uint32_t)(c.L * c.D) + d0) * 4u;
+    step = (uint32_t)c.D * 4u;
+  };
+  auto load = [&](int i) __attribute__((always_inline)) {  // rows past the end: the last row once more, zeroed when stored
+    if (i < XL) {
+      const uint32_t row = min((uint32_t)(r0 + 8 * i), (uint32_t)(c.F - 1));
+      const float2 v = *reinterpret_cast<const float2*>(px + (vx + row * step));
+      xv[i][0] = v.x;
+      xv[i][1] = v.y;
+    } else {
+      const int k = i - XL;
+      const uint32_t row = min((uint32_t)(r0 + 8 * k), (uint32_t)(c.L - 1));
+      const float2 v = *reinterpret_cast<const float2*>(pd + (vd + row * step));
+      dv[k][0] = v.x;
+      dv[k][1] = v.y;
+    }
+  };
+  auto store = [&](int buf, int i) __attribute__((always_inline)) {
+    uint32_t* xs = lds + buf * kBuf;
+    uint32_t* ds = xs + kXs;
+    if (i < XL) {
+      const bool in = r0 + 8 * i < c.F;
+      *reinterpret_cast<float2*>(reinterpret_cast<float*>(xs) + (r0 + 8 * i) * kDwXPitch + 2 * pc) =
+          make_float2(in ? xv[i][0] : 0.f, in ? xv[i][1] : 0.f);
+    } else {
+      const int k = i - XL;
+      const bool in = r0 + 8 * k < c.L;
+      ds[(r0 + 8 * k) * kDwPitch + pc] = pack_bf16(in ? dv[k][0] : 0.f, in ? dv[k][1] : 0.f);
+    }
+  };
+
+  f32x16 acc[TT][NT];
+#pragma unroll
+  for (int t = 0; t < TT; ++t)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[t][nt][i] = 0.f;
+
+  if (nch > 0) {
+    prep(ch0);
+#pragma unroll
+    for (int i = 0; i < kLoads; ++i) load(i);
+#pragma unroll
+    for (int i = 0; i < kLoads; ++i) store(0, i);
+  }
+  __syncthreads();
+  typedef float f32x4v __attribute__((ext_vector_type(4)));
+  typedef float f32x2v __attribute__((ext_vector_type(2)));
+  struct OperandSet {
+    f32x4v xf[TT][2], xh[TT][2];
+    uint4 b[NT];
+  };
+  for (int ch = 0; ch < nch; ++ch) {
+    const bool more = ch + 1 < nch;
+    if (more) prep(ch0 + ch + 1);
+    const float* xs = reinterpret_cast<const float*>(lds + (ch & 1) * kBuf);
+    const uint32_t* ds = lds + (ch & 1) * kBuf + kXs;
+    auto read_set = [&](int ks, OperandSet& o) __attribute__((always_inline)) {
+#pragma unroll
+      for (int t = 0; t < TT; ++t) {
+        const float* pf = xs + offf[t] + 16 * ks + 8 * half;
+        const float* ph = xs + offh[t] + 16 * ks + 8 * half;
+        o.xf[t][0] = *reinterpret_cast<const f32x4v*>(pf);
+        o.xf[t][1] = *reinterpret_cast<const f32x4v*>(pf + 4);
+        o.xh[t][0] = *reinterpret_cast<const f32x4v*>(ph);
+        o.xh[t][1] = *reinterpret_cast<const f32x4v*>(ph + 4);
+      }
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+        o.b[nt] = *reinterpret_cast<const uint4*>(ds + (32 * nt + r) * kDwPitch + 8 * ks + 4 * half);
+    };
+    auto form_step = [&](const OperandSet& o, uint4* z, int j) __attribute__((always_inline)) {
+      const int t = j >> 2, q = j & 3;
+      const f32x4v a4 = o.xf[t][q >> 1], h4 = o.xh[t][q >> 1];
+      const f32x2v pr = (q & 1) ? __builtin_shufflevector(a4, a4, 2, 3) * __builtin_shufflevector(h4, h4, 2, 3)
+                                : __builtin_shufflevector(a4, a4, 0, 1) * __builtin_shufflevector(h4, h4, 0, 1);
+      const uint32_t w = pack_bf16(pr.x, pr.y);
+      if (q == 0) z[t].x = w;
+      if (q == 1) z[t].y = w;
+      if (q == 2) z[t].z = w;
+      if (q == 3) z[t].w = w;
+    };
+    bf16x8 a[TT], b[NT];
+    {
+      OperandSet o;
+      uint4 z[TT];
+      read_set(0, o);
+#pragma unroll
+      for (int j = 0; j < TT * 4; ++j) form_step(o, z, j);
+#pragma unroll
+      for (int t = 0; t < TT; ++t) a[t] = as_frag(z[t]);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) b[nt] = as_frag(o.b[nt]);
+    }
+    constexpr int kStepsPerProduct = 4 / NT;  // TT * 4 quarter fragments over TT * NT products
+#pragma unroll
+    for (int ks = 0; ks < kDwKM / 16; ++ks) {
+      const bool next = ks + 1 < kDwKM / 16;
+      OperandSet o;
+      uint4 z[TT];
+      if (next) read_set(ks + 1, o);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int t = 0; t < TT; ++t) {
+          acc[t][nt] = mfma(a[t], b[nt], acc[t][nt]);
+          __builtin_amdgcn_sched_barrier(0);
+          if (more) {  // the next chunk's loads, one at a time between the products of the first two k steps
+            constexpr int kHalf = 2 * TT * NT;
+            const int g = (ks * NT + nt) * TT + t;
+            if (g < kHalf) {
+#pragma unroll
+              for (int i = g * kLoads / kHalf; i < (g + 1) * kLoads / kHalf; ++i) load(i);
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          }
+          if (next) {
+#pragma unroll
+            for (int k = 0; k < kStepsPerProduct; ++k) form_step(o, z, (nt * TT + t) * kStepsPerProduct + k);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+      if (next) {
+#pragma unroll
+        for (int t = 0; t < TT; ++t) a[t] = as_frag(z[t]);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) b[nt] = as_frag(o.b[nt]);
+      }
+    }
+    if (more) {
+#pragma unroll
+      for (int i = 0; i < kLoads; ++i) store((ch + 1) & 1, i);
+    }
+    __syncthreads();
+  }
+  // part[split][pair (Ppad)][NT * 32]
+  float* dst = part + (size_t)split * Ppad * (NT * 32);
+#pragma unroll
+  for (int t = 0; t < TT; ++t) {
+    const int pbase = ((og * 4 + wave) * TT + t) * 32;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int p = pbase + tile_row(i, half);
+        if (p < P) dst[(size_t)p * (NT * 32) + 32 * nt + r] = acc[t][nt][i];
+      }
+  }
+}
+
+__global__ void cin_bf16_dw_tri_reduce_kernel(Dims c, const float* __restrict__ part, int S, int Ppad, int Lp,
+                                              float* __restrict__ d_w, int ldw) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)c.F * c.H * c.L) return;
+  const int n = (int)(idx % c.L);
+  const int64_t t = idx / c.L;
+  const int h = (int)(t % c.H), f = (int)(t / c.H);
+  if (h <= f) {  // not part of the layer: its gradient is zero
+    d_w[(int64_t)(f * c.H + h) * ldw + n] = 0.f;
+    return;
+  }
+  const int p = f * (2 * c.F - f - 1) / 2 + (h - f - 1);
+  const float* src = part + (size_t)p * Lp + n;
+  const size_t stride = (size_t)Ppad * Lp;
+  float sum = 0.f;
+  for (int k = 0; k < S; ++k) sum += src[k * stride];  // split order: the same bits on every run
+  d_w[(int64_t)(f * c.H + h) * ldw + n] = 2.f * sum;
+}
+
+// the pair form serves: the masked layer, F <= 64 staged rows, every staged m existing
+bool tri_serves(int64_t cols, int F, int D, int L, int masked) {
+  static const bool on = !(getenv("XDFM_DW_TRI") && getenv("XDFM_DW_TRI")[0] == '0');
+  return on && masked && F >= 2 && F <= kTriXR && (D & 1) == 0 && cols % kDwKM == 0 && cols < ((int64_t)1 << 31) &&
+         (int64_t)(F > L ? F : L) * D * 4 * (kDwKM / D + 3) < ((int64_t)1 << 31);
+}
+
+void tri_geometry(int64_t cols, int F, int* S, int* OGT, int* chunks_per_split) {
+  const int64_t chunks = cols / kDwKM;
+  const int tiles = (tri_pairs(F) + 31) / 32;
+  *OGT = (tiles + 4 * kTriTT - 1) / (4 * kTriTT);
+  int64_t s = 8 * (32 / *OGT > 0 ? 32 / *OGT : 1);  // one block per CU, the blocks of a split on one XCD
+  if (s > chunks / 4) s = chunks / 4;
+  if (s < 1) s = 1;
+  *S = (int)s;
+  *chunks_per_split = (int)((chunks + s - 1) / s);
+}
+
 }  // namespace
 
 extern "C" int xdfm_cin_bf16_bwd_dw_workspace_floats(int64_t B, int32_t F, int32_t H, int32_t D, int32_t L,
@@ -392,6 +643,12 @@ extern "C" int xdfm_cin_bf16_bwd_dw_workspace_floats(int64_t B, int32_t F, int32
   dw_geometry(B * D, F, &S, &OGn, &cps);
   const int HT = H <= 32 ? 1 : (H <= 64 ? 2 : 4), NT = L <= 32 ? 1 : (L <= 64 ? 2 : 4);
   *floats = (size_t)S * OGn * 4 * HT * 32 * NT * 32;
+  if (F == H && F >= 2 && F <= kTriXR) {  // the masked layer's pair form (whether it serves is decided per call)
+    int St, OGT, cpst;
+    tri_geometry(B * D / kDwKM * kDwKM, F, &St, &OGT, &cpst);
+    const size_t tri = (size_t)St * OGT * 4 * kTriTT * 32 * NT * 32;
+    if (tri > *floats) *floats = tri;
+  }
   return XDFM_OK;
 }
 
@@ -408,6 +665,33 @@ extern "C" int xdfm_cin_bf16_bwd_dw(const float* x0, const float* xk, const floa
   dw_geometry(c.cols, F, &S, &OGn, &cps);
   const int HT = H <= 32 ? 1 : (H <= 64 ? 2 : 4), NT = L <= 32 ? 1 : (L <= 64 ? 2 : 4);
   XDFM_REQUIRE(B == 0 || (x0 && xk && d_xnext && workspace), "xdfm_cin_bf16_bwd_dw: null argument");
+  if (B > 0 && tri_serves(c.cols, F, D, L, masked)) {
+    int St, OGT, cpst;
+    tri_geometry(c.cols, F, &St, &OGT, &cpst);
+    const size_t ldst = (size_t)2 * (kTriXR * kDwXPitch + NT * 32 * kDwPitch) * 4;
+    const dim3 gridt((unsigned)(8 * ((St + 7) / 8) * OGT));
+#define TRI(NTV)                                                                                                   \
+  do {                                                                                                             \
+    if (ldst > 64 * 1024)                                                                                          \
+      XDFM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(cin_bf16_dw_tri_kernel<NTV>),                     \
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldst));                        \
+    XDFM_LAUNCH("cin_bf16_dw_tri_kernel<" #NTV ">", stream, (cin_bf16_dw_tri_kernel<NTV>), gridt, dim3(256), ldst, \
+                c, x0, d_xnext, workspace, St, OGT, cpst);                                                         \
+  } while (0)
+    if (NT == 1)
+      TRI(1);
+    else if (NT == 2)
+      TRI(2);
+    else
+      TRI(4);
+#undef TRI
+    const int64_t total = (int64_t)F * H * L;
+    XDFM_LAUNCH("cin_bf16_dw_tri_reduce_kernel", stream, cin_bf16_dw_tri_reduce_kernel,
+                dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c, workspace, St, OGT * 4 * kTriTT * 32, NT * 32,
+                d_w, ldw);
+    XDFM_LAUNCH_CHECK();
+    return XDFM_OK;
+  }
   if (B == 0) S = 0;
   const size_t lds = (size_t)2 * (HT * 32 * kDwXPitch + NT * 32 * kDwPitch + 4 * kDwKM) * 4;
   const dim3 grid((unsigned)(8 * ((S + 7) / 8) * OGn));

@@ -265,14 +265,17 @@ def test_bf16_dense_products_against_fp64(B, K, N, act):
 @pytest.mark.parametrize("B,F,H,D,L,Lfull,masked", [
     (5, 6, 6, 8, 20, 34, 1), (7, 6, 20, 16, 40, 40, 0), (33, 39, 39, 64, 128, 256, 1), (33, 39, 128, 64, 128, 256, 0),
     (300, 5, 33, 10, 70, 70, 0), (64, 39, 128, 64, 128, 256, 0), (700, 39, 128, 64, 128, 128, 0),
-    (512, 10, 64, 32, 128, 128, 0),
+    (512, 10, 64, 32, 128, 128, 0), (700, 39, 39, 64, 128, 128, 1), (256, 20, 20, 32, 70, 70, 1), (96, 64, 64, 16, 40, 40, 1),
 ])
 def test_bf16_cin_layer_kernels_against_fp64(B, F, H, D, L, Lfull, masked):
     """xdfm_cin_bf16_fwd / bwd_dx / bwd_dw through the C ABI on their own (a layer's L hidden channels
     of a filter Lfull wide) against float64 einsums; (64, ..) has B*D a multiple of 64 and full tiles:
     the filter gradient's mask-free staging path; (700, ..) gives each of its blocks 14-15 staged chunks
     (loads issued between the products, pieces of later chunks touched ahead), (512, ..) that path with
-    D = 32 (a chunk spans two samples) and a 64 x 128 tile."""
+    D = 32 (a chunk spans two samples) and a 64 x 128 tile.  The masked cases with B*D a multiple of 64
+    take the filter gradient whose rows are the pairs f < h: 741 pairs in two blocks per split (39
+    fields), 190 pairs and channel tiles not filled (20 fields, 70 channels), the most fields it serves
+    (64: 2016 pairs, six blocks per split)."""
     lib = _lib.lib
     g = torch.Generator(device="cuda").manual_seed(B + H)
     x0 = torch.randn(B, F, D, device="cuda", generator=g)
