@@ -384,6 +384,188 @@ void dw_geometry(int64_t cols, int F, int* S, int* OGn, int* chunks_per_split) {
 }
 
 
+// ---------------------------------------------------------------- full tiles, D = 64: loads that write LDS themselves
+// With D = 64 a chunk is one sample: xk[b] and dcurr[b] are 128 rows of 256 contiguous bytes each.  They go to
+// LDS as they are (fp32, `global_load_lds_dwordx4`: no staging registers, no store pass with the matrix core
+// idle): a wave-instruction fills 1 KB of LDS in lane order, so the image is the linear sequence of 16-byte
+// pieces of rows of 17 pieces (272 bytes = kDwXPitch words: the 17th is padding and gets the 16th's bytes again),
+// 34 instructions per array, dealt to the four waves.  dcurr is rounded to bf16 when a fragment is read
+// (packed conversions between the products, as the A operand's multiplies are).  The x0 factors of a wave's f
+// take one 4-byte instruction per wave.  The barrier at a chunk's end waits for the loads of the next.
+constexpr int kGlPieces = 17;                                   // 16-byte pieces per LDS row
+constexpr int kGlInstr = 128 * kGlPieces / 64;                  // wave-instructions per array and chunk: 34
+constexpr int kGlPerWave = (kGlInstr + 3) / 4;                  // 9 (waves 2 and 3: 8)
+constexpr int kGlImg = 128 * kDwXPitch;                         // words per array image
+constexpr int kGlBuf = 2 * kGlImg + 4 * kDwKM;                  // words per buffer: xk, dcurr, factors
+#ifndef GL_EVERY
+#define GL_EVERY 2
+#endif
+constexpr int kGlEvery = GL_EVERY;
+
+typedef __attribute__((address_space(1))) const void* gl_src_t;
+typedef __attribute__((address_space(3))) void* gl_dst_t;
+
+__global__ __launch_bounds__(256, 1) void cin_bf16_dw_glds_kernel(Dims c, const float* __restrict__ x0,
+                                                                   const float* __restrict__ xk,
+                                                                   const float* __restrict__ d_xnext,
+                                                                   float* __restrict__ part, int S, int OGn,
+                                                                   int chunks_per_split) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  constexpr int HT = 4, NT = 4;
+  uint32_t* lds = reinterpret_cast<uint32_t*>(smem);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, r = lane & 31;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int split = xcd + 8 * (slot / OGn), og = slot % OGn;
+  if (split >= S) return;
+  const int f = og * 4 + wave;
+  const int64_t total_chunks = c.B;  // one sample each
+  const int64_t ch0 = (int64_t)split * chunks_per_split;
+  int nch = (int)(total_chunks - ch0 < chunks_per_split ? total_chunks - ch0 : chunks_per_split);
+  if (nch < 0) nch = 0;
+
+  // byte offset, inside a sample's array, of the piece this lane brings with its wave's i-th instruction
+  uint32_t soff[kGlPerWave];
+#pragma unroll
+  for (int i = 0; i < kGlPerWave; ++i) {
+    const int q = (wave + 4 * i) * 64 + lane;
+    const int row = q / kGlPieces, col = q - row * kGlPieces;
+    soff[i] = (uint32_t)(row * 256 + (col < 16 ? col : 15) * 16);
+  }
+  const int64_t x0_row = (int64_t)(f < c.F ? f : c.F - 1) * kDwKM + lane;  // this wave's factors: x0[b][f][lane]
+  // instruction i of this wave for sample b into buffer buf: i < 9 xk, i < 18 dcurr, 18 the factors
+  constexpr int kIssues = 2 * kGlPerWave + 1;
+  auto issue = [&](int64_t b, int buf, int i) __attribute__((always_inline)) {
+    unsigned char* base = smem + (size_t)buf * kGlBuf * 4;
+    if (i < 2 * kGlPerWave) {
+      const int arr = i / kGlPerWave, k = i - arr * kGlPerWave;
+      const int j = wave + 4 * k;
+      if (j < kGlInstr) {
+        const char* src = reinterpret_cast<const char*>((arr ? d_xnext : xk) + b * 128 * kDwKM) + soff[k];
+        __builtin_amdgcn_global_load_lds((gl_src_t)src, (gl_dst_t)(base + (size_t)arr * kGlImg * 4 + (size_t)j * 1024),
+                                         16, 0, 0);
+      }
+    } else {
+      __builtin_amdgcn_global_load_lds((gl_src_t)(x0 + b * c.F * kDwKM + x0_row),
+                                       (gl_dst_t)(base + (size_t)2 * kGlImg * 4 + (size_t)wave * kDwKM * 4), 4, 0, 0);
+    }
+  };
+
+  f32x16 acc[HT][NT];
+#pragma unroll
+  for (int ht = 0; ht < HT; ++ht)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[ht][nt][i] = 0.f;
+
+  if (nch > 0) {
+#pragma unroll
+    for (int i = 0; i < kIssues; ++i) issue(ch0, 0, i);
+  }
+  __syncthreads();  // (with loads to LDS outstanding the compiler waits for them here)
+  typedef float f32x4v __attribute__((ext_vector_type(4)));
+  typedef float f32x2v __attribute__((ext_vector_type(2)));
+  struct OperandSet {
+    f32x4v m0, m1, x[HT][2], d[NT][2];
+  };
+  for (int ch = 0; ch < nch; ++ch) {
+    const bool more = ch + 1 < nch;
+    const float* xs = reinterpret_cast<const float*>(lds + (ch & 1) * kGlBuf);
+    const float* ds = xs + kGlImg;
+    const float* xc = ds + kGlImg + wave * kDwKM;
+    auto read_set = [&](int ks, OperandSet& o) __attribute__((always_inline)) {
+      o.m0 = *reinterpret_cast<const f32x4v*>(xc + 16 * ks + 8 * half);
+      o.m1 = *reinterpret_cast<const f32x4v*>(xc + 16 * ks + 8 * half + 4);
+#pragma unroll
+      for (int ht = 0; ht < HT; ++ht) {
+        const float* xr = xs + (32 * ht + r) * kDwXPitch + 16 * ks + 8 * half;
+        o.x[ht][0] = *reinterpret_cast<const f32x4v*>(xr);
+        o.x[ht][1] = *reinterpret_cast<const f32x4v*>(xr + 4);
+      }
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const float* dr = ds + (32 * nt + r) * kDwXPitch + 16 * ks + 8 * half;
+        o.d[nt][0] = *reinterpret_cast<const f32x4v*>(dr);
+        o.d[nt][1] = *reinterpret_cast<const f32x4v*>(dr + 4);
+      }
+    };
+    // quarter fragments: j < 16 the A operand (x0 factor times xk, then rounded), j >= 16 the B operand (rounded)
+    auto form_step = [&](const OperandSet& o, uint4* za, uint4* zb, int j) __attribute__((always_inline)) {
+      const int t = (j & 15) >> 2, q = j & 3;
+      uint32_t w;
+      if (j < 16) {
+        const f32x4v xv4 = o.x[t][q >> 1], mv4 = (q >> 1) ? o.m1 : o.m0;
+        const f32x2v pr = (q & 1) ? __builtin_shufflevector(xv4, xv4, 2, 3) * __builtin_shufflevector(mv4, mv4, 2, 3)
+                                  : __builtin_shufflevector(xv4, xv4, 0, 1) * __builtin_shufflevector(mv4, mv4, 0, 1);
+        w = pack_bf16(pr.x, pr.y);
+      } else {
+        const f32x4v dv4 = o.d[t][q >> 1];
+        w = (q & 1) ? pack_bf16(dv4.z, dv4.w) : pack_bf16(dv4.x, dv4.y);
+      }
+      uint4* z = j < 16 ? za : zb;
+      if (q == 0) z[t].x = w;
+      if (q == 1) z[t].y = w;
+      if (q == 2) z[t].z = w;
+      if (q == 3) z[t].w = w;
+    };
+    bf16x8 a[HT], b[NT];
+    {
+      OperandSet o;
+      uint4 za[HT], zb[NT];
+      read_set(0, o);
+#pragma unroll
+      for (int j = 0; j < 32; ++j) form_step(o, za, zb, j);
+#pragma unroll
+      for (int ht = 0; ht < HT; ++ht) a[ht] = as_frag(za[ht]);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) b[nt] = as_frag(zb[nt]);
+    }
+#pragma unroll
+    for (int ks = 0; ks < kDwKM / 16; ++ks) {
+      const bool next = ks + 1 < kDwKM / 16;
+      OperandSet o;
+      uint4 za[HT], zb[NT];
+      if (next) read_set(ks + 1, o);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int ht = 0; ht < HT; ++ht) {
+          acc[ht][nt] = mfma(a[ht], b[nt], acc[ht][nt]);
+          __builtin_amdgcn_sched_barrier(0);
+          const int g = (ks * NT + nt) * HT + ht;  // the next sample's loads: one per kGlEvery products
+          if (more && g % kGlEvery == 0 && g / kGlEvery < kIssues) {
+            issue(ch0 + ch + 1, (ch + 1) & 1, g / kGlEvery);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+
+          if (next) {
+            form_step(o, za, zb, 2 * (nt * HT + ht));
+            form_step(o, za, zb, 2 * (nt * HT + ht) + 1);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+      if (next) {
+#pragma unroll
+        for (int ht = 0; ht < HT; ++ht) a[ht] = as_frag(za[ht]);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) b[nt] = as_frag(zb[nt]);
+      }
+    }
+    __syncthreads();  // everyone is done reading this buffer; the next one's loads have landed
+  }
+  if (f < c.F) {
+    float* dst = part + ((size_t)split * (OGn * 4) + f) * (HT * 32) * (NT * 32);
+#pragma unroll
+    for (int ht = 0; ht < HT; ++ht)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+          dst[(size_t)(32 * ht + tile_row(i, half)) * (NT * 32) + 32 * nt + r] = acc[ht][nt][i];
+  }
+}
+
 // ---------------------------------------------------------------- filter gradient of the masked first layer
 // xk == x0 and only the pairs f < h are filter rows (xDeepFM.py:208-217), 741 of the 39 x 64 (f, h) slots the
 // kernel above computes for configs[4].  Here the PAIRS are the rows of the product: pair p = (f, h) in row-major
@@ -693,6 +875,22 @@ extern "C" int xdfm_cin_bf16_bwd_dw(const float* x0, const float* xk, const floa
     return XDFM_OK;
   }
   if (B == 0) S = 0;
+  static const bool glds_on = !(getenv("XDFM_DW_GLDS") && getenv("XDFM_DW_GLDS")[0] == '0');
+  if (glds_on && S > 0 && !masked && D == kDwKM && H == 128 && L == 128 &&
+      (reinterpret_cast<uintptr_t>(xk) & 15) == 0 && (reinterpret_cast<uintptr_t>(d_xnext) & 15) == 0 &&
+      (reinterpret_cast<uintptr_t>(x0) & 3) == 0) {
+    const size_t ldsg = (size_t)2 * kGlBuf * 4;
+    const dim3 gridg((unsigned)(8 * ((S + 7) / 8) * OGn));
+    XDFM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(cin_bf16_dw_glds_kernel),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsg));
+    XDFM_LAUNCH("cin_bf16_dw_glds_kernel", stream, cin_bf16_dw_glds_kernel, gridg, dim3(256), ldsg, c, x0, xk, d_xnext,
+                workspace, S, OGn, cps);
+    const int64_t total = (int64_t)F * H * L;
+    XDFM_LAUNCH("cin_bf16_dw_reduce_kernel", stream, cin_bf16_dw_reduce_kernel, dim3((unsigned)((total + 255) / 256)),
+                dim3(256), 0, c, workspace, S, OGn, HT * 32, NT * 32, d_w, ldw);
+    XDFM_LAUNCH_CHECK();
+    return XDFM_OK;
+  }
   const size_t lds = (size_t)2 * (HT * 32 * kDwXPitch + NT * 32 * kDwPitch + 4 * kDwKM) * 4;
   const dim3 grid((unsigned)(8 * ((S + 7) / 8) * OGn));
   const bool fast = (D & 1) == 0 && H == HT * 32 && L == NT * 32 && (c.cols % kDwKM) == 0 &&
