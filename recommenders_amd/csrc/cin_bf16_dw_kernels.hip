@@ -352,6 +352,21 @@ __global__ __launch_bounds__(256, 1) void cin_bf16_dw_kernel(Dims c, const float
   }
 }
 
+// the partial sums of one element, added in split order (the same bits on every run), eight loads in flight
+__device__ __forceinline__ float sum_splits(const float* __restrict__ src, size_t stride, int S) {
+  float sum = 0.f;
+  int k = 0;
+  for (; k + 8 <= S; k += 8) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = src[(size_t)(k + u) * stride];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) sum += v[u];
+  }
+  for (; k < S; ++k) sum += src[(size_t)k * stride];
+  return sum;
+}
+
 __global__ void cin_bf16_dw_reduce_kernel(Dims c, const float* __restrict__ part, int S, int OGn, int Hp, int Lp,
                                           float* __restrict__ d_w, int ldw) {
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -365,8 +380,7 @@ __global__ void cin_bf16_dw_reduce_kernel(Dims c, const float* __restrict__ part
   }
   const size_t stride = (size_t)(OGn * 4) * Hp * Lp;
   const float* src = part + ((size_t)f * Hp + h) * Lp + n;
-  float sum = 0.f;
-  for (int k = 0; k < S; ++k) sum += src[k * stride];  // split order: the same bits on every run
+  const float sum = sum_splits(src, stride, S);
   d_w[(int64_t)(f * c.H + h) * ldw + n] = c.masked ? 2.f * sum : sum;
 }
 
@@ -792,8 +806,7 @@ __global__ void cin_bf16_dw_tri_reduce_kernel(Dims c, const float* __restrict__ 
   const int p = f * (2 * c.F - f - 1) / 2 + (h - f - 1);
   const float* src = part + (size_t)p * Lp + n;
   const size_t stride = (size_t)Ppad * Lp;
-  float sum = 0.f;
-  for (int k = 0; k < S; ++k) sum += src[k * stride];  // split order: the same bits on every run
+  const float sum = sum_splits(src, stride, S);
   d_w[(int64_t)(f * c.H + h) * ldw + n] = 2.f * sum;
 }
 
