@@ -147,7 +147,16 @@ def kernel_models(hp, nnz, uniq):
             if nh:
                 add("cin_bf16_fwd_kernel<%d>" % nks(H), "mfma16", 2.0 * rows * pairs * nh)
                 add("cin_bf16_dx_kernel<%d>" % nks(nh), "mfma16", 2.0 * rows * pairs * nh)
-                add("cin_bf16_dw_kernel<%d, %d>" % (tiles(H), tiles(nh)), "mfma16", 2.0 * rows * pairs * nh)
+                # filter gradient, as csrc/cin_bf16_dw_kernels.hip dispatches it: the masked layer's pair form,
+                # the full 128 x 128 tile at D = 64 with loads that write LDS, else the staged form
+                cols_ok = D % 2 == 0 and (B * D) % 64 == 0
+                if k == 0 and F <= 64 and cols_ok and os.environ.get("XDFM_DW_TRI", "1") != "0":
+                    dw_name = "cin_bf16_dw_tri_kernel<%d>" % tiles(nh)
+                elif k != 0 and D == 64 and H == 128 and nh == 128 and os.environ.get("XDFM_DW_GLDS", "1") != "0":
+                    dw_name = "cin_bf16_dw_glds_kernel"
+                else:
+                    dw_name = "cin_bf16_dw_kernel<%d, %d>" % (tiles(H), tiles(nh))
+                add(dw_name, "mfma16", 2.0 * rows * pairs * nh)
             H = nh
         return m
     for k, L in enumerate(hp.cross_layer_sizes):

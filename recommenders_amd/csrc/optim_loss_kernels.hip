@@ -77,8 +77,30 @@ __global__ __launch_bounds__(256) void dense_stats_kernel(SegTable tab, const fl
     const float nrm = sqrtf(stats[s * 4 + 0]);
     inv_norm = nrm > 0.f ? 1.f / nrm : 0.f;
   }
-  for (long long i = beg + (long long)blockIdx.x * 256 + threadIdx.x; i < end;
-       i += (long long)kStatBlocks * 256) {
+  // eight elements of a thread's strided walk in flight (a large segment gives a thread ~80 of them; one
+  // load at a time made this kernel 40 us at configs[4]); they are added in the walk's order as before
+  constexpr long long kStride = (long long)kStatBlocks * 256;
+  long long i = beg + (long long)blockIdx.x * 256 + threadIdx.x;
+  for (; i + 7 * kStride < end; i += 8 * kStride) {
+    float p[8], gq[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) p[u] = param[i + u * kStride];
+    if (pass != 0) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) gq[u] = grad ? grad[i + u * kStride] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      if (pass == 0) {
+        a += p[u] * p[u];
+        b += fabsf(p[u]);
+      } else {
+        const float t = total_grad(gq[u], p[u], tab.l2[s], tab.l1[s], tab.nl2[s], inv_norm);
+        a += t * t;
+      }
+    }
+  }
+  for (; i < end; i += kStride) {
     const float p = param[i];
     if (pass == 0) {
       a += p * p;
