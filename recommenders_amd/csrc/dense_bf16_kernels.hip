@@ -301,6 +301,9 @@ __global__ __launch_bounds__(256, 2) void dense_bf16_kernel(GemmArgs g, float* _
 //     [pair of k][row] (pitch 136 words: the two halves of a wave read banks 32 apart), and a lane's fragment is 4
 //     words from 4 rows of that image instead of one 16-byte read.
 constexpr int kPitchT = 136;
+#ifndef XDFM_DENSE_REMAP
+#define XDFM_DENSE_REMAP 1
+#endif
 
 template <int MODE>
 __global__ __launch_bounds__(256, 2) void dense_bf16_v4_kernel(GemmArgs g, float* __restrict__ part) {
@@ -309,7 +312,22 @@ __global__ __launch_bounds__(256, 2) void dense_bf16_v4_kernel(GemmArgs g, float
   constexpr bool A_KFAST = MODE != kDw, B_KFAST = MODE == kDx;
   typedef float f4 __attribute__((ext_vector_type(4)));
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, r = lane & 31;
-  const int m0 = blockIdx.y * kBM, n0 = blockIdx.x * kBN;
+  // Workgroups go to the 8 XCDs round robin by linear id, and each XCD has its own L2.  With the column
+  // tile as the fast grid index, the 8 column tiles that share a row tile's operand land on 8 different
+  // XCDs and every XCD pulls the whole row operand through the fabric (counters: half of the L2 requests
+  // missed, 3.6 x the operands' bytes fetched).  Remapped: XCD k works on the k-th eighth of the tiles in
+  // row-major order, so a row tile's column tiles share one L2.
+  int tx = blockIdx.x, ty = blockIdx.y;
+  {
+    const unsigned tiles = gridDim.x * gridDim.y;
+    if (XDFM_DENSE_REMAP && (tiles & 7u) == 0) {
+      const unsigned lin = blockIdx.x + gridDim.x * blockIdx.y;
+      const unsigned t = (lin & 7u) * (tiles >> 3) + (lin >> 3);
+      ty = (int)(t / gridDim.x);
+      tx = (int)(t - (unsigned)ty * gridDim.x);
+    }
+  }
+  const int m0 = ty * kBM, n0 = tx * kBN;
   const int split = blockIdx.z;
   const int k_lo = split * g.r_per_split;
   int k_hi = k_lo + g.r_per_split;
