@@ -266,6 +266,7 @@ def test_bf16_dense_products_against_fp64(B, K, N, act):
     (5, 6, 6, 8, 20, 34, 1), (7, 6, 20, 16, 40, 40, 0), (33, 39, 39, 64, 128, 256, 1), (33, 39, 128, 64, 128, 256, 0),
     (300, 5, 33, 10, 70, 70, 0), (64, 39, 128, 64, 128, 256, 0), (700, 39, 128, 64, 128, 128, 0),
     (512, 10, 64, 32, 128, 128, 0), (700, 39, 39, 64, 128, 128, 1), (256, 20, 20, 32, 70, 70, 1), (96, 64, 64, 16, 40, 40, 1),
+    (128, 6, 6, 8, 20, 34, 1), (64, 2, 2, 64, 128, 128, 1),
 ])
 def test_bf16_cin_layer_kernels_against_fp64(B, F, H, D, L, Lfull, masked):
     """xdfm_cin_bf16_fwd / bwd_dx / bwd_dw through the C ABI on their own (a layer's L hidden channels
@@ -275,7 +276,7 @@ def test_bf16_cin_layer_kernels_against_fp64(B, F, H, D, L, Lfull, masked):
     D = 32 (a chunk spans two samples) and a 64 x 128 tile.  The masked cases with B*D a multiple of 64
     take the filter gradient whose rows are the pairs f < h: 741 pairs in two blocks per split (39
     fields), 190 pairs and channel tiles not filled (20 fields, 70 channels), the most fields it serves
-    (64: 2016 pairs, six blocks per split)."""
+    (64: 2016 pairs, six blocks per split), one channel tile (20 channels), a single pair (2 fields)."""
     lib = _lib.lib
     g = torch.Generator(device="cuda").manual_seed(B + H)
     x0 = torch.randn(B, F, D, device="cuda", generator=g)
